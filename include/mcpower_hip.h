@@ -1,0 +1,318 @@
+/*
+ * mcpower_hip.h -- C ABI of the MI355X-native Monte-Carlo power engine.
+ *
+ * This is the drop-in boundary for ONE path of pawlenartowicz/MCPower:
+ * `engine-core`'s simulate loop.  The reference exposes that path only as a
+ * Rust API (`engine-core` is an rlib with `#![forbid(unsafe_code)]`,
+ * crates/engine-core/Cargo.toml:12-13), so every entry point below cites the
+ * Rust item it replaces; INTEGRATION.md shows the `extern "C"` block a
+ * maintainer adds on the Rust side.
+ *
+ *   reference item                                  (file:line)               C entry point
+ *   ----------------------------------------------  ------------------------  -------------------------
+ *   run_batch(spec, sample_sizes, n_sims, seed,     batch.rs:130              mcp_run_batch
+ *             sink) -> Result<BatchResult,_>
+ *   run_batch_st (sequential, bit-identical)        batch.rs:157              mcp_run_batch (same result
+ *                                                                             by construction; the GPU
+ *                                                                             path has no thread order)
+ *   run_batch_st_capture (+ squared statistics)     batch.rs:180              mcp_run_batch + MCP_WANT_STAT_CAPTURE
+ *   set_n_threads(n)                                batch.rs:93               mcp_set_device
+ *   SimulationSpec                                  spec.rs:251-417           mcp_spec
+ *   ScenarioPerturbations                           spec.rs:118-237           mcp_scenario
+ *   ClusterSpec / ClusterSizing                     engine-contract/src/
+ *                                                   generation.rs:121-171     mcp_cluster
+ *   BatchResult / ResultShape                       spec.rs:535-600           mcp_batch_result
+ *   EngineError                                     spec.rs:20-29             mcp_status + mcp_last_error
+ *   ProgressSink::report / is_cancelled             spec.rs:38-52             mcp_progress_fn
+ *   aggregate_batch counters (what a multi-GPU      orchestrator/src/
+ *     merge pools)                                  aggregation.rs:61-330     mcp_counter_layout + counters[]
+ *   introspect::capture_sim0_data (debug: the       introspect.rs:104         mcp_generate_design
+ *     generated design/outcome of chosen sims)
+ *   introspect::fit_provided_data (debug: fit       introspect.rs:174         mcp_fit_design
+ *     caller-provided bytes with the shipped solver)
+ *
+ * Ownership: every pointer inside `mcp_spec` is borrowed and read-only for the
+ * duration of the call (the reference clones the spec, batch.rs:336).  Result
+ * buffers are allocated by the library and released with mcp_free_result.
+ *
+ * Threading: entry points are re-entrant; the only process-global state is the
+ * selected device (mcp_set_device) and a thread-local error string.
+ *
+ * Determinism: results are a pure function of
+ * (spec, sample_sizes, n_sims, base_seed, sim_offset) -- independent of the
+ * number of GPUs the replicate range is split over (batch.rs:2734-2752).
+ */
+#ifndef MCPOWER_HIP_H
+#define MCPOWER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCP_ABI_VERSION 1u
+
+/* ---- status codes (EngineError, spec.rs:20-29) --------------------------- */
+typedef enum mcp_status {
+  MCP_OK = 0,
+  MCP_ERR_INVALID_SPEC = 1,       /* EngineError::InvalidSpec(String)      */
+  MCP_ERR_CORRELATION_NOT_PSD = 2,/* EngineError::CorrelationNotPSD        */
+  MCP_ERR_RANK_DEFICIENT = 3,     /* EngineError::RankDeficient(u32)       */
+  MCP_ERR_CANCELLED = 4,          /* EngineError::Cancelled                */
+  MCP_ERR_UNSUPPORTED = 5,        /* valid spec, feature not on the device path yet: fails loudly, never falls back to a CPU path */
+  MCP_ERR_DEVICE = 6              /* HIP runtime error / no gfx950 device  */
+} mcp_status;
+
+/* ---- enums mirrored from engine-contract --------------------------------- */
+typedef enum mcp_distribution {   /* engine_contract::Distribution */
+  MCP_DIST_NORMAL = 0,
+  MCP_DIST_BINARY = 1,
+  MCP_DIST_RIGHT_SKEWED = 2,
+  MCP_DIST_LEFT_SKEWED = 3,
+  MCP_DIST_HIGH_KURTOSIS = 4,
+  MCP_DIST_UNIFORM = 5,
+  MCP_DIST_UPLOADED_DATA = 6,
+  MCP_DIST_UPLOADED_BINARY = 7,
+  MCP_DIST_UPLOADED_FACTOR = 8
+} mcp_distribution;
+
+typedef enum mcp_residual_dist {  /* engine_contract::ResidualDist */
+  MCP_RESID_NORMAL = 0,
+  MCP_RESID_HIGH_KURTOSIS = 1,
+  MCP_RESID_RIGHT_SKEWED = 2,
+  MCP_RESID_LEFT_SKEWED = 3,
+  MCP_RESID_UNIFORM = 4
+} mcp_residual_dist;
+
+typedef enum mcp_outcome_kind { MCP_OUTCOME_CONTINUOUS = 0, MCP_OUTCOME_BINARY = 1, MCP_OUTCOME_COUNT = 2 } mcp_outcome_kind;
+typedef enum mcp_link_kind { MCP_LINK_CANONICAL = 0, MCP_LINK_PROBIT = 1 } mcp_link_kind;
+typedef enum mcp_estimator { MCP_EST_OLS = 0, MCP_EST_GLM = 1, MCP_EST_MLE = 2 } mcp_estimator;
+typedef enum mcp_correction {     /* engine_contract::CorrectionMethod */
+  MCP_CORR_NONE = 0,
+  MCP_CORR_BONFERRONI = 1,
+  MCP_CORR_HOLM = 2,
+  MCP_CORR_BH = 3,
+  MCP_CORR_TUKEY_HSD = 4
+} mcp_correction;
+typedef enum mcp_cluster_sizing { MCP_CLUSTER_FIXED_CLUSTERS = 0, MCP_CLUSTER_FIXED_SIZE = 1 } mcp_cluster_sizing;
+
+/* ---- ScenarioPerturbations (spec.rs:118-176) ------------------------------ */
+typedef struct mcp_scenario {
+  double heterogeneity;
+  double heteroskedasticity_ratio;      /* 1.0 = off */
+  double correlation_noise_sd;
+  double distribution_change_prob;
+  const int32_t* new_distributions;     /* mcp_distribution menu */
+  uint32_t n_new_distributions;
+  double residual_change_prob;
+  const int32_t* residual_dists;        /* mcp_residual_dist menu */
+  uint32_t n_residual_dists;
+  double residual_df;
+  uint8_t sampled_factor_proportions;
+  uint8_t truth_start;
+  uint8_t has_lme;                      /* scenario.lme.is_some() */
+  uint8_t _pad0;
+  int32_t lme_random_effect_dist;       /* mcp_residual_dist */
+  double lme_random_effect_df;
+  double lme_icc_noise_sd;
+} mcp_scenario;
+
+/* ---- ClusterSpec (random intercept; slopes / extra groupings are reported
+ *      MCP_ERR_UNSUPPORTED on this path for now) --------------------------- */
+typedef struct mcp_cluster {
+  uint8_t present;                      /* spec.cluster.is_some() */
+  uint8_t _pad[3];
+  int32_t sizing;                       /* mcp_cluster_sizing */
+  uint32_t sizing_value;                /* n_clusters or cluster_size */
+  double tau_squared;
+  uint32_t n_slopes;                    /* must be 0 (unsupported otherwise) */
+  uint32_t n_extra_groupings;           /* must be 0 (unsupported otherwise) */
+} mcp_cluster;
+
+/* ---- SimulationSpec (spec.rs:251-417), field for field -------------------- */
+typedef struct mcp_spec {
+  uint32_t abi_version;                 /* MCP_ABI_VERSION */
+  uint32_t n_non_factor;
+  uint32_t n_factor_dummies;
+  const double* correlation;            /* n_non_factor^2, column-major */
+  const int32_t* var_types;             /* n_non_factor mcp_distribution */
+  const uint8_t* var_pinned;            /* n_var_pinned entries (may be 0) */
+  uint32_t n_var_pinned;
+  const double* var_params;             /* n_var_params entries */
+  uint32_t n_var_params;
+  const double* upload_normal;          /* (rows, cols) row-major */
+  uint32_t upload_normal_rows, upload_normal_cols;
+  const double* upload_data;
+  uint32_t upload_data_rows, upload_data_cols;
+  const int32_t* bootstrap_frame_map;   /* -1 = None */
+  uint32_t n_bootstrap_frame_map;
+  const uint32_t* between_var_indices;
+  uint32_t n_between_var_indices;
+  const int32_t* factor_n_levels;
+  uint32_t n_factors;
+  const double* factor_proportions;     /* sum(factor_n_levels) */
+  uint32_t n_factor_proportions;
+  const int8_t* factor_sampled;         /* -1 inherit, 0 exact, 1 sampled */
+  uint32_t n_factor_sampled;
+  const double* effect_sizes;           /* 1 + n_non_factor + n_factor_dummies + n_interactions */
+  uint32_t n_effect_sizes;
+  const uint32_t* target_indices;
+  uint32_t n_target_indices;
+  const uint32_t* fit_columns;
+  uint32_t n_fit_columns;
+  const uint32_t* contrast_pairs;       /* 2 * n_contrast_pairs: (positive, negative) */
+  uint32_t n_contrast_pairs;
+  const uint32_t* interaction_components; /* CSR payload */
+  const uint32_t* interaction_offsets;  /* n_interactions + 1 */
+  uint32_t n_interactions;
+  int32_t correction_method;            /* mcp_correction */
+  double alpha;                         /* crit_values.alpha */
+  double posthoc_alpha;                 /* NaN = None */
+  int32_t heteroskedasticity_driver;    /* -1 = None (linear predictor) */
+  int32_t residual_dist;                /* mcp_residual_dist */
+  uint8_t residual_pinned;
+  uint8_t report_overall;
+  uint8_t _pad1[2];
+  int32_t outcome_kind;                 /* mcp_outcome_kind */
+  int32_t link;                         /* mcp_link_kind */
+  int32_t estimator;                    /* mcp_estimator */
+  double intercept;                     /* metadata only (spec.rs:367-371) */
+  const uint32_t* posthoc_factor_index; /* one per posthoc block */
+  const uint32_t* posthoc_target_offsets; /* n_posthoc + 1 */
+  const uint32_t* posthoc_target_indices;
+  uint32_t n_posthoc;
+  double max_failed_fraction;           /* evaluated by the caller */
+  uint32_t factor_min_level_count;
+  uint32_t _pad2;
+  mcp_cluster cluster;
+  mcp_scenario scenario;
+} mcp_spec;
+
+/* ---- counters: the additive reduction `aggregate_batch` performs
+ *      (orchestrator/src/aggregation.rs:84-284).  `counters` is a flat
+ *      uint64 vector; per sample-size index the block layout is given by
+ *      mcp_counter_layout (offsets relative to `n_idx * stride`).  This vector
+ *      is what ranks all-reduce (sum) over RCCL. ----------------------------- */
+typedef struct mcp_counter_layout {
+  uint32_t stride;          /* uint64 words per sample-size index */
+  uint32_t k_unc;           /* [n_targets] success counts, uncorrected */
+  uint32_t k_cor;           /* [n_targets] success counts, corrected */
+  uint32_t converged;       /* [1] */
+  uint32_t overall;         /* [1] (0 when report_overall is false) */
+  uint32_t hist_unc;        /* [n_targets + n_posthoc_contrasts + 1] joint-success histogram */
+  uint32_t hist_cor;        /* same */
+  uint32_t posthoc_unc;     /* [n_posthoc_contrasts] */
+  uint32_t posthoc_cor;     /* [n_posthoc_contrasts] */
+  uint32_t excl_sparse;     /* [n_factors] factor_excluded == 1 */
+  uint32_t excl_sep;        /* [n_factors] factor_excluded == 2 */
+  uint32_t joint_unc;       /* [1] Mle joint Wald chi2 */
+  uint32_t joint_cor;       /* [1] */
+  uint32_t boundary_1;      /* [1] boundary_hit == 1 */
+  uint32_t boundary_2;      /* [1] boundary_hit == 2 */
+  uint32_t n_sims;          /* [1] replicates folded into this block */
+} mcp_counter_layout;
+
+/* ---- BatchResult (spec.rs:553-600) --------------------------------------- */
+typedef struct mcp_batch_result {
+  /* ResultShape */
+  uint32_t n_sims, n_sample_sizes, n_targets, n_factors;
+  uint32_t n_posthoc_contrasts, n_variance_components;
+  /* sim-major tensors; NULL when MCP_WANT_PER_SIM is not requested */
+  uint8_t* uncorrected;        /* (n_sims, n_ss, n_targets) */
+  uint8_t* corrected;
+  uint8_t* posthoc_unc;        /* (n_sims, n_ss, n_posthoc_contrasts) or NULL */
+  uint8_t* posthoc_cor;
+  uint8_t* converged;          /* (n_sims, n_ss) */
+  uint8_t* boundary_hit;
+  uint64_t* pinned_components;
+  uint8_t* joint_unc;
+  uint8_t* joint_cor;
+  uint8_t* overall;            /* NULL unless spec.report_overall */
+  uint8_t* factor_excluded;    /* (n_sims, n_ss, n_factors) or NULL */
+  double* tau_squared_hat;     /* NaN except GLMM fits */
+  double* stat_capture;        /* (n_sims, n_targets) squared statistics at grid point 0, NaN if not converged; NULL unless MCP_WANT_STAT_CAPTURE */
+  /* reduced form: always filled */
+  uint64_t* counters;          /* n_sample_sizes * layout.stride */
+  mcp_counter_layout layout;
+  /* timing of the device work inside the call (HIP events on the launch stream) */
+  double device_ms;            /* all kernels of the call */
+  double kernel_ms;            /* dominant (simulate) kernel only */
+  uint32_t n_kernel_launches;
+  uint32_t _pad;
+} mcp_batch_result;
+
+/* progress / cancel: ProgressSink::report(current,total)->bool (spec.rs:41);
+ * return 0 to cancel.  Called from the host thread between device chunks. */
+typedef int (*mcp_progress_fn)(uint64_t current, uint64_t total, void* user);
+
+/* option bits */
+#define MCP_WANT_PER_SIM      0x1u   /* fill the sim-major u8 tensors (BatchResult parity) */
+#define MCP_WANT_STAT_CAPTURE 0x2u   /* run_batch_st_capture (batch.rs:180) */
+#define MCP_PIPELINE_STAGED   0x4u   /* generator -> HBM design -> fit kernels instead of the fused kernel */
+
+typedef struct mcp_run_options {
+  uint32_t flags;
+  uint32_t chunk_sims;       /* replicates per device launch; 0 = library default */
+  uint64_t sim_offset;       /* first sim_id of this call: this rank's shard is [sim_offset, sim_offset + n_sims) */
+  void* hip_stream;          /* hipStream_t to launch on; NULL = the library's own stream */
+} mcp_run_options;
+
+/* ---- entry points --------------------------------------------------------- */
+
+/* ABI version of the loaded library. */
+uint32_t mcp_abi_version(void);
+
+/* Thread-local message of the last non-OK status on this thread. */
+const char* mcp_last_error(void);
+
+/* Select the HIP device used by subsequent calls of this process (replaces
+ * batch.rs:93 set_n_threads: one process per GPU). */
+int mcp_set_device(int device_index);
+
+/* Number of visible HIP devices (0 when there is none). */
+int mcp_device_count(void);
+
+/* run_batch / run_batch_st / run_batch_st_capture (batch.rs:130,157,180).
+ * `sample_sizes` strictly increasing, [0] > 0 (batch.rs:236-253).
+ * On MCP_OK `*out` is filled and must be released with mcp_free_result. */
+int mcp_run_batch(const mcp_spec* spec, const uint32_t* sample_sizes, uint32_t n_sample_sizes,
+                  uint32_t n_sims, uint64_t base_seed, const mcp_run_options* opts,
+                  mcp_progress_fn progress, void* progress_user, mcp_batch_result* out);
+
+void mcp_free_result(mcp_batch_result* r);
+
+/* Host-only part of run_batch (no device): validation (batch.rs:208-330) and
+ * the critical-value table (critvals.rs:827-1012).  `crit_out` receives, per
+ * sample size, [t_crit_sq_uncorrected, correction_t_crit_sq[0..n_targets),
+ * posthoc_t_crit_sq, joint_t_crit_sq, overall_crit] = n_targets + 4 doubles. */
+int mcp_build_crit_table(const mcp_spec* spec, const uint32_t* sample_sizes, uint32_t n_sample_sizes,
+                         double* crit_out);
+
+/* Scalar quantile functions of critvals.rs (t_ppf :211, norm_ppf :33,
+ * chi2_ppf :356, f_ppf :450), exported so hosts can reuse the exact thresholds. */
+double mcp_t_ppf(double p, double df);
+double mcp_norm_ppf(double p);
+double mcp_chi2_ppf(double p, double k);
+double mcp_f_ppf(double p, double dfn, double dfd);
+
+/* introspect::capture_sim0_data (introspect.rs:104) generalised to a range of
+ * replicates: writes the generated design (column-major f32, max_n x p per
+ * replicate, replicate-major) and outcome (max_n f32 per replicate) of
+ * sim_id in [sim_offset, sim_offset + n_sims) into caller-provided HOST buffers. */
+int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, uint64_t base_seed,
+                        uint64_t sim_offset, float* design_out, float* outcome_out);
+
+/* introspect::fit_provided_data (introspect.rs:174) for the OLS arm: fit
+ * caller-provided designs on the device with the shipped solver.
+ * design: n_fits x (p columns x n rows) column-major f32; outcome: n_fits x n.
+ * Outputs per fit: beta[p], se[p], t_sq[p], rss, sst, converged. */
+int mcp_fit_design(const float* design, const float* outcome, uint32_t n_fits, uint32_t n, uint32_t p,
+                   double* beta_out, double* se_out, double* t_sq_out, double* rss_out, double* sst_out,
+                   uint8_t* converged_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPOWER_HIP_H */

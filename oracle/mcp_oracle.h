@@ -1,0 +1,100 @@
+/*
+ * mcp_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's simulate loop
+ * (pawlenartowicz/MCPower, crates/engine-core) used only as the checker for the
+ * HIP path: by tests/, by __graft_entry__.smoke() and by bench.py's
+ * cpu_baseline leg.  Nothing under mcpower_amd/ may include, link or call it.
+ *
+ * It shares the POD layouts of include/mcpower_hip.h (mcp_spec,
+ * mcp_batch_result) so a test can hand the same spec to both sides; it shares
+ * no code with the product.
+ *
+ * Parity pins (see oracle/README.md):
+ *   RNG / uniform / normal / categorical / scenario stream -- bit-exact against
+ *     crates/engine-core/tests/{rng_byte_identity.rs,golden_rng.rs};
+ *   full DGP (design + outcome)  -- bit-exact against validation/data/NAME.rds
+ *     (introspect::capture_sim0_data output) for OLS / logit / LME cases;
+ *   OLS fit + critical values    -- 1e-11 rel / 1e-9 abs against NAME.golden.rds
+ *     (R lm / qt on the same bytes).
+ */
+#ifndef MCP_ORACLE_H
+#define MCP_ORACLE_H
+
+#include <stdint.h>
+#include "../include/mcpower_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- RNG primitives (rng.rs:22-38, rand_philox 0.1.0) -------------------- */
+uint64_t mcpo_splitmix64(uint64_t z);
+uint64_t mcpo_pcg_mix64(uint64_t base_seed, uint64_t sim_id);
+void mcpo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+float mcpo_u32_to_unit_f32(uint32_t w);
+float mcpo_norm_inv_cdf_f32(float u);
+
+/* sequential SimRng (rng.rs:51-128) */
+typedef struct mcpo_simrng {
+  uint32_t key[2];
+  uint64_t counter;
+  uint32_t buf[4];
+  uint32_t buf_pos;
+} mcpo_simrng;
+void mcpo_simrng_new(mcpo_simrng* r, uint64_t base_seed, uint64_t sim_id);
+uint32_t mcpo_simrng_next_u32(mcpo_simrng* r);
+float mcpo_simrng_next_uniform(mcpo_simrng* r);
+float mcpo_simrng_next_normal(mcpo_simrng* r);
+uint32_t mcpo_simrng_next_categorical(mcpo_simrng* r, const double* probs, uint32_t n);
+
+/* planar fills (rng.rs:154-261) */
+void mcpo_fill_words(const uint32_t key[2], uint32_t cls, uint32_t col, uint32_t* out, uint32_t n);
+void mcpo_fill_uniform_column(const uint32_t key[2], uint32_t cls, uint32_t col, float* out, uint32_t n);
+void mcpo_fill_normal_column(const uint32_t key[2], uint32_t cls, uint32_t col, float* out, uint32_t n);
+
+/* golden-test helpers: n draws of one stream kind for (base_seed, sim_id);
+ * kind 0 = next_normal, 1 = next_uniform, 2 = scenario_rng next_uniform */
+void mcpo_stream_f32(uint64_t base_seed, uint64_t sim_id, int kind, float* out, uint32_t n);
+void mcpo_stream_categorical(uint64_t base_seed, uint64_t sim_id, const double* probs, uint32_t n_probs,
+                             uint32_t* out, uint32_t n);
+
+/* distributions.rs:32-97 (libm exp in place of glmm's owned exp: <= 2^-52 abs on phi) */
+double mcpo_phi(double z);
+double mcpo_marginal_uniform(double z, double a, double b);
+
+/* ---- critical values (critvals.rs) --------------------------------------- */
+double mcpo_norm_ppf(double p);
+double mcpo_t_ppf(double p, double df);
+double mcpo_chi2_ppf(double p, double k);
+double mcpo_f_ppf(double p, double dfn, double dfd);
+/* per sample size: [t_crit_sq_unc, correction[0..n_targets), posthoc, joint, overall] */
+int mcpo_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, double* out);
+
+/* correction.rs:16-92 */
+void mcpo_apply_correction(int method, const double* t_sq, uint32_t t, double crit_unc,
+                           const double* crit_sq, uint8_t* out);
+
+/* ---- DGP (data_gen.rs:87-925) --------------------------------------------
+ * x_out: max_n x p column-major f32; y_out: max_n f32; cluster_ids_out may be NULL. */
+int mcpo_generate_sim_data(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, uint32_t max_n,
+                           float* x_out, float* y_out, uint32_t* cluster_ids_out);
+
+/* ---- OLS fit on provided bytes (glmm fit_suff_stats_t_sq, inferred from
+ *      batch.rs:958-1142, posthoc.rs:62-99, introspect.rs:280-284) ----------- */
+int mcpo_ols_fit(const float* x_colmajor, const float* y, uint32_t n_rows, uint32_t ld, uint32_t p,
+                 double* beta, double* se, double* t_sq, double* rss, double* sst, uint8_t* converged);
+
+/* ---- run_batch (batch.rs:199-776) ----------------------------------------
+ * Same contract as mcp_run_batch; `n_threads` >= 1 splits the replicate range
+ * over pthreads (results identical for any thread count). */
+int mcpo_run_batch(const mcp_spec* spec, const uint32_t* sample_sizes, uint32_t n_sample_sizes,
+                   uint32_t n_sims, uint64_t base_seed, const mcp_run_options* opts, uint32_t n_threads,
+                   mcp_batch_result* out);
+void mcpo_free_result(mcp_batch_result* r);
+const char* mcpo_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""ctypes binding of the CPU ORACLE (`oracle/_build/libmcp_oracle.so`).
+
+TEST INFRASTRUCTURE ONLY -- a plain-C restatement of the reference's simulate
+loop (see the headers of oracle/*.c for the reference file:line each function
+follows).  It is the checker for the HIP path; it is never the thing shipped
+or measured, and nothing under `mcpower_amd/` imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from mcpower_amd import spec as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmcp_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.mcpo_splitmix64.restype = C.c_uint64
+        L.mcpo_splitmix64.argtypes = [C.c_uint64]
+        L.mcpo_pcg_mix64.restype = C.c_uint64
+        L.mcpo_pcg_mix64.argtypes = [C.c_uint64, C.c_uint64]
+        L.mcpo_u32_to_unit_f32.restype = C.c_float
+        L.mcpo_u32_to_unit_f32.argtypes = [C.c_uint32]
+        L.mcpo_norm_inv_cdf_f32.restype = C.c_float
+        L.mcpo_norm_inv_cdf_f32.argtypes = [C.c_float]
+        for name in ("mcpo_norm_ppf",):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double]
+        for name in ("mcpo_t_ppf", "mcpo_chi2_ppf"):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double, C.c_double]
+        L.mcpo_f_ppf.restype = C.c_double
+        L.mcpo_f_ppf.argtypes = [C.c_double] * 3
+        L.mcpo_phi.restype = C.c_double
+        L.mcpo_phi.argtypes = [C.c_double]
+        L.mcpo_marginal_uniform.restype = C.c_double
+        L.mcpo_marginal_uniform.argtypes = [C.c_double] * 3
+        L.mcpo_last_error.restype = C.c_char_p
+        L.mcpo_run_batch.restype = C.c_int
+        L.mcpo_run_batch.argtypes = [C.POINTER(S.CSpec), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint64,
+                                     C.POINTER(S.CRunOptions), C.c_uint32, C.POINTER(S.CBatchResult)]
+        L.mcpo_free_result.argtypes = [C.POINTER(S.CBatchResult)]
+        L.mcpo_generate_sim_data.restype = C.c_int
+        L.mcpo_build_crit_table.restype = C.c_int
+        L.mcpo_ols_fit.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise S.EngineError(rc, (lib().mcpo_last_error() or b"").decode() or f"oracle status {rc}")
+
+
+def splitmix64(z: int) -> int:
+    return lib().mcpo_splitmix64(C.c_uint64(z & (2**64 - 1)))
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().mcpo_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def u32_to_unit_f32_bits(w: int) -> int:
+    return int(np.float32(lib().mcpo_u32_to_unit_f32(w)).view(np.uint32))
+
+
+def norm_inv_cdf_f32(u: np.ndarray) -> np.ndarray:
+    f = lib().mcpo_norm_inv_cdf_f32
+    return np.array([f(float(x)) for x in np.asarray(u, dtype=np.float32)], dtype=np.float32)
+
+
+def stream_f32(base_seed: int, sim_id: int, kind: str, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.float32)
+    k = {"normal": 0, "uniform": 1, "scenario_uniform": 2}[kind]
+    lib().mcpo_stream_f32(C.c_uint64(base_seed), C.c_uint64(sim_id), C.c_int(k),
+                          out.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(n))
+    return out
+
+
+def stream_categorical(base_seed: int, sim_id: int, probs, n: int) -> np.ndarray:
+    p = np.ascontiguousarray(probs, dtype=np.float64)
+    out = np.zeros(n, dtype=np.uint32)
+    lib().mcpo_stream_categorical(C.c_uint64(base_seed), C.c_uint64(sim_id), p.ctypes.data_as(C.POINTER(C.c_double)),
+                                  C.c_uint32(p.size), out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(n))
+    return out
+
+
+def fill_normal_column(key, cls: int, col: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.float32)
+    k = (C.c_uint32 * 2)(*key)
+    lib().mcpo_fill_normal_column(k, C.c_uint32(cls), C.c_uint32(col), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                  C.c_uint32(n))
+    return out
+
+
+def t_ppf(p, df):
+    return lib().mcpo_t_ppf(p, df)
+
+
+def norm_ppf(p):
+    return lib().mcpo_norm_ppf(p)
+
+
+def chi2_ppf(p, k):
+    return lib().mcpo_chi2_ppf(p, k)
+
+
+def f_ppf(p, dfn, dfd):
+    return lib().mcpo_f_ppf(p, dfn, dfd)
+
+
+def phi(z):
+    return lib().mcpo_phi(z)
+
+
+def generate_sim_data(spec: S.SimulationSpec, base_seed: int, sim_id: int, max_n: int):
+    """(design (max_n, p) f32 Fortran-ordered view, outcome (max_n,) f32, cluster_ids or None)."""
+    low = spec.to_c()
+    p = spec.n_predictors
+    x = np.zeros((p, max_n), dtype=np.float32)  # column-major max_n x p
+    y = np.zeros(max_n, dtype=np.float32)
+    ids = np.zeros(max_n, dtype=np.uint32)
+    rc = lib().mcpo_generate_sim_data(low.byref(), C.c_uint64(base_seed), C.c_uint64(sim_id), C.c_uint32(max_n),
+                                      x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                                      ids.ctypes.data_as(C.POINTER(C.c_uint32)))
+    _check(rc)
+    return x.T, y, (ids if spec.cluster is not None else None)
+
+
+def build_crit_table(spec: S.SimulationSpec, sample_sizes) -> np.ndarray:
+    low = spec.to_c()
+    ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
+    out = np.zeros((ns.size, spec.n_targets + 4), dtype=np.float64)
+    rc = lib().mcpo_build_crit_table(low.byref(), ns.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(ns.size),
+                                     out.ctypes.data_as(C.POINTER(C.c_double)))
+    _check(rc)
+    return out
+
+
+def ols_fit(design: np.ndarray, outcome: np.ndarray):
+    """OLS on provided bytes: design (n, p), outcome (n,). Returns dict(beta, se, t_sq, rss, sst, converged)."""
+    n, p = design.shape
+    x = np.ascontiguousarray(design.T, dtype=np.float32)
+    y = np.ascontiguousarray(outcome, dtype=np.float32)
+    beta, se, tsq = (np.zeros(p) for _ in range(3))
+    rss, sst, conv = C.c_double(), C.c_double(), C.c_uint8()
+    pd = C.POINTER(C.c_double)
+    rc = lib().mcpo_ols_fit(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                            C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), beta.ctypes.data_as(pd), se.ctypes.data_as(pd),
+                            tsq.ctypes.data_as(pd), C.byref(rss), C.byref(sst), C.byref(conv))
+    _check(rc)
+    return dict(beta=beta, se=se, t_sq=tsq, rss=rss.value, sst=sst.value, converged=bool(conv.value))
+
+
+def run_batch(spec: S.SimulationSpec, sample_sizes, n_sims: int, base_seed: int, *, sim_offset: int = 0,
+              stat_capture: bool = False, n_threads: int = 1) -> S.BatchResult:
+    """Oracle twin of `mcpower_amd.engine.run_batch` (reference batch.rs:130)."""
+    low = spec.to_c()
+    ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
+    opts = S.CRunOptions()
+    opts.flags = S.WANT_PER_SIM | (S.WANT_STAT_CAPTURE if stat_capture else 0)
+    opts.sim_offset = sim_offset
+    res = S.CBatchResult()
+    rc = lib().mcpo_run_batch(low.byref(), ns.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(ns.size),
+                              C.c_uint32(n_sims), C.c_uint64(base_seed), C.byref(opts), C.c_uint32(n_threads),
+                              C.byref(res))
+    _check(rc)
+    try:
+        return S.result_from_c(res)
+    finally:
+        lib().mcpo_free_result(C.byref(res))

@@ -1,0 +1,57 @@
+/* oracle_internal.h -- CPU ORACLE (test infrastructure): shared internals. */
+#ifndef MCP_ORACLE_INTERNAL_H
+#define MCP_ORACLE_INTERNAL_H
+#include <stdint.h>
+#include "mcp_oracle.h"
+
+#define MCPO_MAX_K 16      /* continuous predictors */
+#define MCPO_MAX_P 40      /* design columns */
+#define MCPO_MAX_LEVELS 64 /* sum of factor levels */
+
+typedef struct mcpo_ws {
+  float* x;          /* max_n x p, column-major */
+  float* y;          /* max_n */
+  float* z;          /* max_n x k planar normals */
+  float* resid;      /* max_n */
+  float* resid_g;    /* max_n */
+  double* acc;       /* max_n (mix_acc) */
+  double* eta;       /* max_n (eta_acc) */
+  float* cluster_u;  /* cap_clusters */
+  uint32_t* cluster_ids;
+  uint32_t cap_clusters;
+} mcpo_ws;
+
+mcpo_ws* mcpo_ws_new(uint32_t max_n, uint32_t p, uint32_t k, uint32_t cap_clusters);
+void mcpo_ws_free(mcpo_ws* ws);
+int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, uint32_t max_n, mcpo_ws* ws);
+int mcpo_chol_colmajor(double* a, uint32_t k);
+int mcpo_spec_supported(const mcp_spec* spec);
+uint32_t mcpo_cluster_of_row(const mcp_cluster* c, uint32_t i);
+uint32_t mcpo_n_clusters_at(const mcp_cluster* c, uint32_t n);
+void mcpo_compute_het_coeffs(const mcp_spec* spec, double* lp_mean, double* lp_std, double* col_mean, double* col_std);
+
+/* OLS sufficient statistics + fit (fit_ols.c) */
+typedef struct mcpo_olsfit_t {
+  uint32_t p;
+  int converged;
+  double beta[MCPO_MAX_P];
+  double L[MCPO_MAX_P * MCPO_MAX_P]; /* row-major lower Cholesky factor of X'X */
+  double sigma_sq, rss, sst, df_resid;
+} mcpo_olsfit_t;
+
+typedef struct mcpo_suff {
+  uint32_t p;
+  double xtx[MCPO_MAX_P * MCPO_MAX_P]; /* row-major, lower triangle valid */
+  double xty[MCPO_MAX_P];
+  double yty, sum_y;
+  uint64_t n_rows;
+} mcpo_suff;
+
+void mcpo_suff_reset(mcpo_suff* s, uint32_t p);
+void mcpo_suff_add_rows(mcpo_suff* s, const float* x, const float* y, uint32_t ld, uint32_t from, uint32_t to);
+void mcpo_fit_suff(const mcpo_suff* s, mcpo_olsfit_t* fit);
+/* squared statistic of c'beta; NaN when not well formed (posthoc.rs:86-99) */
+double mcpo_contrast_t_sq(const mcpo_olsfit_t* fit, const double* c);
+
+void mcpo_set_error(const char* fmt, ...);
+#endif

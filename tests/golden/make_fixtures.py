@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ from the DATA the
+reference's own tests hold.  Run in the build container (needs /root/reference);
+the GPU box never sees the reference, only the small files this writes.
+
+Sources (all data, no code):
+  * crates/engine-core/tests/rng_byte_identity.rs:18-50   Philox / splitmix64 / uniform KATs
+  * crates/engine-core/tests/golden_rng.rs:37-235          64-draw stream goldens, phi, marginal_uniform
+  * crates/engine-core/src/critvals.rs:1807-1926           quantile known answers (hand-copied table below)
+  * validation/data/<case>.rds + <case>.golden.rds         sim-0 design/outcome bytes (introspect::capture_sim0_data)
+                                                           and R lm/glm/lme4 fits of the same bytes
+Each per-case fixture stores the *kernel-level* spec the case lowers to
+(contract_adapter.rs column layout: [intercept | continuous | factor dummies |
+interactions]) so tests can rebuild a SimulationSpec
+without parsing formulas on the GPU box.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from rds_reader import read_rds, to_py  # noqa: E402
+
+REF = "/root/reference"
+
+
+# ---------------------------------------------------------------------------
+# 1. RNG known answers: pull the hex tables out of the Rust test sources
+# ---------------------------------------------------------------------------
+def _rust_array(src: str, name: str):
+    m = re.search(r"const\s+" + name + r"\s*:\s*\[[^\]]*\]\s*=\s*\[(.*?)\];", src, re.S)
+    if not m:
+        raise KeyError(name)
+    body = re.sub(r"//[^\n]*", "", m.group(1))
+    vals = []
+    for tok in body.replace("\n", " ").split(","):
+        tok = tok.strip().replace("_", "")
+        if not tok:
+            continue
+        if tok.lower().startswith("0x"):
+            vals.append(int(tok, 16))
+        else:
+            vals.append(float(tok) if ("." in tok or "e" in tok.lower()) else int(tok))
+    return vals
+
+
+def make_rng_kat():
+    g = open(f"{REF}/crates/engine-core/tests/golden_rng.rs").read()
+    kat = {
+        "source": "crates/engine-core/tests/{rng_byte_identity.rs,golden_rng.rs}",
+        "philox": [
+            {"ctr": [0, 0, 0, 0], "key": [0, 0], "out": [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]},
+            {"ctr": [0xFFFFFFFF] * 4, "key": [0xFFFFFFFF] * 2, "out": [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]},
+            {"ctr": [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], "key": [0xA4093822, 0x299F31D0],
+             "out": [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]},
+        ],
+        "splitmix64": [[0, 0], [1, 0x5692161D100B05E5], [0x0123456789ABCDEF, 0xB2C058E4EBB5112C],
+                       [0xFFFFFFFFFFFFFFFF, 0xB4D055FCF2CBBD7B]],
+        "u32_to_unit_f32_bits": [[0, 0x33800000], [0xFFFFFFFF, 0x3F7FFFFF], [0x9E3779B9, 0x3F1E3779]],
+        # golden_rng.rs: normals seed (42, sim 0), uniforms (42, 1), categoricals (42, 2) probs [.2,.3,.5],
+        # scenario uniforms (42, 0)
+        "normals_seed42_sim0_bits": _rust_array(g, "GOLDEN_NORMALS"),
+        "uniforms_seed42_sim1_bits": _rust_array(g, "GOLDEN_UNIFORMS"),
+        "categoricals_seed42_sim2": _rust_array(g, "GOLDEN_CATEGORICALS"),
+        "categorical_probs": [0.2, 0.3, 0.5],
+        "scenario_uniforms_seed42_sim0_bits": _rust_array(g, "GOLDEN_SCENARIO_U32S"),
+        "z_grid": _rust_array(g, "Z_GRID"),
+        "phi_bits": _rust_array(g, "GOLDEN_PHI"),
+        "marginal_uniform_bits": _rust_array(g, "GOLDEN_MARGINAL_UNIFORM"),
+    }
+    # confirm the seeds used by the golden tests (data, read from the test bodies)
+    assert "SimRng::new(42, 0)" in g and "SimRng::new(42, 1)" in g and "SimRng::new(42, 2)" in g, "golden seeds moved"
+    with open(os.path.join(HERE, "rng_kat.json"), "w") as fh:
+        json.dump(kat, fh, indent=1)
+    print("rng_kat.json", {k: (len(v) if isinstance(v, list) else v) for k, v in kat.items()})
+
+
+# ---------------------------------------------------------------------------
+# 2. validation cases: formula -> kernel spec
+# ---------------------------------------------------------------------------
+def _parse_kv(s: str):
+    out = {}
+    for part in re.split(r",\s*(?![^()]*\))", s):
+        part = part.strip()
+        if not part:
+            continue
+        k, v = part.split("=", 1)
+        out[k.strip()] = v.strip()
+    return out
+
+
+def lower_case(spec: dict, columns):
+    """Lower the readable case description to the kernel layout."""
+    one = lambda v: v[0] if isinstance(v, (list, np.ndarray)) and len(v) == 1 else v
+    formula = one(spec["formula"])
+    family = one(spec["family"])
+    rhs = formula.split("~", 1)[1]
+    rhs = re.sub(r"\+\s*\([^)]*\)", "", rhs).strip()  # drop (1|grp)
+    # variables + factor declarations
+    vt = spec.get("variable_types")
+    vts = [vt] if isinstance(vt, str) else (list(vt) if vt is not None else [])
+    factors = {}
+    for entry in vts:
+        for name, val in _parse_kv(entry).items():
+            m = re.match(r"\(factor,\s*(.*)\)", val)
+            if m:
+                factors[name] = [float(x) for x in m.group(1).split(",")]
+    terms = [t.strip() for t in rhs.split("+")]
+    mains, inters = [], []
+    for t in terms:
+        if "*" in t:
+            a, b = [x.strip() for x in t.split("*")]
+            for v in (a, b):
+                if v not in mains:
+                    mains.append(v)
+            inters.append((a, b))
+        elif ":" in t:
+            a, b = [x.strip() for x in t.split(":")]
+            inters.append((a, b))
+        elif t not in mains:
+            mains.append(t)
+    cont = [v for v in mains if v not in factors]
+    facs = [v for v in mains if v in factors]
+    k = len(cont)
+    col_of = {v: 1 + i for i, v in enumerate(cont)}
+    dummy_cols = {}
+    c = 1 + k
+    factor_n_levels, factor_props = [], []
+    for f in facs:
+        nl = len(factors[f])
+        factor_n_levels.append(nl)
+        factor_props.extend(factors[f])
+        for lvl in range(2, nl + 1):
+            dummy_cols[(f, lvl)] = c
+            c += 1
+    n_fd = c - 1 - k
+    interactions, inter_names = [], []
+    for a, b in inters:
+        a_cols = [(a, col_of[a])] if a in col_of else [(f"{a}[{l}]", dummy_cols[(a, l)]) for l in range(2, len(factors[a]) + 1)]
+        b_cols = [(b, col_of[b])] if b in col_of else [(f"{b}[{l}]", dummy_cols[(b, l)]) for l in range(2, len(factors[b]) + 1)]
+        for an, ac in a_cols:
+            for bn, bc in b_cols:
+                interactions.append([ac, bc])
+                inter_names.append(f"{an}:{bn}")
+    p = 1 + k + n_fd + len(interactions)
+    assert p == len(columns), (formula, p, columns)
+    eff = [0.0] * p
+    for name, val in _parse_kv(one(spec["effects"])).items():
+        v = float(val)
+        if ":" in name:
+            idx = 1 + k + n_fd + inter_names.index(name) if name in inter_names else None
+            if idx is None:  # 2-level factor named bare in the interaction
+                a, b = name.split(":")
+                cand = [i for i, nm in enumerate(inter_names) if nm.split(":")[0].split("[")[0] == a.split("[")[0]
+                        and nm.split(":")[1].split("[")[0] == b.split("[")[0]]
+                assert len(cand) == 1, name
+                idx = 1 + k + n_fd + cand[0]
+            eff[idx] = v
+        else:
+            m = re.match(r"(\w+)\[(\d+)\]", name)
+            if m:
+                eff[dummy_cols[(m.group(1), int(m.group(2)))]] = v
+            elif name in col_of:
+                eff[col_of[name]] = v
+            else:  # bare 2-level factor
+                eff[dummy_cols[(name, 2)]] = v
+    corr = np.eye(k)
+    cs = spec.get("correlations")
+    if cs is not None:
+        for m in re.finditer(r"corr\((\w+),\s*(\w+)\)\s*=\s*([-\d.]+)", one(cs)):
+            i, j = col_of[m.group(1)] - 1, col_of[m.group(2)] - 1
+            corr[i, j] = corr[j, i] = float(m.group(3))
+    out = dict(
+        family=family, n=int(one(spec["n"])), user_seed=int(one(spec["seed"])),
+        n_non_factor=k, n_factor_dummies=n_fd, correlation=corr.flatten(order="F").tolist(),
+        factor_n_levels=factor_n_levels, factor_proportions=factor_props, interactions=interactions,
+        effect_sizes=eff, formula=formula,
+    )
+    if family in ("logit", "probit"):
+        bp = float(one(spec["baseline_probability"]))
+        out["baseline_probability"] = bp
+        if family == "logit":
+            out["effect_sizes"][0] = math.log(bp / (1.0 - bp))
+    if "cluster" in spec and spec["cluster"] is not None:
+        cl = spec["cluster"]
+        icc = float(one(cl["ICC"]))
+        out["cluster"] = dict(n_clusters=int(one(cl["n_clusters"])), cluster_size=int(one(cl["cluster_size"])),
+                              icc=icc, tau_squared=icc / (1.0 - icc))
+    return out
+
+
+CASES = (
+    [f"ols_{n}" for n in ("simple_a", "simple_b", "two_a", "two_b", "zero_a", "corr_a", "corr_b", "factor_a",
+                          "factor_b", "ff_a", "ff_b", "interaction_a", "interaction_b", "cf_a", "cf_b")]
+    + [f"glm_{n}" for n in ("simple_a", "simple_b", "two_a", "two_b", "factor_a", "factor_b", "interaction_a",
+                            "interaction_b")]
+    + [f"lme_{n}" for n in ("simple_a", "simple_b", "two_a", "two_b", "factor_a", "factor_b", "interaction_a",
+                            "interaction_b")]
+)
+
+
+def make_cases():
+    index = {}
+    for name in CASES:
+        d = to_py(read_rds(f"{REF}/validation/data/{name}.rds"))
+        g = to_py(read_rds(f"{REF}/validation/data/{name}.golden.rds"))
+        low = lower_case(d["spec"], d["columns"])
+        design = np.asarray(d["design"], dtype=np.float64)
+        outcome = np.asarray(d["outcome"], dtype=np.float64)
+        # the reference's data plane is f32: the stored doubles must be exact f32 values
+        assert np.array_equal(design.astype(np.float32).astype(np.float64), design), name
+        assert np.array_equal(outcome.astype(np.float32).astype(np.float64), outcome), name
+        arrays = dict(
+            design=design.astype(np.float32), outcome=outcome.astype(np.float32),
+            golden_beta=np.asarray(g["beta"], dtype=np.float64), golden_se=np.asarray(g["se"], dtype=np.float64),
+            golden_stat=np.asarray(g["stat"], dtype=np.float64), golden_crit=np.asarray(g["crit"], dtype=np.float64),
+        )
+        if d.get("cluster_ids") is not None:
+            arrays["cluster_ids"] = np.asarray(d["cluster_ids"], dtype=np.int64)
+        for extra in ("vc", "theta", "sigma", "tau_squared"):
+            if extra in g and g[extra] is not None:
+                try:
+                    arrays["golden_" + extra] = np.asarray(g[extra], dtype=np.float64)
+                except Exception:
+                    pass
+        low["golden_keys"] = sorted(k for k in g.keys())
+        low["hash"] = d["hash"][0] if isinstance(d["hash"], list) else d["hash"]
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), spec_json=np.array(json.dumps(low)), **arrays)
+        index[name] = dict(n=low["n"], p=len(d["columns"]), family=low["family"])
+        print(name, design.shape, low["family"], "golden:", low["golden_keys"])
+    with open(os.path.join(HERE, "cases.json"), "w") as fh:
+        json.dump(index, fh, indent=1)
+
+
+# quantile known answers restated from crates/engine-core/src/critvals.rs tests (:1807-1926) are checked
+# against scipy in tests/test_oracle_critvals.py; the per-case `crit` goldens above pin t_ppf/norm_ppf to R.
+
+if __name__ == "__main__":
+    make_rng_kat()
+    make_cases()

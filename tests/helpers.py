@@ -1,0 +1,132 @@
+"""Shared test helpers: golden-case loading and frozen bench specs.
+
+The frozen specs restate the *inputs* of the reference's throughput cases
+(crates/engine-core/src/bin/throughput.rs:167-247, 268-321) and BASELINE.md's
+C1..C5 configurations.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import numpy as np
+
+from mcpower_amd import spec as S
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MASK64 = (1 << 64) - 1
+
+
+def splitmix64(z: int) -> int:
+    """Mix13 finalizer (host-side restatement used to derive base_seed = splitmix64(user_seed),
+    reference find_power.rs:259); pinned in tests against rng_kat.json."""
+    z &= MASK64
+    z ^= z >> 30
+    z = (z * 0xBF58476D1CE4E5B9) & MASK64
+    z ^= z >> 27
+    z = (z * 0x94D049BB133111EB) & MASK64
+    z ^= z >> 31
+    return z
+
+
+def load_kat():
+    with open(os.path.join(GOLDEN, "rng_kat.json")) as fh:
+        return json.load(fh)
+
+
+def case_names(family=None):
+    with open(os.path.join(GOLDEN, "cases.json")) as fh:
+        idx = json.load(fh)
+    return [k for k, v in idx.items() if family is None or v["family"] == family]
+
+
+def load_case(name):
+    """-> (SimulationSpec, base_seed, arrays dict, lowered-json dict)."""
+    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    low = json.loads(str(z["spec_json"]))
+    k = low["n_non_factor"]
+    p = 1 + k + low["n_factor_dummies"] + len(low["interactions"])
+    fam = low["family"]
+    spec = S.SimulationSpec(
+        n_non_factor=k,
+        n_factor_dummies=low["n_factor_dummies"],
+        correlation=low["correlation"],
+        var_types=[S.Distribution.Normal] * k,
+        var_params=[0.0] * k,
+        factor_n_levels=low["factor_n_levels"],
+        factor_proportions=low["factor_proportions"],
+        effect_sizes=low["effect_sizes"],
+        target_indices=list(range(1, p)),
+        interactions=low["interactions"],
+        outcome_kind=S.OutcomeKind.Binary if fam == "logit" else S.OutcomeKind.Continuous,
+        estimator={"ols": S.EstimatorSpec.Ols, "logit": S.EstimatorSpec.Glm, "lme": S.EstimatorSpec.Mle}[fam],
+        intercept=low["effect_sizes"][0],
+    )
+    if "cluster" in low:
+        spec.cluster = S.ClusterSpec(sizing=("FixedClusters", low["cluster"]["n_clusters"]),
+                                     tau_squared=low["cluster"]["tau_squared"])
+    base_seed = splitmix64(low["user_seed"])
+    arrays = {k2: z[k2] for k2 in z.files if k2 != "spec_json"}
+    return spec, base_seed, arrays, low
+
+
+# ---- frozen bench / parity specs (throughput.rs:167-321) ----
+def base_spec(k: int) -> S.SimulationSpec:
+    corr = np.eye(k).flatten().tolist()
+    return S.SimulationSpec(
+        n_non_factor=k, correlation=corr, var_types=[S.Distribution.Normal] * k, var_params=[0.0] * k,
+        effect_sizes=[0.0] * (1 + k), target_indices=[1, 2], max_failed_fraction=0.1,
+    )
+
+
+def spec_c1() -> S.SimulationSpec:
+    """C1: two-group t-test, n=100, p=2 (deterministic X, fixed allocation)."""
+    return S.SimulationSpec(
+        n_non_factor=0, n_factor_dummies=1, correlation=[], factor_n_levels=[2], factor_proportions=[0.5, 0.5],
+        effect_sizes=[0.0, 0.5], target_indices=[1],
+    )
+
+
+def spec_c2a() -> S.SimulationSpec:
+    """C2a: x1,x2,x3 + x1:x2 -> p=5, beta=(0,.18,.18,0,.10), targets [1,2,4]."""
+    s = base_spec(3)
+    s.interactions = [[1, 2]]
+    s.effect_sizes = [0.0, 0.18, 0.18, 0.0, 0.10]
+    s.target_indices = [1, 2, 4]
+    return s
+
+
+def spec_c2b() -> S.SimulationSpec:
+    """C2b: the reference's frozen `ols_multi` (throughput.rs:269-272): base_spec(5), x1=x2=0.18."""
+    s = base_spec(5)
+    s.effect_sizes[1] = 0.18
+    s.effect_sizes[2] = 0.18
+    return s
+
+
+def spec_c3() -> S.SimulationSpec:
+    """C3: glm_spec(3, 0.3): logit, beta0=ln(.3/.7), x1=x2=0.4, targets [1,2,3]."""
+    s = base_spec(3)
+    s.outcome_kind = S.OutcomeKind.Binary
+    s.estimator = S.EstimatorSpec.Glm
+    s.intercept = math.log(0.3 / 0.7)
+    s.effect_sizes = [s.intercept, 0.4, 0.4, 0.0]
+    s.target_indices = [1, 2, 3]
+    s.max_failed_fraction = 0.25
+    return s
+
+
+def spec_c4() -> S.SimulationSpec:
+    """C4: lme_spec(2, 30 clusters) at n=600, tau^2=0.25, x1=x2=0.15, truth_start."""
+    s = base_spec(2)
+    s.estimator = S.EstimatorSpec.Mle
+    s.cluster = S.ClusterSpec(sizing=("FixedClusters", 30), tau_squared=0.25)
+    s.effect_sizes = [0.0, 0.15, 0.15]
+    s.scenario = S.ScenarioPerturbations(name="optimistic", truth_start=True)
+    s.max_failed_fraction = 0.25
+    return s
+
+
+USER_SEED = 2137
+BASE_SEED = splitmix64(USER_SEED)  # find_power.rs:259
