@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- replicate-fits/sec of the simulate path on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE run_batch call (reference batch.rs:130) over a batch of 10^6 synthetic replicates
+per GPU at BASELINE.json configs[1] (OLS, n=200, p=5: x1,x2,x3 + x1:x2; C2a in BASELINE.md), all
+data generated in-kernel from Philox (there are no input tensors; the launch-constant block is
+resident in HBM before the timed region).  Replicates shard by sim_id range with the same
+base_seed (weak scaling: per-GPU work is fixed) and every step ends with the path's single
+collective: one all-reduce (sum) of the rejection counters over RCCL.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the dominant
+kernel of the timed region, `roofline_staged_fit` for the HBM-bound staged fit kernel, and
+`cpu_baseline` (the CPU oracle timed on this host's cores, a reported baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# chip constants: /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0          # HBM3E spec; ~6300 GB/s measured achievable
+PEAK_VALU_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s (= 157.3 TFLOP/s fp32 FMA / 2)
+
+# algorithmic work per replicate-fit
+WORKLOADS = {
+    # name: (spec factory, n, ops per fit for the fused kernel, staged bytes read per fit)
+    "c2a": ("spec_c2a", 200, 3.76e4, 4 * 200 * 5),   # x1,x2,x3,x1:x2,y stored: 5 f32 columns
+    "c2b": ("spec_c2b", 200, 5.26e4, 4 * 200 * 6),   # 5 predictors + y: the 4800 B of BASELINE.md
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2a", choices=sorted(WORKLOADS))
+    ap.add_argument("--sims-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--pipeline", default="fused", choices=["fused", "staged"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import helpers
+    from mcpower_amd import dist as mdist
+    from mcpower_amd import engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if engine.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    engine.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    fac, n_obs, ops_per_fit, bytes_per_fit = WORKLOADS[args.workload]
+    spec = getattr(helpers, fac)()
+    ns = [n_obs]
+    S = args.sims_per_gpu
+    staged = args.pipeline == "staged"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        # weak scaling: every rank simulates S new replicates per step; ids never repeat across steps
+        off = (i * world + rank) * S
+        r = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, sim_offset=off, staged=staged)
+        pooled = mdist.allreduce_counters(r.counters)
+        return r, pooled
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = aux_ms = 0.0
+    launches = 0
+    pooled = None
+    for i in range(args.steps):
+        r, pooled = step(args.warmup + i)
+        kernel_ms += r.kernel_ms
+        aux_ms += r.aux_kernel_ms
+        launches += r.n_kernel_launches
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_fits = float(S) * world * args.steps * len(ns)
+        value = total_fits / elapsed
+        nt = spec.n_targets
+        k_unc = pooled[0, r.layout["k_unc"]:r.layout["k_unc"] + nt].astype(np.float64)
+        n_pool = float(pooled[0, r.layout["n_sims"]])
+        avg_launch_ms = kernel_ms / max(launches, 1)          # HIP events on the launch stream (host_api.hip)
+        fits_per_launch = S / max(launches / args.steps, 1)
+        out = {
+            "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: OLS n={n_obs} p={spec.n_predictors} "
+                                   f"({'x1,x2,x3 + x1:x2' if args.workload == 'c2a' else 'ols_multi, 5 predictors'}), "
+                                   f"{S} replicates per GPU per step, seed 2137",
+                       "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
+                       "collective": "1 all-reduce(sum) of counters per step"},
+            "power_last_step": (k_unc / n_pool).round(5).tolist(),
+        }
+        if not staged:
+            ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "valu", "kernel": f"ols_sim_kernel<{spec.n_predictors},fused>",
+                               "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
+                               "traffic": None, "ops_per_fit": ops_per_fit, "avg_launch_ms": avg_launch_ms,
+                               "fits_per_launch": fits_per_launch,
+                               "note": "fused generate+fit: no design bytes touch HBM; bound is VALU/integer issue "
+                                       "(SURVEY.md 8d); HBM-equivalent rate in hbm_equiv_gbs",
+                               "hbm_equiv_gbs": bytes_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e9}
+            # the HBM-bound kernel of the path: staged fit over a resident design tile (measured outside the timed region)
+            rs = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, staged=True)
+            rs = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, staged=True)
+            fit_ms = rs.kernel_ms / rs.n_kernel_launches
+            fpl = S / rs.n_kernel_launches
+            gbs = bytes_per_fit * fpl / (fit_ms * 1e-3) / 1e9
+            out["roofline_staged_fit"] = {"bound": "hbm", "kernel": f"ols_sim_kernel<{spec.n_predictors},fit>",
+                                          "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": gbs / PEAK_HBM_GBS, "traffic": None, "bytes_per_fit": bytes_per_fit,
+                                          "avg_launch_ms": fit_ms, "generator_launch_ms": rs.aux_kernel_ms / rs.n_kernel_launches,
+                                          "fits_per_launch": fpl}
+        else:
+            gbs = bytes_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": f"ols_sim_kernel<{spec.n_predictors},fit>", "achieved": gbs,
+                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                               "bytes_per_fit": bytes_per_fit, "avg_launch_ms": avg_launch_ms,
+                               "generator_launch_ms": aux_ms / max(launches, 1), "fits_per_launch": fits_per_launch}
+        if not args.no_cpu_baseline and world == 1:
+            # the CPU oracle ("port"): same spec, same seeds, on this host's cores, bounded sample
+            from oracle import oracle
+            cores = max(1, min(os.cpu_count() or 1, 16))
+            t1 = time.perf_counter()
+            oracle.run_batch(spec, ns, 50_000, helpers.BASE_SEED, n_threads=cores)
+            rate = 50_000 / (time.perf_counter() - t1)
+            sample = int(min(max(rate * args.cpu_seconds, 50_000), 4_000_000))
+            t1 = time.perf_counter()
+            o = oracle.run_batch(spec, ns, sample, helpers.BASE_SEED, n_threads=cores)
+            dt = time.perf_counter() - t1
+            g = engine.run_batch(spec, ns, sample, helpers.BASE_SEED, per_sim=False)
+            out["cpu_baseline"] = {"value": sample / dt, "unit": "fits/s", "cores": cores, "kind": "port",
+                                   "sample": f"{sample} replicates of the same workload (sim_id 0..{sample - 1}), "
+                                             f"oracle/ C restatement, {cores} pthreads, {dt:.1f} s",
+                                   "power_delta_pp_vs_gpu": float(np.max(np.abs(
+                                       o.counters[0, :nt].astype(np.float64) - g.counters[0, :nt].astype(np.float64)))
+                                       / sample * 100.0)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -238,7 +238,8 @@ typedef struct mcp_batch_result {
   mcp_counter_layout layout;
   /* timing of the device work inside the call (HIP events on the launch stream) */
   double device_ms;            /* all kernels of the call */
-  double kernel_ms;            /* dominant (simulate) kernel only */
+  double kernel_ms;            /* dominant kernel only, summed over launches (fused simulate kernel; fit kernel when staged) */
+  double aux_kernel_ms;        /* staged pipeline: generator kernel, summed over launches; 0 otherwise */
   uint32_t n_kernel_launches;
   uint32_t _pad;
 } mcp_batch_result;
@@ -311,6 +312,11 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
 int mcp_fit_design(const float* design, const float* outcome, uint32_t n_fits, uint32_t n, uint32_t p,
                    double* beta_out, double* se_out, double* t_sq_out, double* rss_out, double* sst_out,
                    uint8_t* converged_out);
+
+/* Debug probe of the frozen f32 inverse-normal-CDF kernel (rng.rs:354):
+ * out[i] = norm_inv_cdf_f32(u32_to_unit_f32(first_word + i * stride)), i < n.
+ * Lets a host test sweep all 2^23 reachable uniforms (rng.rs:539). */
+int mcp_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,449 @@
+// host_api.hip -- the C ABI (include/mcpower_hip.h) over the gfx950 kernels.
+//
+// Host orchestration of run_batch (reference crates/engine-core/src/batch.rs:199-776):
+// validate -> crit tables -> result tensors -> dispatch replicates -> fold.  The
+// reference dispatches replicates over a rayon pool (:637-742); here the replicate
+// range is cut into device launches ("chunks") on one HIP stream, the progress /
+// cancel callback runs between chunks (:2149-2177), and the additive counters the
+// orchestrator would fold (aggregation.rs:84-284) are accumulated on the device.
+// There is NO CPU fallback: anything the kernels do not cover returns
+// MCP_ERR_UNSUPPORTED, and a missing device returns MCP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mcpower_hip.h"
+#include "host_internal.hpp"
+#include "mcp_params.hpp"
+
+namespace mcp {
+hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
+hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
+hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
+hipError_t launch_ols_fit_provided(int P, const float* design, const float* outcome, uint32_t n_fits, uint32_t n,
+                                   double* beta, double* se, double* tsq, double* rss, double* sst, uint8_t* conv,
+                                   hipStream_t st);
+hipError_t launch_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out, hipStream_t st);
+}  // namespace mcp
+
+namespace {
+
+thread_local std::string g_err;
+int g_device = 0;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t e_ = (expr);                                                                                    \
+    if (e_ != hipSuccess)                                                                                      \
+      return fail(MCP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);          \
+  } while (0)
+
+// grow-only device buffers reused across calls of one host thread (no hipMalloc on the steady-state path)
+struct Arena {
+  struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+  };
+  Buf slots[12];
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> events;
+  int device = -1;
+
+  hipError_t get(int slot, size_t bytes, void** out) {
+    Buf& b = slots[slot];
+    if (bytes > b.cap) {
+      if (b.p) (void)hipFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+      const size_t want = bytes + (bytes >> 3) + 256;
+      hipError_t e = hipMalloc(&b.p, want);
+      if (e != hipSuccess) return e;
+      b.cap = want;
+    }
+    *out = b.p;
+    return hipSuccess;
+  }
+  hipError_t event(size_t i, hipEvent_t* ev) {
+    while (events.size() <= i) {
+      hipEvent_t e;
+      hipError_t rc = hipEventCreate(&e);
+      if (rc != hipSuccess) return rc;
+      events.push_back(e);
+    }
+    *ev = events[i];
+    return hipSuccess;
+  }
+};
+thread_local Arena g_arena;
+
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1 };
+
+int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(MCP_ERR_DEVICE, "no HIP device visible: the MI355X path cannot run (there is no CPU fallback)");
+  if (g_device >= n) return fail(MCP_ERR_DEVICE, "selected device index out of range");
+  HIP_TRY(hipSetDevice(g_device));
+  if (g_arena.device != g_device) {
+    g_arena = Arena();
+    g_arena.device = g_device;
+  }
+  if (opts && opts->hip_stream) {
+    *st = (hipStream_t)opts->hip_stream;
+  } else {
+    if (!g_arena.stream) HIP_TRY(hipStreamCreateWithFlags(&g_arena.stream, hipStreamNonBlocking));
+    *st = g_arena.stream;
+  }
+  return MCP_OK;
+}
+
+template <class T>
+T* host_alloc(size_t n) {
+  return (T*)std::malloc((n ? n : 1) * sizeof(T));
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t mcp_abi_version(void) { return MCP_ABI_VERSION; }
+const char* mcp_last_error(void) { return g_err.c_str(); }
+
+int mcp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mcp_set_device(int device_index) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MCP_ERR_DEVICE, "no HIP device visible");
+  if (device_index < 0 || device_index >= n) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: device index out of range");
+  g_device = device_index;
+  return MCP_OK;
+}
+
+double mcp_t_ppf(double p, double df) { return mcp::t_ppf(p, df); }
+double mcp_norm_ppf(double p) { return mcp::norm_ppf(p); }
+double mcp_chi2_ppf(double p, double k) { return mcp::chi2_ppf(p, k); }
+double mcp_f_ppf(double p, double dfn, double dfd) { return mcp::f_ppf(p, dfn, dfd); }
+
+int mcp_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, double* crit_out) {
+  std::string err;
+  int rc = mcp::validate_spec(spec, ns, n_ns, err);
+  if (rc) return fail(rc, err);
+  const uint32_t P = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
+  const uint32_t nt = spec->n_target_indices + spec->n_contrast_pairs;
+  std::vector<double> rows;
+  rc = mcp::build_crit_rows(spec->estimator, spec->correction_method, spec->alpha, spec->posthoc_alpha, P, nt, ns, n_ns,
+                            rows, err);
+  if (rc) return fail(rc, err);
+  std::memcpy(crit_out, rows.data(), rows.size() * sizeof(double));
+  return MCP_OK;
+}
+
+void mcp_free_result(mcp_batch_result* r) {
+  if (!r) return;
+  std::free(r->uncorrected); std::free(r->corrected); std::free(r->posthoc_unc); std::free(r->posthoc_cor);
+  std::free(r->converged); std::free(r->boundary_hit); std::free(r->pinned_components); std::free(r->joint_unc);
+  std::free(r->joint_cor); std::free(r->overall); std::free(r->factor_excluded); std::free(r->tau_squared_hat);
+  std::free(r->stat_capture); std::free(r->counters);
+  std::memset(r, 0, sizeof *r);
+}
+
+int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t n_sims, uint64_t base_seed,
+                  const mcp_run_options* opts, mcp_progress_fn progress, void* progress_user, mcp_batch_result* out) {
+  if (!out) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null result pointer");
+  std::memset(out, 0, sizeof *out);
+  std::string err;
+  int rc = mcp::validate_spec(spec, ns, n_ns, err);
+  if (rc) return fail(rc, err);
+  mcp::SimParams prm;
+  mcp::Lowered low;
+  rc = mcp::lower_spec(spec, ns, n_ns, prm, low, err);
+  if (rc) return fail(rc, err);
+
+  const uint32_t flags = opts ? opts->flags : (uint32_t)MCP_WANT_PER_SIM;
+  const bool per_sim = flags & MCP_WANT_PER_SIM;
+  const bool want_stat = flags & MCP_WANT_STAT_CAPTURE;
+  const bool staged = flags & MCP_PIPELINE_STAGED;
+  const uint64_t sim_offset = opts ? opts->sim_offset : 0;
+  const uint32_t nt = low.n_tests, P = low.P;
+  const size_t cells = (size_t)n_sims * n_ns;
+
+  mcp_counter_layout layout;
+  mcp::counter_layout(spec, &layout);
+  out->layout = layout;
+  out->n_sims = n_sims; out->n_sample_sizes = n_ns; out->n_targets = nt; out->n_factors = spec->n_factors;
+  out->n_posthoc_contrasts = 0; out->n_variance_components = 0;
+  out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
+  std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
+  if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
+
+  hipStream_t st = nullptr;
+  rc = ensure_device(&st, opts);
+  if (rc) { mcp_free_result(out); return rc; }
+  Arena& ar = g_arena;
+
+  // chunking: the callback cadence of the reference is ~50 reports per run (batch.rs:450)
+  uint32_t chunk = opts && opts->chunk_sims ? opts->chunk_sims : 0;
+  if (!chunk) {
+    chunk = staged ? (1u << 20) : (1u << 22);
+    if (progress) {
+      uint32_t step = n_sims / 50u;
+      if (step < 16384u) step = 16384u;
+      if (step < chunk) chunk = step;
+    }
+  }
+  if (chunk > n_sims) chunk = n_sims;
+  const uint32_t n_chunks = (n_sims + chunk - 1) / chunk;
+
+#define DEV_TRY(expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t e_ = (expr);                                                                                    \
+    if (e_ != hipSuccess) {                                                                                    \
+      mcp_free_result(out);                                                                                    \
+      return fail(MCP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);          \
+    }                                                                                                          \
+  } while (0)
+
+  mcp::SimParams* d_prm = nullptr;
+  double* d_crit = nullptr;
+  uint8_t* d_levels = nullptr;
+  unsigned long long* d_ctr = nullptr;
+  uint8_t *d_unc = nullptr, *d_cor = nullptr, *d_conv = nullptr, *d_ov = nullptr;
+  double* d_stat = nullptr;
+  float* d_tile = nullptr;
+  DEV_TRY(ar.get(S_PRM, sizeof(mcp::SimParams) * n_chunks, (void**)&d_prm));
+  DEV_TRY(ar.get(S_CRIT, low.crit.size() * sizeof(double), (void**)&d_crit));
+  DEV_TRY(ar.get(S_LEVELS, low.fixed_levels.size(), (void**)&d_levels));
+  DEV_TRY(ar.get(S_COUNTERS, (size_t)n_ns * layout.stride * sizeof(uint64_t), (void**)&d_ctr));
+  if (per_sim) {
+    DEV_TRY(ar.get(S_UNC, cells * nt + 1, (void**)&d_unc));
+    DEV_TRY(ar.get(S_COR, cells * nt + 1, (void**)&d_cor));
+    DEV_TRY(ar.get(S_CONV, cells + 1, (void**)&d_conv));
+    if (spec->report_overall) DEV_TRY(ar.get(S_OVERALL, cells + 1, (void**)&d_ov));
+  }
+  if (want_stat) DEV_TRY(ar.get(S_STAT, ((size_t)n_sims * nt + 1) * sizeof(double), (void**)&d_stat));
+  if (staged) DEV_TRY(ar.get(S_TILE, (size_t)P * prm.max_n * chunk * sizeof(float), (void**)&d_tile));
+
+  hipEvent_t ev_begin, ev_end;
+  DEV_TRY(ar.event(0, &ev_begin));
+  DEV_TRY(ar.event(1, &ev_end));
+  DEV_TRY(hipEventRecord(ev_begin, st));
+  DEV_TRY(hipMemcpyAsync(d_crit, low.crit.data(), low.crit.size() * sizeof(double), hipMemcpyHostToDevice, st));
+  DEV_TRY(hipMemcpyAsync(d_levels, low.fixed_levels.data(), low.fixed_levels.size(), hipMemcpyHostToDevice, st));
+  DEV_TRY(hipMemsetAsync(d_ctr, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t), st));
+
+  prm.base_seed = base_seed;
+  prm.fixed_levels = d_levels;
+  prm.crit = d_crit;
+  prm.unc = d_unc; prm.cor = d_cor; prm.conv = d_conv; prm.overall = d_ov; prm.stat = d_stat;
+  prm.counters = d_ctr;
+  prm.ctr_stride = layout.stride; prm.ctr_k_unc = layout.k_unc; prm.ctr_k_cor = layout.k_cor;
+  prm.ctr_conv = layout.converged; prm.ctr_overall = layout.overall; prm.ctr_hist_unc = layout.hist_unc;
+  prm.ctr_hist_cor = layout.hist_cor; prm.ctr_n_sims = layout.n_sims;
+  prm.tile = d_tile;
+  prm.tile_sims = chunk;
+  std::vector<mcp::SimParams> h_prm(n_chunks, prm);
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const uint32_t b = c * chunk;
+    h_prm[c].sim_begin = sim_offset + b;
+    h_prm[c].n_sims = (n_sims - b) < chunk ? (n_sims - b) : chunk;
+    h_prm[c].out_base = b;
+  }
+  DEV_TRY(hipMemcpyAsync(d_prm, h_prm.data(), sizeof(mcp::SimParams) * n_chunks, hipMemcpyHostToDevice, st));
+
+  // launches, each bracketed by events on the launch stream
+  const size_t ev_per_chunk = staged ? 3 : 2;
+  bool cancelled = false;
+  uint32_t launched = 0;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    hipEvent_t e0, e1, e2 = nullptr;
+    DEV_TRY(ar.event(2 + c * ev_per_chunk, &e0));
+    DEV_TRY(ar.event(3 + c * ev_per_chunk, &e1));
+    if (staged) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
+    DEV_TRY(hipEventRecord(e0, st));
+    if (!staged) {
+      DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(hipEventRecord(e1, st));
+    } else {
+      DEV_TRY(mcp::launch_ols_generate((int)P, d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(hipEventRecord(e1, st));
+      DEV_TRY(mcp::launch_ols_fit((int)P, d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(hipEventRecord(e2, st));
+    }
+    ++launched;
+    if (progress) {  // ProgressSink::report between chunks; false cancels (spec.rs:38-52)
+      DEV_TRY(hipStreamSynchronize(st));
+      const uint64_t done = (uint64_t)h_prm[c].out_base + h_prm[c].n_sims;
+      if (!progress(done, n_sims, progress_user)) {
+        cancelled = true;
+        break;
+      }
+    }
+  }
+  if (cancelled) {
+    (void)hipStreamSynchronize(st);
+    mcp_free_result(out);
+    return fail(MCP_ERR_CANCELLED, "cancelled by host");
+  }
+
+  // results
+  DEV_TRY(hipMemcpyAsync(out->counters, d_ctr, (size_t)n_ns * layout.stride * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  if (per_sim) {
+    out->uncorrected = host_alloc<uint8_t>(cells * nt);
+    out->corrected = host_alloc<uint8_t>(cells * nt);
+    out->converged = host_alloc<uint8_t>(cells);
+    out->boundary_hit = (uint8_t*)std::calloc(cells ? cells : 1, 1);         // OLS: never a boundary (batch.rs:1016)
+    out->pinned_components = (uint64_t*)std::calloc(cells ? cells : 1, 8);
+    out->joint_unc = (uint8_t*)std::calloc(cells ? cells : 1, 1);
+    out->joint_cor = (uint8_t*)std::calloc(cells ? cells : 1, 1);
+    out->tau_squared_hat = host_alloc<double>(cells);
+    for (size_t i = 0; i < cells; ++i) out->tau_squared_hat[i] = NAN;
+    if (spec->n_factors) out->factor_excluded = (uint8_t*)std::calloc(cells * spec->n_factors + 1, 1);
+    DEV_TRY(hipMemcpyAsync(out->uncorrected, d_unc, cells * nt, hipMemcpyDeviceToHost, st));
+    DEV_TRY(hipMemcpyAsync(out->corrected, d_cor, cells * nt, hipMemcpyDeviceToHost, st));
+    DEV_TRY(hipMemcpyAsync(out->converged, d_conv, cells, hipMemcpyDeviceToHost, st));
+    if (spec->report_overall) {
+      out->overall = host_alloc<uint8_t>(cells);
+      DEV_TRY(hipMemcpyAsync(out->overall, d_ov, cells, hipMemcpyDeviceToHost, st));
+    }
+  }
+  if (want_stat) {
+    out->stat_capture = host_alloc<double>((size_t)n_sims * nt);
+    DEV_TRY(hipMemcpyAsync(out->stat_capture, d_stat, (size_t)n_sims * nt * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  DEV_TRY(hipEventRecord(ev_end, st));
+  DEV_TRY(hipStreamSynchronize(st));
+
+  float ms = 0.f;
+  DEV_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+  out->device_ms = ms;
+  double kernel_ms = 0.0, aux_ms = 0.0;
+  for (uint32_t c = 0; c < launched; ++c) {
+    hipEvent_t e0 = ar.events[2 + c * ev_per_chunk], e1 = ar.events[3 + c * ev_per_chunk];
+    DEV_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (!staged) {
+      kernel_ms += ms;
+    } else {
+      aux_ms += ms;  // generator
+      DEV_TRY(hipEventElapsedTime(&ms, e1, ar.events[4 + c * ev_per_chunk]));
+      kernel_ms += ms;  // fit
+    }
+  }
+  out->kernel_ms = kernel_ms;
+  out->aux_kernel_ms = aux_ms;
+  out->n_kernel_launches = launched;
+#undef DEV_TRY
+  return MCP_OK;
+}
+
+int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, uint64_t base_seed, uint64_t sim_offset,
+                        float* design_out, float* outcome_out) {
+  std::string err;
+  const uint32_t ns1[1] = {max_n};
+  int rc = mcp::validate_spec(spec, ns1, 1, err);
+  if (rc) return fail(rc, err);
+  mcp::SimParams prm;
+  mcp::Lowered low;
+  rc = mcp::lower_spec(spec, ns1, 1, prm, low, err);
+  if (rc) return fail(rc, err);
+  if (n_sims == 0) return MCP_OK;
+  hipStream_t st = nullptr;
+  rc = ensure_device(&st, nullptr);
+  if (rc) return rc;
+  Arena& ar = g_arena;
+  const uint32_t P = low.P;
+  mcp::SimParams* d_prm = nullptr;
+  uint8_t* d_levels = nullptr;
+  float* d_tile = nullptr;
+  const size_t tile_floats = (size_t)P * max_n * n_sims;
+  HIP_TRY(ar.get(S_PRM, sizeof(mcp::SimParams), (void**)&d_prm));
+  HIP_TRY(ar.get(S_LEVELS, low.fixed_levels.size(), (void**)&d_levels));
+  HIP_TRY(ar.get(S_TILE, tile_floats * sizeof(float), (void**)&d_tile));
+  HIP_TRY(hipMemcpyAsync(d_levels, low.fixed_levels.data(), low.fixed_levels.size(), hipMemcpyHostToDevice, st));
+  prm.base_seed = base_seed;
+  prm.sim_begin = sim_offset;
+  prm.n_sims = n_sims;
+  prm.fixed_levels = d_levels;
+  prm.tile = d_tile;
+  prm.tile_sims = n_sims;
+  HIP_TRY(hipMemcpyAsync(d_prm, &prm, sizeof prm, hipMemcpyHostToDevice, st));
+  HIP_TRY(mcp::launch_ols_generate((int)P, d_prm, n_sims, st));
+  std::vector<float> tile(tile_floats);
+  HIP_TRY(hipMemcpyAsync(tile.data(), d_tile, tile_floats * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // tile [column: x1..x_{P-1}, y][row][sim] -> design [sim][column 0..P-1][row], outcome [sim][row]
+  const size_t col = (size_t)max_n * n_sims;
+  for (uint32_t s = 0; s < n_sims; ++s) {
+    float* d = design_out + (size_t)s * P * max_n;
+    for (uint32_t i = 0; i < max_n; ++i) d[i] = 1.0f;
+    for (uint32_t c = 1; c < P; ++c)
+      for (uint32_t i = 0; i < max_n; ++i) d[(size_t)c * max_n + i] = tile[(size_t)(c - 1) * col + (size_t)i * n_sims + s];
+    for (uint32_t i = 0; i < max_n; ++i) outcome_out[(size_t)s * max_n + i] = tile[(size_t)(P - 1) * col + (size_t)i * n_sims + s];
+  }
+  return MCP_OK;
+}
+
+int mcp_fit_design(const float* design, const float* outcome, uint32_t n_fits, uint32_t n, uint32_t p, double* beta_out,
+                   double* se_out, double* t_sq_out, double* rss_out, double* sst_out, uint8_t* converged_out) {
+  if (p < 2 || p > (uint32_t)mcp::MAX_P)
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: design columns outside [2, 8]");
+  if (n <= p) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: df = N - P < 1");
+  if (n_fits == 0) return MCP_OK;
+  hipStream_t st = nullptr;
+  int rc = ensure_device(&st, nullptr);
+  if (rc) return rc;
+  Arena& ar = g_arena;
+  const size_t xb = (size_t)n_fits * n * p * sizeof(float), yb = (size_t)n_fits * n * sizeof(float);
+  const size_t pb = (size_t)n_fits * p * sizeof(double), sb = (size_t)n_fits * sizeof(double);
+  float *d_x = nullptr, *d_y = nullptr;
+  double* d_out = nullptr;
+  uint8_t* d_conv = nullptr;
+  HIP_TRY(ar.get(S_TILE, xb, (void**)&d_x));
+  HIP_TRY(ar.get(S_MISC0, yb, (void**)&d_y));
+  HIP_TRY(ar.get(S_MISC1, 3 * pb + 2 * sb, (void**)&d_out));
+  HIP_TRY(ar.get(S_CONV, n_fits, (void**)&d_conv));
+  double* d_beta = d_out;
+  double* d_se = d_out + (size_t)n_fits * p;
+  double* d_tsq = d_se + (size_t)n_fits * p;
+  double* d_rss = d_tsq + (size_t)n_fits * p;
+  double* d_sst = d_rss + n_fits;
+  HIP_TRY(hipMemcpyAsync(d_x, design, xb, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_y, outcome, yb, hipMemcpyHostToDevice, st));
+  HIP_TRY(mcp::launch_ols_fit_provided((int)p, d_x, d_y, n_fits, n, d_beta, d_se, d_tsq, d_rss, d_sst, d_conv, st));
+  HIP_TRY(hipMemcpyAsync(beta_out, d_beta, pb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(se_out, d_se, pb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(t_sq_out, d_tsq, pb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(rss_out, d_rss, sb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(sst_out, d_sst, sb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(converged_out, d_conv, n_fits, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MCP_OK;
+}
+
+// Debug probe of the frozen inverse-CDF kernel (rng.rs:354): out[i] = icdf(u32_to_unit_f32(first + i*stride)).
+int mcp_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out) {
+  if (n == 0) return MCP_OK;
+  hipStream_t st = nullptr;
+  int rc = ensure_device(&st, nullptr);
+  if (rc) return rc;
+  float* d = nullptr;
+  HIP_TRY(g_arena.get(S_MISC0, (size_t)n * sizeof(float), (void**)&d));
+  HIP_TRY(mcp::launch_icdf_probe(first_word, stride, n, d, st));
+  HIP_TRY(hipMemcpyAsync(out, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MCP_OK;
+}
+
+}  // extern "C"

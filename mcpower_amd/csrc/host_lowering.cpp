@@ -1,0 +1,267 @@
+// host_lowering.cpp -- run_batch's host prologue: validation and lowering of a
+// SimulationSpec to the launch-constant block the kernels read.
+//
+// Restates /root/reference/crates/engine-core/src/batch.rs:208-330 (validation,
+// same order and wording of the InvalidSpec messages), data_gen.rs:943-961
+// (fixed_level_next, the deterministic largest-remainder allocation walk --
+// consumes no RNG, so it is evaluated once per call on the host and uploaded as
+// a level table), data_gen.rs:998-1005 + correlation.rs:48 (Cholesky factor of
+// the correlation, identical for every replicate on the optimistic path), and
+// batch.rs:2334-2407 (critical-value tables).
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "host_internal.hpp"
+#include "mcp_params.hpp"
+
+namespace mcp {
+
+static bool scenario_is_optimistic(const mcp_scenario& s) {  // spec.rs:229-236
+  return s.heterogeneity == 0.0 && s.heteroskedasticity_ratio == 1.0 && s.correlation_noise_sd == 0.0 &&
+         s.distribution_change_prob == 0.0 && s.residual_change_prob == 0.0 && !s.has_lme;
+}
+
+// lower Cholesky factor, column-major in, row-major out; false when a pivot is not positive
+static bool chol_lower(const double* a_colmajor, uint32_t k, double* l_rowmajor, uint32_t ld) {
+  for (uint32_t i = 0; i < k; ++i)
+    for (uint32_t j = 0; j < ld; ++j) l_rowmajor[i * ld + j] = 0.0;
+  for (uint32_t j = 0; j < k; ++j) {
+    double d = a_colmajor[j * k + j];
+    for (uint32_t t = 0; t < j; ++t) d -= l_rowmajor[j * ld + t] * l_rowmajor[j * ld + t];
+    if (!(d > 0.0)) return false;
+    const double ljj = std::sqrt(d);
+    l_rowmajor[j * ld + j] = ljj;
+    for (uint32_t i = j + 1; i < k; ++i) {
+      double s = a_colmajor[j * k + i];
+      for (uint32_t t = 0; t < j; ++t) s -= l_rowmajor[i * ld + t] * l_rowmajor[j * ld + t];
+      l_rowmajor[i * ld + j] = s / ljj;
+    }
+  }
+  return true;
+}
+
+void counter_layout(const mcp_spec* spec, mcp_counter_layout* L) {
+  const uint32_t nt = spec->n_target_indices + spec->n_contrast_pairs;
+  uint32_t npc = 0;
+  for (uint32_t b = 0; b < spec->n_posthoc; ++b) {
+    const uint32_t k = spec->posthoc_target_offsets[b + 1] - spec->posthoc_target_offsets[b] + 1;
+    npc += k * (k - 1) / 2;
+  }
+  uint32_t o = 0;
+  L->k_unc = o; o += nt;
+  L->k_cor = o; o += nt;
+  L->converged = o; o += 1;
+  L->overall = o; o += 1;
+  L->hist_unc = o; o += nt + npc + 1;
+  L->hist_cor = o; o += nt + npc + 1;
+  L->posthoc_unc = o; o += npc;
+  L->posthoc_cor = o; o += npc;
+  L->excl_sparse = o; o += spec->n_factors;
+  L->excl_sep = o; o += spec->n_factors;
+  L->joint_unc = o; o += 1;
+  L->joint_cor = o; o += 1;
+  L->boundary_1 = o; o += 1;
+  L->boundary_2 = o; o += 1;
+  L->n_sims = o; o += 1;
+  L->stride = o;
+}
+
+int validate_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, std::string& err) {
+  auto bad = [&](const std::string& m) {
+    err = "invalid spec: " + m;
+    return (int)MCP_ERR_INVALID_SPEC;
+  };
+  if (!spec) return bad("null spec");
+  if (spec->abi_version != MCP_ABI_VERSION) return bad("abi_version mismatch");
+  if (spec->estimator == MCP_EST_MLE && !spec->cluster.present) return bad("estimator Mle requires ClusterSpec");
+  if (spec->n_posthoc && spec->estimator != MCP_EST_OLS) return bad("posthoc tests are only supported for estimator=Ols");
+  if (n_ns == 0 || !ns) return bad("sample_sizes must be non-empty");
+  for (uint32_t i = 1; i < n_ns; ++i)
+    if (ns[i] <= ns[i - 1])
+      return bad("sample_sizes must be strictly increasing; got " + std::to_string(ns[i - 1]) + " then " + std::to_string(ns[i]));
+  if (ns[0] == 0) return bad("sample_sizes[0] must be > 0");
+  const uint32_t k = spec->n_non_factor;
+  const uint32_t p = 1 + k + spec->n_factor_dummies + spec->n_interactions;
+  if (spec->n_effect_sizes != p)
+    return bad("effect_sizes length " + std::to_string(spec->n_effect_sizes) + " does not match n_predictors " +
+               std::to_string(p) + " (1 intercept + " + std::to_string(k) + " non_factor + " +
+               std::to_string(spec->n_factor_dummies) + " factor dummies)");
+  uint32_t expected_props = 0, expected_dummies = 0;
+  for (uint32_t f = 0; f < spec->n_factors; ++f) {
+    if (spec->factor_n_levels[f] < 2)
+      return bad("factor_n_levels entries must be >= 2; got " + std::to_string(spec->factor_n_levels[f]));
+    expected_props += (uint32_t)spec->factor_n_levels[f];
+    expected_dummies += (uint32_t)spec->factor_n_levels[f] - 1;
+  }
+  if (spec->n_factor_proportions != expected_props)
+    return bad("factor_proportions length " + std::to_string(spec->n_factor_proportions) +
+               " does not match sum(factor_n_levels) " + std::to_string(expected_props));
+  if (expected_dummies != spec->n_factor_dummies) return bad("n_factor_dummies does not match factor_n_levels");
+  for (uint32_t t = 0; t < spec->n_target_indices; ++t)
+    if (spec->target_indices[t] >= p)
+      return bad("target_indices entry " + std::to_string(spec->target_indices[t]) + " out of range (n_predictors = " +
+                 std::to_string(p) + ")");
+  for (uint32_t c = 0; c < 2 * spec->n_contrast_pairs; ++c)
+    if (spec->contrast_pairs[c] >= p)
+      return bad("contrast_pairs entry " + std::to_string(spec->contrast_pairs[c]) + " out of range (n_predictors = " +
+                 std::to_string(p) + ")");
+  for (uint32_t j = 0; j < spec->n_interactions; ++j)
+    for (uint32_t c = spec->interaction_offsets[j]; c < spec->interaction_offsets[j + 1]; ++c)
+      if (spec->interaction_components[c] == 0 || spec->interaction_components[c] >= 1 + k + spec->n_factor_dummies)
+        return bad("interaction component out of range");
+  if (k > 0) {  // trial Cholesky (batch.rs:320-330)
+    std::vector<double> l((size_t)k * k);
+    if (!chol_lower(spec->correlation, k, l.data(), k)) {
+      err = "correlation matrix is not positive semi-definite";
+      return MCP_ERR_CORRELATION_NOT_PSD;
+    }
+  }
+  return MCP_OK;
+}
+
+// data_gen.rs:943-961
+static uint32_t fixed_level_next(const double* probs, uint32_t* counts, uint32_t nl) {
+  double total = 0.0;
+  uint32_t assigned = 0;
+  for (uint32_t g = 0; g < nl; ++g) {
+    total += probs[g];
+    assigned += counts[g];
+  }
+  const double t = double(assigned + 1);
+  uint32_t best = 0;
+  double best_def = -INFINITY;
+  for (uint32_t g = 0; g < nl; ++g) {
+    const double deficit = (probs[g] / total) * t - double(counts[g]);
+    if (deficit > best_def) {
+      best_def = deficit;
+      best = g;
+    }
+  }
+  counts[best] += 1;
+  return best;
+}
+
+int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParams& prm, Lowered& low, std::string& err) {
+  auto unsupported = [&](const std::string& m) {
+    err = "unsupported on the device path: " + m;
+    return (int)MCP_ERR_UNSUPPORTED;
+  };
+  std::memset(&prm, 0, sizeof prm);
+  const uint32_t K = spec->n_non_factor;
+  const uint32_t P = 1 + K + spec->n_factor_dummies + spec->n_interactions;
+  const uint32_t nt = spec->n_target_indices + spec->n_contrast_pairs;
+  const uint32_t max_n = ns[n_ns - 1];
+  if (P < 2 || P > (uint32_t)MAX_P) return unsupported("design columns P = " + std::to_string(P) + " outside [2, " + std::to_string(MAX_P) + "]");
+  if (K > (uint32_t)MAX_K) return unsupported("more than " + std::to_string(MAX_K) + " continuous predictors");
+  if (nt > (uint32_t)MAX_T) return unsupported("more than " + std::to_string(MAX_T) + " tests per fit");
+  if (n_ns > (uint32_t)MAX_GRID) return unsupported("more than " + std::to_string(MAX_GRID) + " sample sizes per call");
+  if (spec->n_factors > (uint32_t)MAX_FACTORS) return unsupported("more than " + std::to_string(MAX_FACTORS) + " factors");
+  if (spec->n_factor_proportions > (uint32_t)MAX_LEVELS) return unsupported("more than " + std::to_string(MAX_LEVELS) + " factor levels in total");
+  if (spec->estimator != MCP_EST_OLS) return unsupported("estimator Glm / Mle (OLS arm only so far)");
+  if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS) return unsupported("Binary / Count outcomes");
+  if (spec->cluster.present) return unsupported("clustered data generation");
+  if (!scenario_is_optimistic(spec->scenario)) return unsupported("scenario perturbations (optimistic path only so far)");
+  if (spec->residual_dist != MCP_RESID_NORMAL) return unsupported("non-normal residual distributions");
+  for (uint32_t j = 0; j < K; ++j)
+    if (spec->var_types[j] != MCP_DIST_NORMAL) return unsupported("non-normal predictor marginals");
+  if (spec->n_bootstrap_frame_map || spec->upload_normal_rows || spec->upload_data_rows) return unsupported("uploaded data");
+  if (spec->n_between_var_indices) return unsupported("cluster-level (between) predictors");
+  if (spec->n_posthoc) return unsupported("post-hoc contrasts");
+  if (spec->n_fit_columns && spec->n_fit_columns < P) return unsupported("reduced test design (fit_columns)");
+  if (spec->n_factors && spec->factor_min_level_count > 0) return unsupported("sparse-factor exclusion");
+  if (spec->heteroskedasticity_driver >= 0 && spec->scenario.heteroskedasticity_ratio != 1.0) return unsupported("heteroskedasticity");
+
+  prm.max_n = max_n;
+  prm.n_grid = n_ns;
+  for (uint32_t g = 0; g < n_ns; ++g) prm.ns[g] = ns[g];
+  prm.P = P;
+  prm.K = K;
+  bool ident = true;
+  if (K) {
+    if (!chol_lower(spec->correlation, K, prm.L, MAX_K)) {
+      err = "correlation matrix is not positive semi-definite";
+      return MCP_ERR_CORRELATION_NOT_PSD;
+    }
+    for (uint32_t i = 0; i < K; ++i)
+      for (uint32_t j = 0; j < K; ++j)
+        if (prm.L[i * MAX_K + j] != (i == j ? 1.0 : 0.0)) ident = false;
+  }
+  prm.ident_L = ident ? 1u : 0u;
+  for (uint32_t c = 0; c < P; ++c) prm.beta[c] = spec->effect_sizes[c];
+
+  // factors
+  prm.n_factors = spec->n_factors;
+  for (uint32_t c = 0; c < (uint32_t)MAX_P; ++c) {
+    prm.col_factor[c] = 0xffffffffu;
+    prm.col_level[c] = 0;
+    prm.inter_mask[c] = 0;
+  }
+  uint32_t col = 1 + K, poff = 0, n_sampled = 0;
+  for (uint32_t f = 0; f < spec->n_factors; ++f) {
+    const uint32_t nl = (uint32_t)spec->factor_n_levels[f];
+    prm.f_levels[f] = nl;
+    prm.f_col[f] = col;
+    prm.f_prop_off[f] = poff;
+    int sampled = spec->scenario.sampled_factor_proportions;
+    if (f < spec->n_factor_sampled && spec->factor_sampled[f] >= 0) sampled = spec->factor_sampled[f];
+    prm.f_sampled[f] = sampled ? 1u : 0u;
+    prm.f_seq_slot[f] = sampled ? n_sampled++ : 0u;
+    for (uint32_t l = 0; l < nl; ++l) prm.f_props[poff + l] = spec->factor_proportions[poff + l];
+    for (uint32_t d = 0; d + 1 < nl; ++d) {
+      prm.col_factor[col + d] = f;
+      prm.col_level[col + d] = d + 1;
+    }
+    col += nl - 1;
+    poff += nl;
+  }
+  prm.n_seq_pre = 0;
+  prm.n_seq_per_row = n_sampled;
+  low.fixed_levels.assign((size_t)max_n * (spec->n_factors ? spec->n_factors : 1), 0);
+  {
+    std::vector<uint32_t> counts(spec->n_factor_proportions ? spec->n_factor_proportions : 1, 0u);
+    for (uint32_t i = 0; i < max_n; ++i)
+      for (uint32_t f = 0; f < spec->n_factors; ++f)
+        if (!prm.f_sampled[f])
+          low.fixed_levels[(size_t)i * spec->n_factors + f] =
+              (uint8_t)fixed_level_next(spec->factor_proportions + prm.f_prop_off[f], counts.data() + prm.f_prop_off[f],
+                                        prm.f_levels[f]);
+  }
+  // interactions: ascending component lists become bitmasks (two-component products are exact in f64 and
+  // commutative; longer ones must already be listed ascending, the order the reference multiplies in)
+  for (uint32_t j = 0; j < spec->n_interactions; ++j) {
+    uint32_t mask = 0, prev = 0;
+    const uint32_t b = spec->interaction_offsets[j], e = spec->interaction_offsets[j + 1];
+    for (uint32_t c = b; c < e; ++c) {
+      const uint32_t comp = spec->interaction_components[c];
+      if (e - b > 2 && comp <= prev) return unsupported("interaction with >2 components not listed in ascending column order");
+      if (mask & (1u << comp)) return unsupported("interaction repeating a component (powers)");
+      prev = comp;
+      mask |= 1u << comp;
+    }
+    if (mask == 0) return unsupported("empty interaction");
+    prm.inter_mask[1 + K + spec->n_factor_dummies + j] = mask;
+  }
+  // tests: marginal targets then contrast pairs (batch.rs:1045-1088)
+  prm.n_tests = nt;
+  for (uint32_t t = 0; t < spec->n_target_indices; ++t) prm.contrast[t * MAX_P + spec->target_indices[t]] = 1.0;
+  for (uint32_t q = 0; q < spec->n_contrast_pairs; ++q) {
+    double* c = prm.contrast + (spec->n_target_indices + q) * MAX_P;
+    c[spec->contrast_pairs[2 * q]] += 1.0;
+    c[spec->contrast_pairs[2 * q + 1]] -= 1.0;
+  }
+  prm.correction = spec->correction_method;
+  prm.report_overall = spec->report_overall ? 1u : 0u;
+  prm.crit_stride = nt + 4;
+  prm.outcome_kind = (uint32_t)spec->outcome_kind;
+  prm.estimator = (uint32_t)spec->estimator;
+
+  const int rc = build_crit_rows(spec->estimator, spec->correction_method, spec->alpha, spec->posthoc_alpha, P, nt, ns,
+                                 n_ns, low.crit, err);
+  if (rc) return rc;
+  low.P = P;
+  low.n_tests = nt;
+  return MCP_OK;
+}
+
+}  // namespace mcp

@@ -1,0 +1,83 @@
+// mcp_params.hpp -- launch-constant block shared by host lowering and kernels.
+//
+// The host lowers a validated mcp_spec (reference SimulationSpec, spec.rs:251)
+// into this flat block once per run_batch call; kernels read it through scalar
+// (wave-uniform) loads.  Column layout is the reference's fixed kernel layout
+// [0 intercept | 1..K continuous | factor dummies | interactions]
+// (data_gen.rs:79-83).
+#pragma once
+#include <stdint.h>
+
+namespace mcp {
+
+constexpr int MAX_P = 8;         // design columns incl. intercept handled by the register-resident kernels
+constexpr int MAX_K = 7;         // continuous predictors
+constexpr int MAX_GRID = 64;     // sample-size grid points per call
+constexpr int MAX_T = 8;         // tests per fit (marginal targets + contrast pairs)
+constexpr int MAX_FACTORS = 4;
+constexpr int MAX_LEVELS = 16;   // sum of levels over all factors
+
+struct SimParams {
+  uint64_t base_seed;
+  uint64_t sim_begin;      // sim_id of lane 0 of block 0
+  uint32_t n_sims;         // replicates in this launch
+  uint32_t out_base;       // row of the first replicate in the per-sim output tensors
+  uint32_t max_n;
+  uint32_t n_grid;
+  uint32_t ns[MAX_GRID];   // strictly increasing sample sizes
+
+  uint32_t P;              // total design columns
+  uint32_t K;              // continuous predictors (columns 1..K)
+  uint32_t ident_L;        // 1 when the correlation Cholesky factor is exactly I
+  double L[MAX_K * MAX_K]; // row-major lower factor of the correlation (data_gen.rs:998-1005)
+  double beta[MAX_P];      // effect_sizes
+
+  // factors (data_gen.rs:509-551)
+  uint32_t n_factors;
+  uint32_t f_levels[MAX_FACTORS];
+  uint32_t f_col[MAX_FACTORS];       // first dummy column of factor f
+  uint32_t f_prop_off[MAX_FACTORS];
+  uint32_t f_sampled[MAX_FACTORS];   // 1 = categorical draw on the sequential stream
+  uint32_t f_seq_slot[MAX_FACTORS];  // ordinal of this factor among the sampled ones
+  double f_props[MAX_LEVELS];
+  uint32_t n_seq_pre;                // sequential-stream draws consumed before the row loop
+  uint32_t n_seq_per_row;            // sequential-stream draws consumed per row
+  uint32_t col_factor[MAX_P];        // owning factor of a dummy column (else 0xffffffff)
+  uint32_t col_level[MAX_P];         // level (>=1) a dummy column indicates
+  uint32_t inter_mask[MAX_P];        // component-column bitmask of an interaction column (else 0)
+
+  // tests (batch.rs:1045-1095): row t of `contrast` is the vector c with c'beta tested
+  uint32_t n_tests;
+  double contrast[MAX_T * MAX_P];
+  int32_t correction;                // mcp_correction
+  uint32_t report_overall;
+  uint32_t crit_stride;              // n_tests + 4
+
+  // cluster random intercept (data_gen.rs:146-161, generation.rs:125-158)
+  uint32_t has_cluster;
+  uint32_t cluster_fixed_clusters;   // 1: row i -> i % v ; 0: row i -> i / v
+  uint32_t cluster_v;
+  uint32_t n_clusters_max;           // clusters present at max_n
+  double tau;                        // sqrt(max(tau_squared, 0))
+
+  // outcome
+  uint32_t outcome_kind;             // mcp_outcome_kind
+  uint32_t estimator;                // mcp_estimator
+
+  // device pointers
+  const uint8_t* fixed_levels;       // [max_n][n_factors] levels of the deterministic allocation walk
+  const double* crit;                // [n_grid][crit_stride]
+  uint8_t* unc;                      // [n_sims_total][n_grid][n_tests] or null
+  uint8_t* cor;
+  uint8_t* conv;                     // [n_sims_total][n_grid] or null
+  uint8_t* overall;
+  double* stat;                      // [n_sims_total][n_tests] or null
+  unsigned long long* counters;      // [n_grid][ctr_stride]
+  uint32_t ctr_stride, ctr_k_unc, ctr_k_cor, ctr_conv, ctr_overall, ctr_hist_unc, ctr_hist_cor, ctr_n_sims;
+
+  // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
+  float* tile;
+  uint32_t tile_sims;
+};
+
+}  // namespace mcp

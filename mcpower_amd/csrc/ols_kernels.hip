@@ -1,0 +1,642 @@
+// ols_kernels.hip -- gfx950 kernels of the OLS simulate path.
+//
+// Mapping: ONE LANE PER REPLICATE (64 replicates per wavefront).  Every
+// replicate keeps its whole state in registers: the 4-row Philox block of every
+// design column, the lower triangle of X'X, X'y, y'y and the p x p Cholesky
+// factor -- no LDS staging, no cross-lane reduction and no divergence on the
+// integer/RNG path, which is what bounds this kernel.
+//
+// Reference functions restated here (crates/engine-core/src):
+//   data_gen.rs:87-925 generate_sim_data (continuous block :316-363, residual
+//     :412-421, factor walk :509-551, interactions :643-649, y assembly :781-857)
+//   batch.rs:871-1142 OLS arm of run_one_sim (grid-incremental sufficient
+//     statistics, t^2 per target, correction, overall F)
+//   correction.rs:16-92 apply_correction
+// The X'X accumulation and Cholesky solve replace glmm 0.1.2's
+// OlsSuffStats::add_rows / fit_suff_stats_t_sq (out of tree; semantics from the
+// call sites batch.rs:884-968 and posthoc.rs:62-149).
+#include <hip/hip_runtime.h>
+#include "mcp_device.hpp"
+#include "mcp_params.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mcp {
+
+constexpr double EPS_RANK = 1e-12;         // batch.rs:41
+constexpr double FLOAT_NEAR_ZERO = 1e-30;  // lib.rs:46
+
+enum : int { MODE_FUSED = 0, MODE_GENERATE = 1, MODE_FIT = 2 };
+
+template <int P>
+struct Suff {
+  double sxx[(P - 1) * P / 2];  // x_a.x_b for 1 <= b <= a < P
+  double sx[P - 1];             // column sums (= X'X[a][0], the intercept column is 1)
+  double sxy[P - 1];
+  double sy, syy;
+};
+
+template <int P>
+__device__ __forceinline__ void suff_reset(Suff<P>& s) {
+#pragma unroll
+  for (int i = 0; i < (P - 1) * P / 2; ++i) s.sxx[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < P - 1; ++i) {
+    s.sx[i] = 0.0;
+    s.sxy[i] = 0.0;
+  }
+  s.sy = 0.0;
+  s.syy = 0.0;
+}
+
+// one design row into the sufficient statistics (replaces glmm add_rows; f64, fma)
+template <int P>
+__device__ __forceinline__ void suff_add_row(Suff<P>& s, const float (&xg)[P][4], const float (&yg)[4], int r) {
+  const double y = (double)yg[r];
+  double xd[P];
+#pragma unroll
+  for (int a = 1; a < P; ++a) xd[a] = (double)xg[a][r];
+  int idx = 0;
+#pragma unroll
+  for (int a = 1; a < P; ++a) {
+#pragma unroll
+    for (int b = 1; b <= a; ++b) {
+      s.sxx[idx] = __builtin_fma(xd[a], xd[b], s.sxx[idx]);
+      ++idx;
+    }
+    s.sx[a - 1] += xd[a];
+    s.sxy[a - 1] = __builtin_fma(xd[a], y, s.sxy[a - 1]);
+  }
+  s.sy += y;
+  s.syy = __builtin_fma(y, y, s.syy);
+}
+
+// categorical draw on the sequential stream (rng.rs:112-127)
+__device__ __forceinline__ uint32_t categorical(const SimParams& prm, uint32_t f, uint32_t k0, uint32_t k1, uint64_t q) {
+  const double u = (double)u32_to_unit_f32(sequential_word(k0, k1, q));
+  const uint32_t nl = prm.f_levels[f];
+  const uint32_t off = prm.f_prop_off[f];
+  double acc = 0.0;
+  uint32_t lvl = nl - 1;
+  bool found = false;
+  for (uint32_t i = 0; i < nl; ++i) {
+    acc += prm.f_props[off + i];
+    if (!found && u < acc) {
+      lvl = i;
+      found = true;
+    }
+  }
+  return lvl;
+}
+
+// rows 4*ctr .. 4*ctr+3 of one replicate: design columns and outcome (data_gen.rs:286-857)
+template <int P>
+__device__ __forceinline__ void gen_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr,
+                                          float (&xg)[P][4], float (&yg)[4]) {
+  const uint32_t K = prm.K;
+  // (a) continuous block: planar normals (rng.rs:236), then the L.z mix in f64, k ascending (data_gen.rs:334-351)
+  float z[P - 1][4];
+#pragma unroll
+  for (int j = 0; j < P - 1; ++j) {
+    if ((uint32_t)j < K) {
+      const u32x4 w = planar_words(k0, k1, CLASS_XNORM, (uint32_t)j, ctr);
+      z[j][0] = norm_inv_cdf_f32(u32_to_unit_f32(w.x));
+      z[j][1] = norm_inv_cdf_f32(u32_to_unit_f32(w.y));
+      z[j][2] = norm_inv_cdf_f32(u32_to_unit_f32(w.z));
+      z[j][3] = norm_inv_cdf_f32(u32_to_unit_f32(w.w));
+    } else {
+      z[j][0] = z[j][1] = z[j][2] = z[j][3] = 0.0f;
+    }
+  }
+  // (c) residual column: CLASS_RESID slot 0, N(0,1) (data_gen.rs:412-421)
+  float e[4];
+  {
+    const u32x4 w = planar_words(k0, k1, CLASS_RESID, 0u, ctr);
+    e[0] = norm_inv_cdf_f32(u32_to_unit_f32(w.x));
+    e[1] = norm_inv_cdf_f32(u32_to_unit_f32(w.y));
+    e[2] = norm_inv_cdf_f32(u32_to_unit_f32(w.z));
+    e[3] = norm_inv_cdf_f32(u32_to_unit_f32(w.w));
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t row = 4u * ctr + (uint32_t)r;
+    xg[0][r] = 1.0f;
+    // factor levels of this row (data_gen.rs:513-551)
+    uint32_t lvl[MAX_FACTORS];
+#pragma unroll
+    for (int f = 0; f < MAX_FACTORS; ++f) {
+      lvl[f] = 0u;
+      if ((uint32_t)f < prm.n_factors) {
+        if (prm.f_sampled[f]) {
+          const uint64_t q = (uint64_t)prm.n_seq_pre + (uint64_t)row * prm.n_seq_per_row + prm.f_seq_slot[f];
+          lvl[f] = categorical(prm, (uint32_t)f, k0, k1, q);
+        } else {
+          lvl[f] = row < prm.max_n ? (uint32_t)prm.fixed_levels[(size_t)row * prm.n_factors + f] : 0u;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 1; c < P; ++c) {
+      float v = 0.0f;
+      if ((uint32_t)(c - 1) < K) {
+        if (prm.ident_L) {
+          v = z[c - 1][r];
+        } else {
+          double acc = 0.0;
+#pragma unroll
+          for (int t = 0; t < c; ++t) {  // t <= j = c - 1
+            const double l = prm.L[(c - 1) * MAX_K + t];
+            if (l != 0.0) acc = acc + l * (double)z[t][r];  // separately rounded mul, add
+          }
+          v = (float)acc;
+        }
+      } else if (prm.col_factor[c] != 0xffffffffu) {
+        const uint32_t f = prm.col_factor[c];
+        const uint32_t lv = f == 0 ? lvl[0] : (f == 1 ? lvl[1] : (f == 2 ? lvl[2] : lvl[3]));
+        v = (lv == prm.col_level[c]) ? 1.0f : 0.0f;
+      } else if (prm.inter_mask[c] != 0u) {
+        // raw elementwise product in f64, components ascending (data_gen.rs:643-649)
+        double prod = 1.0;
+#pragma unroll
+        for (int cc = 1; cc < c; ++cc)
+          if ((prm.inter_mask[c] >> cc) & 1u) prod = prod * (double)xg[cc][r];
+        v = (float)prod;
+      }
+      xg[c][r] = v;
+    }
+    // y = f32( sum_j f64(x_ij) beta_j + f64(eps_i) + u_re )  (data_gen.rs:785-857); zero betas add exact zeros
+    double lp = 0.0;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const double b = prm.beta[c];
+      if (b != 0.0) lp = lp + (double)xg[c][r] * b;
+    }
+    yg[r] = (float)((lp + (double)e[r]) + 0.0);
+  }
+}
+
+// Holm / BH need the descending order of t^2 (correction.rs:96-115): rank_i = number of tests ordered before i
+template <int T>
+__device__ __forceinline__ void ranks_desc(const double (&t)[T], uint32_t n, uint32_t (&rank)[T]) {
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    uint32_t rk = 0;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      if ((uint32_t)j < n && j != i) {
+        const bool in = t[i] != t[i], jn = t[j] != t[j];
+        bool before;  // j sorts before i
+        if (in && jn) before = j < i;
+        else if (jn) before = false;
+        else if (in) before = true;
+        else before = (t[j] > t[i]) || (t[j] == t[i] && j < i);
+        rk += before ? 1u : 0u;
+      }
+    }
+    rank[i] = rk;
+  }
+}
+
+// Fit the accumulated prefix of n rows and decide every test (batch.rs:956-1142).
+template <int P>
+__device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& s, uint32_t g, uint32_t n,
+                                           bool active, uint32_t out_row) {
+  // ---- X'X (lower) and X'y ----
+  double A[P][P];
+  double rhs[P];
+  A[0][0] = (double)n;
+  rhs[0] = s.sy;
+  {
+    int idx = 0;
+#pragma unroll
+    for (int a = 1; a < P; ++a) {
+      A[a][0] = s.sx[a - 1];
+      rhs[a] = s.sxy[a - 1];
+#pragma unroll
+      for (int b = 1; b <= a; ++b) A[a][b] = s.sxx[idx++];
+    }
+  }
+  // ---- Cholesky, converged = min|L_ii| / max|L_ii| >= EPS_RANK (batch.rs:40-41) ----
+  double Lm[P][P];
+  double invd[P];
+  bool ok = true;
+  double dmin = __builtin_inf(), dmax = 0.0;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    double d = A[j][j];
+#pragma unroll
+    for (int t = 0; t < j; ++t) d = __builtin_fma(-Lm[j][t], Lm[j][t], d);
+    ok = ok && (d > 0.0) && (d < __builtin_inf());
+    const double ljj = __builtin_sqrt(d);
+    Lm[j][j] = ljj;
+    invd[j] = 1.0 / ljj;
+    dmin = ljj < dmin ? ljj : dmin;
+    dmax = ljj > dmax ? ljj : dmax;
+#pragma unroll
+    for (int i = j + 1; i < P; ++i) {
+      double v = A[i][j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) v = __builtin_fma(-Lm[i][t], Lm[j][t], v);
+      Lm[i][j] = v * invd[j];
+    }
+  }
+  const bool conv = ok && (dmin / dmax >= EPS_RANK);
+  // ---- beta = (L L')^-1 X'y ----
+  double zf[P], beta[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    double v = rhs[i];
+#pragma unroll
+    for (int t = 0; t < i; ++t) v = __builtin_fma(-Lm[i][t], zf[t], v);
+    zf[i] = v * invd[i];
+  }
+#pragma unroll
+  for (int i = P - 1; i >= 0; --i) {
+    double v = zf[i];
+#pragma unroll
+    for (int t = i + 1; t < P; ++t) v = __builtin_fma(-Lm[t][i], beta[t], v);
+    beta[i] = v * invd[i];
+  }
+  double bxty = 0.0;
+#pragma unroll
+  for (int i = 0; i < P; ++i) bxty = __builtin_fma(beta[i], rhs[i], bxty);
+  const double nd = (double)n;
+  const double rss = s.syy - bxty;
+  const double df = nd - (double)P;
+  const double sigma_sq = rss / df;
+  const double sst = s.syy - s.sy * s.sy / nd;
+
+  // ---- squared statistic per test: (c'beta)^2 / (sigma^2 ||L^-1 c||^2)  (posthoc.rs:86-99) ----
+  const double* crow = prm.crit + (size_t)g * prm.crit_stride;
+  const double crit_unc = crow[0];
+  const uint32_t nt = prm.n_tests;
+  double tsq[MAX_T];
+#pragma unroll
+  for (int t = 0; t < MAX_T; ++t) {
+    tsq[t] = __builtin_nan("");
+    if ((uint32_t)t < nt) {
+      const double* c = prm.contrast + t * MAX_P;
+      double est = 0.0, nq = 0.0;
+      double u[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        est = __builtin_fma(c[i], beta[i], est);
+        double acc = c[i];
+#pragma unroll
+        for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lm[i][q], u[q], acc);
+        u[i] = acc * invd[i];
+        nq = __builtin_fma(u[i], u[i], nq);
+      }
+      const double se_sq = sigma_sq * nq;
+      if (conv && se_sq > FLOAT_NEAR_ZERO && se_sq < __builtin_inf()) tsq[t] = est * est / se_sq;
+    }
+  }
+
+  // ---- decisions (batch.rs:1089-1117, correction.rs:16-92) ----
+  uint32_t unc_bits = 0, cor_bits = 0;
+#pragma unroll
+  for (int t = 0; t < MAX_T; ++t)
+    if ((uint32_t)t < nt && tsq[t] > crit_unc) unc_bits |= 1u << t;  // NaN compares false
+  const int method = prm.correction;
+  if (method == 0) {
+    cor_bits = unc_bits;
+  } else if (method == 1 || method == 4) {  // Bonferroni / Tukey: per-target threshold
+#pragma unroll
+    for (int t = 0; t < MAX_T; ++t)
+      if ((uint32_t)t < nt && tsq[t] > crow[1 + t]) cor_bits |= 1u << t;
+  } else {
+    uint32_t rank[MAX_T];
+    ranks_desc<MAX_T>(tsq, nt, rank);
+    uint32_t okb = 0;  // test t clears the threshold of its own rank
+#pragma unroll
+    for (int t = 0; t < MAX_T; ++t) {
+      if ((uint32_t)t < nt) {
+        double cr = crow[1];
+#pragma unroll
+        for (int k = 1; k < MAX_T; ++k) cr = (rank[t] == (uint32_t)k && (uint32_t)k < nt) ? crow[1 + k] : cr;
+        if (tsq[t] > cr) okb |= 1u << t;
+      }
+    }
+    if (method == 2) {  // Holm step-down: pass while every better-ranked test passed
+#pragma unroll
+      for (int t = 0; t < MAX_T; ++t) {
+        if ((uint32_t)t < nt) {
+          bool pass = true;
+#pragma unroll
+          for (int j = 0; j < MAX_T; ++j)
+            if ((uint32_t)j < nt && rank[j] <= rank[t] && !((okb >> j) & 1u)) pass = false;
+          if (pass) cor_bits |= 1u << t;
+        }
+      }
+    } else {  // BH step-up: everything ranked at or above the last passing rank
+      int last = -1;
+#pragma unroll
+      for (int t = 0; t < MAX_T; ++t)
+        if ((uint32_t)t < nt && ((okb >> t) & 1u)) last = (int)rank[t] > last ? (int)rank[t] : last;
+#pragma unroll
+      for (int t = 0; t < MAX_T; ++t)
+        if ((uint32_t)t < nt && (int)rank[t] <= last) cor_bits |= 1u << t;
+    }
+  }
+  if (!conv) {
+    unc_bits = 0;
+    cor_bits = 0;
+  }
+  // overall F (batch.rs:1118-1142)
+  bool ov = false;
+  if (prm.report_overall && conv) {
+    const double dfn = (double)(P - 1);
+    if (sst > 1e-10 && rss > 0.0 && rss < __builtin_inf() && sst < __builtin_inf()) {
+      const double f = ((sst - rss) / dfn) / (rss / df);
+      ov = (f < __builtin_inf()) && (f > crow[3 + nt]);
+    }
+  }
+
+  // ---- per-replicate tensors (BatchResult, spec.rs:553-600) ----
+  if (active) {
+    const size_t cell = (size_t)out_row * prm.n_grid + g;
+    if (prm.unc) {
+#pragma unroll
+      for (int t = 0; t < MAX_T; ++t)
+        if ((uint32_t)t < nt) {
+          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
+          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
+        }
+    }
+    if (prm.conv) prm.conv[cell] = conv ? 1 : 0;
+    if (prm.overall) prm.overall[cell] = ov ? 1 : 0;
+    if (prm.stat && g == 0) {
+#pragma unroll
+      for (int t = 0; t < MAX_T; ++t)
+        if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
+    }
+  }
+
+  // ---- additive counters (aggregation.rs:84-284): one atomic per wave per counter ----
+  unsigned long long* ctr = prm.counters + (size_t)g * prm.ctr_stride;
+  const bool lane0 = (threadIdx.x & 63u) == 0u;
+  const uint32_t ub = active ? unc_bits : 0u, cb = active ? cor_bits : 0u;
+#pragma unroll
+  for (int t = 0; t < MAX_T; ++t) {
+    if ((uint32_t)t < nt) {
+      const unsigned long long mu = __ballot((ub >> t) & 1u);
+      const unsigned long long mc = __ballot((cb >> t) & 1u);
+      if (lane0) {
+        if (mu) atomicAdd(ctr + prm.ctr_k_unc + t, (unsigned long long)__popcll(mu));
+        if (mc) atomicAdd(ctr + prm.ctr_k_cor + t, (unsigned long long)__popcll(mc));
+      }
+    }
+  }
+  const uint32_t ku = __popc(ub), kc = __popc(cb);
+#pragma unroll
+  for (int k = 0; k <= MAX_T; ++k) {
+    if ((uint32_t)k <= nt) {
+      const unsigned long long hu = __ballot(active && ku == (uint32_t)k);
+      const unsigned long long hc = __ballot(active && kc == (uint32_t)k);
+      if (lane0) {
+        if (hu) atomicAdd(ctr + prm.ctr_hist_unc + k, (unsigned long long)__popcll(hu));
+        if (hc) atomicAdd(ctr + prm.ctr_hist_cor + k, (unsigned long long)__popcll(hc));
+      }
+    }
+  }
+  {
+    const unsigned long long mcv = __ballot(active && conv);
+    const unsigned long long mov = __ballot(active && ov);
+    const unsigned long long mac = __ballot(active);
+    if (lane0) {
+      if (mcv) atomicAdd(ctr + prm.ctr_conv, (unsigned long long)__popcll(mcv));
+      if (mov) atomicAdd(ctr + prm.ctr_overall, (unsigned long long)__popcll(mov));
+      if (mac) atomicAdd(ctr + prm.ctr_n_sims, (unsigned long long)__popcll(mac));
+    }
+  }
+}
+
+// MODE_FUSED   : generate + accumulate + fit, nothing but flags/counters leaves the chip
+// MODE_GENERATE: generate and store the design tile [column][row][replicate] (f32) to HBM
+// MODE_FIT     : read the tile back (coalesced across replicates) and fit
+template <int P, int MODE>
+__global__ __launch_bounds__(256) void ols_sim_kernel(const SimParams* __restrict__ pp) {
+  const SimParams& prm = *pp;
+  const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = local < prm.n_sims;
+  const uint32_t lsim = active ? local : (prm.n_sims - 1u);
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);  // rng.rs:61-69
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t out_row = prm.out_base + lsim;
+  const uint32_t max_n = prm.max_n;
+  const size_t tile_col = (size_t)max_n * prm.tile_sims;  // floats per tile column
+
+  float xg[P][4];
+  float yg[4];
+  Suff<P> s;
+  suff_reset(s);
+
+  uint32_t row = 0;
+  if (MODE == MODE_GENERATE) {
+    for (uint32_t ctr = 0; 4u * ctr < max_n; ++ctr) {
+      gen_group<P>(prm, k0, k1, ctr, xg, yg);
+      if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t rr = 4u * ctr + r;
+          if (rr < max_n) {
+#pragma unroll
+            for (int c = 1; c < P; ++c) prm.tile[(size_t)(c - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] = xg[c][r];
+            prm.tile[(size_t)(P - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] = yg[r];
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n_end = prm.ns[g];
+    while (row < n_end) {
+      const uint32_t base = row & ~3u;
+      if (MODE == MODE_FUSED) {
+        if ((row & 3u) == 0u) gen_group<P>(prm, k0, k1, row >> 2, xg, yg);
+      } else {  // MODE_FIT: coalesced loads, lane = replicate
+        if ((row & 3u) == 0u) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t rr = base + r;
+            const bool in = rr < max_n;
+#pragma unroll
+            for (int c = 1; c < P; ++c)
+              xg[c][r] = in ? prm.tile[(size_t)(c - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] : 0.0f;
+            yg[r] = in ? prm.tile[(size_t)(P - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] : 0.0f;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t rr = base + (uint32_t)r;
+        if (rr >= row && rr < n_end) suff_add_row<P>(s, xg, yg, r);
+      }
+      const uint32_t nxt = base + 4u;
+      row = nxt < n_end ? nxt : n_end;
+    }
+    fit_decide<P>(prm, s, g, n_end, active, out_row);
+  }
+}
+
+// ---- introspect::fit_provided_data for the OLS arm: one lane per provided design ----
+// design: [fit][column][row] f32 (column 0 must be the intercept), outcome: [fit][row]
+template <int P>
+__global__ __launch_bounds__(64) void ols_fit_provided_kernel(const float* __restrict__ design,
+                                                              const float* __restrict__ outcome, uint32_t n_fits,
+                                                              uint32_t n, double* __restrict__ beta_out,
+                                                              double* __restrict__ se_out, double* __restrict__ tsq_out,
+                                                              double* __restrict__ rss_out, double* __restrict__ sst_out,
+                                                              uint8_t* __restrict__ conv_out) {
+  const uint32_t fit = blockIdx.x * blockDim.x + threadIdx.x;
+  if (fit >= n_fits) return;
+  const float* X = design + (size_t)fit * n * P;
+  const float* Y = outcome + (size_t)fit * n;
+  Suff<P> s;
+  suff_reset(s);
+  float xg[P][4];
+  float yg[4];
+  for (uint32_t i = 0; i < n; ++i) {
+#pragma unroll
+    for (int c = 1; c < P; ++c) xg[c][0] = X[(size_t)c * n + i];
+    yg[0] = Y[i];
+    suff_add_row<P>(s, xg, yg, 0);
+  }
+  double A[P][P], rhs[P], Lm[P][P], invd[P];
+  A[0][0] = (double)n;
+  rhs[0] = s.sy;
+  {
+    int idx = 0;
+#pragma unroll
+    for (int a = 1; a < P; ++a) {
+      A[a][0] = s.sx[a - 1];
+      rhs[a] = s.sxy[a - 1];
+#pragma unroll
+      for (int b = 1; b <= a; ++b) A[a][b] = s.sxx[idx++];
+    }
+  }
+  bool ok = true;
+  double dmin = __builtin_inf(), dmax = 0.0;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    double d = A[j][j];
+#pragma unroll
+    for (int t = 0; t < j; ++t) d = __builtin_fma(-Lm[j][t], Lm[j][t], d);
+    ok = ok && (d > 0.0) && (d < __builtin_inf());
+    const double ljj = __builtin_sqrt(d);
+    Lm[j][j] = ljj;
+    invd[j] = 1.0 / ljj;
+    dmin = ljj < dmin ? ljj : dmin;
+    dmax = ljj > dmax ? ljj : dmax;
+#pragma unroll
+    for (int i = j + 1; i < P; ++i) {
+      double v = A[i][j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) v = __builtin_fma(-Lm[i][t], Lm[j][t], v);
+      Lm[i][j] = v * invd[j];
+    }
+  }
+  const bool conv = ok && (dmin / dmax >= EPS_RANK);
+  double zf[P], beta[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    double v = rhs[i];
+#pragma unroll
+    for (int t = 0; t < i; ++t) v = __builtin_fma(-Lm[i][t], zf[t], v);
+    zf[i] = v * invd[i];
+  }
+#pragma unroll
+  for (int i = P - 1; i >= 0; --i) {
+    double v = zf[i];
+#pragma unroll
+    for (int t = i + 1; t < P; ++t) v = __builtin_fma(-Lm[t][i], beta[t], v);
+    beta[i] = v * invd[i];
+  }
+  double bxty = 0.0;
+#pragma unroll
+  for (int i = 0; i < P; ++i) bxty = __builtin_fma(beta[i], rhs[i], bxty);
+  const double nd = (double)n;
+  const double rss = s.syy - bxty;
+  const double sigma_sq = rss / (nd - (double)P);
+  rss_out[fit] = rss;
+  sst_out[fit] = s.syy - s.sy * s.sy / nd;
+  conv_out[fit] = conv ? 1 : 0;
+  // (X'X)^-1_jj = ||L^-1 e_j||^2
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    double u[P], nq = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lm[i][q], u[q], acc);
+      u[i] = acc * invd[i];
+      nq = __builtin_fma(u[i], u[i], nq);
+    }
+    const double se_sq = sigma_sq * nq;
+    beta_out[(size_t)fit * P + j] = conv ? beta[j] : __builtin_nan("");
+    se_out[(size_t)fit * P + j] = conv ? __builtin_sqrt(se_sq) : __builtin_nan("");
+    tsq_out[(size_t)fit * P + j] = (conv && se_sq > FLOAT_NEAR_ZERO) ? beta[j] * beta[j] / se_sq : __builtin_nan("");
+  }
+}
+
+// ---- exhaustive check kernel for the frozen inverse-CDF: out[i] = icdf(u32_to_unit_f32(first + i * stride)) ----
+__global__ void icdf_probe_kernel(uint32_t first_word, uint32_t stride, uint32_t n, float* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = norm_inv_cdf_f32(u32_to_unit_f32(first_word + i * stride));
+}
+
+}  // namespace mcp
+
+// ---- launchers (C++ linkage, called from host_api.hip) ----
+namespace mcp {
+
+template <int MODE>
+static hipError_t launch_sim_p(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  const dim3 block(256), grid((n_sims + 255u) / 256u);
+  switch (P) {
+    case 2: hipLaunchKernelGGL((ols_sim_kernel<2, MODE>), grid, block, 0, st, d_prm); break;
+    case 3: hipLaunchKernelGGL((ols_sim_kernel<3, MODE>), grid, block, 0, st, d_prm); break;
+    case 4: hipLaunchKernelGGL((ols_sim_kernel<4, MODE>), grid, block, 0, st, d_prm); break;
+    case 5: hipLaunchKernelGGL((ols_sim_kernel<5, MODE>), grid, block, 0, st, d_prm); break;
+    case 6: hipLaunchKernelGGL((ols_sim_kernel<6, MODE>), grid, block, 0, st, d_prm); break;
+    case 7: hipLaunchKernelGGL((ols_sim_kernel<7, MODE>), grid, block, 0, st, d_prm); break;
+    case 8: hipLaunchKernelGGL((ols_sim_kernel<8, MODE>), grid, block, 0, st, d_prm); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  return launch_sim_p<MODE_FUSED>(P, d_prm, n_sims, st);
+}
+hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  return launch_sim_p<MODE_GENERATE>(P, d_prm, n_sims, st);
+}
+hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  return launch_sim_p<MODE_FIT>(P, d_prm, n_sims, st);
+}
+
+hipError_t launch_ols_fit_provided(int P, const float* design, const float* outcome, uint32_t n_fits, uint32_t n,
+                                   double* beta, double* se, double* tsq, double* rss, double* sst, uint8_t* conv,
+                                   hipStream_t st) {
+  const dim3 block(64), grid((n_fits + 63u) / 64u);
+#define LFP(PP) \
+  case PP: hipLaunchKernelGGL((ols_fit_provided_kernel<PP>), grid, block, 0, st, design, outcome, n_fits, n, beta, se, tsq, rss, sst, conv); break;
+  switch (P) {
+    LFP(2) LFP(3) LFP(4) LFP(5) LFP(6) LFP(7) LFP(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef LFP
+  return hipGetLastError();
+}
+
+hipError_t launch_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(icdf_probe_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, first_word, stride, n, out);
+  return hipGetLastError();
+}
+
+}  // namespace mcp

@@ -1,0 +1,63 @@
+"""One process per GPU: shard the replicate range and pool the additive counters.
+
+The reference has no multi-process path; its closest analogue is the browser worker pool,
+which runs `single_core_find_power` per worker and pools raw counters with
+`merge_power_results` (`/root/reference/crates/engine-orchestrator/src/merge.rs:26-70`,
+`ports/wasm/src/seeds.ts:98-103`).  Here rank r of W takes the contiguous slice
+[r*S/W, (r+1)*S/W) of sim_ids with the SAME base_seed (so the union is bit-identical to a
+single-device run, unlike the browser pool which re-seeds per worker), and the only exchange
+on the data path is ONE all-reduce (sum) of the counter vector -- RCCL over xGMI when the
+process group's backend is "nccl", gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+
+def shard_range(n_sims: int, rank: int, world: int) -> Tuple[int, int]:
+    """(offset, count) of rank's contiguous replicate slice; slices partition [0, n_sims)."""
+    lo = n_sims * rank // world
+    hi = n_sims * (rank + 1) // world
+    return lo, hi - lo
+
+
+def allreduce_counters(counters: np.ndarray, group=None) -> np.ndarray:
+    """Sum the (n_ss, stride) uint64 counter block over all ranks (one collective).
+
+    Counts are far below 2^63, so the payload travels as int64 (torch has no uint64 reduction)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return counters.copy()
+    backend = dist.get_backend(group)
+    t = torch.from_numpy(counters.astype(np.int64, copy=True))
+    if backend == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy().astype(np.uint64)
+
+
+def wilson_ci(k: int, n: int):
+    """Wilson 95% score interval, z = 1.96 (reference aggregation.rs:18-36) -- recomputed from pooled counts."""
+    if n == 0:
+        return 0.0, 1.0
+    z = 1.96
+    p = k / n
+    z2 = z * z
+    den = 1.0 + z2 / n
+    center = (p + z2 / (2.0 * n)) / den
+    margin = z * ((p * (1.0 - p) / n + z2 / (4.0 * n * n)) ** 0.5) / den
+    return max(center - margin, 0.0), min(center + margin, 1.0)
+
+
+def run_batch_sharded(spec, sample_sizes, n_sims: int, base_seed: int, *, rank: int, world: int, group=None, **kw):
+    """Each rank runs its slice on its own GPU (counters-only), then one all-reduce pools the counts.
+    Returns (pooled_counters, local BatchResult)."""
+    from . import engine
+
+    off, cnt = shard_range(n_sims, rank, world)
+    local = engine.run_batch(spec, sample_sizes, cnt, base_seed, per_sim=False, sim_offset=off, **kw)
+    return allreduce_counters(local.counters, group), local

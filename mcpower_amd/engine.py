@@ -1,0 +1,177 @@
+"""ctypes binding over the C ABI (`include/mcpower_hip.h`), mirroring the reference's
+`engine_core` entry points: `run_batch`, `run_batch_st`, `run_batch_st_capture`,
+`set_n_threads` (-> `set_device`) -- `/root/reference/crates/engine-core/src/batch.rs:93-197`.
+
+The library is the product: if `libmcpower_hip.so` is missing or no MI355X is
+visible the calls raise; nothing here falls back to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import spec as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "_build", "libmcpower_hip.so")
+EXPORTS = (
+    "mcp_abi_version", "mcp_last_error", "mcp_set_device", "mcp_device_count", "mcp_run_batch", "mcp_free_result",
+    "mcp_build_crit_table", "mcp_t_ppf", "mcp_norm_ppf", "mcp_chi2_ppf", "mcp_f_ppf", "mcp_generate_design",
+    "mcp_fit_design", "mcp_icdf_probe",
+)
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with mcpower_amd.engine.build() "
+                               "(make -C mcpower_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.mcp_abi_version.restype = C.c_uint32
+        L.mcp_last_error.restype = C.c_char_p
+        L.mcp_set_device.argtypes = [C.c_int]
+        L.mcp_run_batch.restype = C.c_int
+        L.mcp_run_batch.argtypes = [C.POINTER(S.CSpec), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint64,
+                                    C.POINTER(S.CRunOptions), S.PROGRESS_FN, C.c_void_p, C.POINTER(S.CBatchResult)]
+        L.mcp_free_result.argtypes = [C.POINTER(S.CBatchResult)]
+        for name, n in (("mcp_t_ppf", 2), ("mcp_norm_ppf", 1), ("mcp_chi2_ppf", 2), ("mcp_f_ppf", 3)):
+            getattr(L, name).restype = C.c_double
+            getattr(L, name).argtypes = [C.c_double] * n
+        if L.mcp_abi_version() != S.ABI_VERSION:
+            raise RuntimeError("libmcpower_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise S.EngineError(rc, (lib().mcp_last_error() or b"").decode() or f"status {rc}")
+
+
+def device_count() -> int:
+    return int(lib().mcp_device_count())
+
+
+def set_device(index: int) -> None:
+    """One process per GPU: replaces `set_n_threads` (batch.rs:93)."""
+    _check(lib().mcp_set_device(int(index)))
+
+
+def run_batch(spec: S.SimulationSpec, sample_sizes: Sequence[int], n_sims: int, base_seed: int,
+              sink: Optional[Callable[[int, int], bool]] = None, *, per_sim: bool = True, stat_capture: bool = False,
+              staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0) -> S.BatchResult:
+    """`run_batch(spec, sample_sizes, n_sims, base_seed, sink)` (batch.rs:130).
+
+    `sink(current, total) -> bool` is `ProgressSink::report` (return False to cancel -> EngineError Cancelled).
+    Keyword extras: `per_sim=False` returns only the additive counters (reduced form for 1e7-replicate runs),
+    `sim_offset` makes this call the shard [sim_offset, sim_offset + n_sims) of a larger run,
+    `staged=True` selects the generator -> HBM design tile -> fit pipeline instead of the fused kernel.
+    """
+    low = spec.to_c()
+    ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
+    opts = S.CRunOptions()
+    opts.flags = (S.WANT_PER_SIM if per_sim else 0) | (S.WANT_STAT_CAPTURE if stat_capture else 0) | (
+        S.PIPELINE_STAGED if staged else 0)
+    opts.chunk_sims = int(chunk_sims)
+    opts.sim_offset = int(sim_offset)
+    opts.hip_stream = hip_stream or None
+    res = S.CBatchResult()
+    cb = S.PROGRESS_FN(lambda cur, tot, _u: 1 if sink(int(cur), int(tot)) else 0) if sink else S.PROGRESS_FN()
+    rc = lib().mcp_run_batch(low.byref(), ns.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(ns.size),
+                             C.c_uint32(n_sims), C.c_uint64(base_seed), C.byref(opts), cb, None, C.byref(res))
+    _check(rc)
+    try:
+        return S.result_from_c(res)
+    finally:
+        lib().mcp_free_result(C.byref(res))
+
+
+def run_batch_st(spec, sample_sizes, n_sims, base_seed, sink=None, **kw) -> S.BatchResult:
+    """`run_batch_st` (batch.rs:157): bit-identical to `run_batch`; there is no thread order on the device."""
+    return run_batch(spec, sample_sizes, n_sims, base_seed, sink, **kw)
+
+
+def run_batch_st_capture(spec, sample_sizes, n_sims, base_seed, **kw):
+    """`run_batch_st_capture` (batch.rs:180): also returns the (n_sims, n_targets) squared statistics of grid point 0."""
+    r = run_batch(spec, sample_sizes, n_sims, base_seed, None, stat_capture=True, **kw)
+    return r, r.stat_capture
+
+
+def build_crit_table(spec: S.SimulationSpec, sample_sizes) -> np.ndarray:
+    low = spec.to_c()
+    ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
+    out = np.zeros((ns.size, spec.n_targets + 4), dtype=np.float64)
+    _check(lib().mcp_build_crit_table(low.byref(), ns.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(ns.size),
+                                      out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def t_ppf(p, df):
+    return lib().mcp_t_ppf(p, df)
+
+
+def norm_ppf(p):
+    return lib().mcp_norm_ppf(p)
+
+
+def chi2_ppf(p, k):
+    return lib().mcp_chi2_ppf(p, k)
+
+
+def f_ppf(p, dfn, dfd):
+    return lib().mcp_f_ppf(p, dfn, dfd)
+
+
+def generate_design(spec: S.SimulationSpec, max_n: int, n_sims: int, base_seed: int, sim_offset: int = 0):
+    """`introspect::capture_sim0_data` (introspect.rs:104) for a replicate range.
+    -> design (n_sims, max_n, p) f32, outcome (n_sims, max_n) f32."""
+    low = spec.to_c()
+    p = spec.n_predictors
+    d = np.zeros((n_sims, p, max_n), dtype=np.float32)
+    y = np.zeros((n_sims, max_n), dtype=np.float32)
+    _check(lib().mcp_generate_design(low.byref(), C.c_uint32(max_n), C.c_uint32(n_sims), C.c_uint64(base_seed),
+                                     C.c_uint64(sim_offset), d.ctypes.data_as(C.POINTER(C.c_float)),
+                                     y.ctypes.data_as(C.POINTER(C.c_float))))
+    return np.transpose(d, (0, 2, 1)), y
+
+
+def fit_design(design: np.ndarray, outcome: np.ndarray):
+    """`introspect::fit_provided_data` (introspect.rs:174), OLS arm: design (n_fits, n, p), outcome (n_fits, n)."""
+    design = np.asarray(design, dtype=np.float32)
+    if design.ndim == 2:
+        design, outcome = design[None], np.asarray(outcome)[None]
+    nf, n, p = design.shape
+    x = np.ascontiguousarray(np.transpose(design, (0, 2, 1)))
+    y = np.ascontiguousarray(outcome, dtype=np.float32)
+    beta, se, tsq = (np.zeros((nf, p)) for _ in range(3))
+    rss, sst = np.zeros(nf), np.zeros(nf)
+    conv = np.zeros(nf, dtype=np.uint8)
+    pd = C.POINTER(C.c_double)
+    _check(lib().mcp_fit_design(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                                C.c_uint32(nf), C.c_uint32(n), C.c_uint32(p), beta.ctypes.data_as(pd),
+                                se.ctypes.data_as(pd), tsq.ctypes.data_as(pd), rss.ctypes.data_as(pd),
+                                sst.ctypes.data_as(pd), conv.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return dict(beta=beta, se=se, t_sq=tsq, rss=rss, sst=sst, converged=conv.astype(bool))
+
+
+def icdf_probe(first_word: int, stride: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.float32)
+    _check(lib().mcp_icdf_probe(C.c_uint32(first_word), C.c_uint32(stride), C.c_uint32(n),
+                                out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out

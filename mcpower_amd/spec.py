@@ -206,7 +206,7 @@ class CBatchResult(C.Structure):
         ("joint_unc", _pu8), ("joint_cor", _pu8), ("overall", _pu8), ("factor_excluded", _pu8),
         ("tau_squared_hat", _pd), ("stat_capture", _pd),
         ("counters", _pu64), ("layout", CCounterLayout),
-        ("device_ms", C.c_double), ("kernel_ms", C.c_double),
+        ("device_ms", C.c_double), ("kernel_ms", C.c_double), ("aux_kernel_ms", C.c_double),
         ("n_kernel_launches", C.c_uint32), ("_pad", C.c_uint32),
     ]
 
@@ -470,6 +470,7 @@ class BatchResult:
     layout: dict
     device_ms: float = 0.0
     kernel_ms: float = 0.0
+    aux_kernel_ms: float = 0.0
     n_kernel_launches: int = 0
 
     def counter(self, name: str, width: int = 1) -> np.ndarray:
@@ -509,5 +510,6 @@ def result_from_c(r: CBatchResult) -> BatchResult:
         layout=layout,
         device_ms=r.device_ms,
         kernel_ms=r.kernel_ms,
+        aux_kernel_ms=r.aux_kernel_ms,
         n_kernel_launches=r.n_kernel_launches,
     )

@@ -53,6 +53,8 @@ void mcpo_fill_words(const uint32_t key[2], uint32_t cls, uint32_t col, uint32_t
 void mcpo_fill_uniform_column(const uint32_t key[2], uint32_t cls, uint32_t col, float* out, uint32_t n);
 void mcpo_fill_normal_column(const uint32_t key[2], uint32_t cls, uint32_t col, float* out, uint32_t n);
 
+void mcpo_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out);
+
 /* golden-test helpers: n draws of one stream kind for (base_seed, sim_id);
  * kind 0 = next_normal, 1 = next_uniform, 2 = scenario_rng next_uniform */
 void mcpo_stream_f32(uint64_t base_seed, uint64_t sim_id, int kind, float* out, uint32_t n);

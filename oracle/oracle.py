@@ -90,6 +90,13 @@ def norm_inv_cdf_f32(u: np.ndarray) -> np.ndarray:
     return np.array([f(float(x)) for x in np.asarray(u, dtype=np.float32)], dtype=np.float32)
 
 
+def icdf_probe(first_word: int, stride: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.float32)
+    lib().mcpo_icdf_probe(C.c_uint32(first_word), C.c_uint32(stride), C.c_uint32(n),
+                          out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
 def stream_f32(base_seed: int, sim_id: int, kind: str, n: int) -> np.ndarray:
     out = np.zeros(n, dtype=np.float32)
     k = {"normal": 0, "uniform": 1, "scenario_uniform": 2}[kind]

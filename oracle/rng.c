@@ -206,3 +206,8 @@ static double erfc_as(double x) {
 
 double mcpo_phi(double z) { return 0.5 * erfc_as(-z * 0.70710678118654752440); }
 double mcpo_marginal_uniform(double z, double a, double b) { return a + (b - a) * mcpo_phi(z); }
+
+/* batch probe used by the exhaustive inverse-CDF parity test (rng.rs:539 sweeps all 2^23 reachable uniforms) */
+void mcpo_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out) {
+  for (uint32_t i = 0; i < n; ++i) out[i] = mcpo_norm_inv_cdf_f32(mcpo_u32_to_unit_f32(first_word + i * stride));
+}

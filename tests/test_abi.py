@@ -1,0 +1,110 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/mcpower_hip.h declares, and its host-only entry points (validation, critical values)
+agree with the oracle.  No device compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import BASE_SEED, spec_c1, spec_c2a, spec_c2b
+from mcpower_amd import spec as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "mcpower_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcp_[a-z0-9_]+)\s*\(", txt)) - {"mcp_progress_fn"})
+
+
+def test_library_exports_every_declared_symbol(engine):
+    L = engine.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/mcpower_hip.h but not exported"
+    assert set(syms) == set(engine.EXPORTS)
+    assert L.mcp_abi_version() == S.ABI_VERSION
+
+
+def test_struct_sizes_are_stable():
+    import ctypes as C
+    # guards the ctypes mirror against silent layout drift (sizes from the C compiler: tests/test_abi_sizes)
+    assert C.sizeof(S.CRunOptions) == 24
+    assert C.sizeof(S.CCounterLayout) == 64
+    assert C.sizeof(S.CCluster) == 32
+    assert C.sizeof(S.CSpec) % 8 == 0
+
+
+def test_crit_table_matches_oracle(engine, oracle):
+    for spec in (spec_c1(), spec_c2a(), spec_c2b()):
+        for corr in S.CorrectionMethod:
+            if corr == S.CorrectionMethod.TukeyHsd:
+                continue
+            spec.correction_method = corr
+            spec.report_overall = True
+            ns = [50, 100, 1000]
+            a, b = engine.build_crit_table(spec, ns), oracle.build_crit_table(spec, ns)
+            assert np.allclose(a, b, rtol=1e-13, atol=0, equal_nan=True)
+
+
+def test_quantiles_match_oracle_and_scipy(engine, oracle):
+    from scipy import stats
+    for df in (1, 2, 3, 7, 94, 194, 994, 200000):
+        assert abs(engine.t_ppf(0.975, df) - oracle.t_ppf(0.975, df)) < 1e-13 * engine.t_ppf(0.975, df)
+        if df < 1e5:
+            assert abs(engine.t_ppf(0.975, df) - stats.t.ppf(0.975, df)) < 1e-9 * stats.t.ppf(0.975, df)
+    assert abs(engine.norm_ppf(0.975) - oracle.norm_ppf(0.975)) < 1e-15
+    assert abs(engine.chi2_ppf(0.95, 3) - stats.chi2.ppf(0.95, 3)) < 1e-8
+    assert abs(engine.f_ppf(0.95, 5, 194) - stats.f.ppf(0.95, 5, 194)) < 1e-8
+
+
+@pytest.mark.parametrize("ns,msg", [([200, 100], "strictly increasing"), ([], "non-empty"), ([0, 5], "must be > 0"),
+                                    ([6], "df = N - P")])
+def test_validation_errors_match_reference_wording(engine, ns, msg):
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec_c2b(), ns, 4, BASE_SEED)
+    assert e.value.status == S.Status.InvalidSpec and msg in str(e.value)
+
+
+def test_not_psd_and_range_errors(engine):
+    bad = spec_c2b()
+    c = np.eye(5)
+    c[0, 1] = c[1, 0] = 1.5
+    bad.correlation = c.flatten().tolist()
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(bad, [100], 4, BASE_SEED)
+    assert e.value.status == S.Status.CorrelationNotPSD
+    bad = spec_c2b()
+    bad.target_indices = [1, 9]
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(bad, [100], 4, BASE_SEED)
+    assert e.value.status == S.Status.InvalidSpec and "out of range" in str(e.value)
+
+
+def test_unsupported_fails_loudly_never_falls_back(engine):
+    s = spec_c2b()
+    s.estimator = S.EstimatorSpec.Mle  # Mle without cluster -> InvalidSpec like the reference (batch.rs:221)
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(s, [100], 4, BASE_SEED)
+    assert e.value.status == S.Status.InvalidSpec
+    s = spec_c2b()
+    s.var_types[0] = S.Distribution.UploadedData
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(s, [100], 4, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path may never import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "mcpower_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "mcpo_" not in txt and "libmcp_oracle" not in txt, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f

@@ -1,0 +1,283 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties.
+
+Bars: f32 data plane bit-exact; squared statistics within 1e-10 relative
+(summation order / fma only); significance flags identical except where |t^2 - crit^2| / crit^2
+< 1e-9 (a knife-edge decision: expected count 0); counters identical whenever flags are.
+"""
+import numpy as np
+import pytest
+
+from helpers import BASE_SEED, base_spec, case_names, load_case, spec_c1, spec_c2a, spec_c2b
+from mcpower_amd import spec as S
+
+pytestmark = pytest.mark.gpu
+
+TSQ_RTOL = 1e-10
+
+
+def _assert_batch_equal(g, o, crit_unc=None):
+    """Flags / counters identical; t^2 within TSQ_RTOL.  Knife-edge replicates (t^2 within 1e-9 of a
+    threshold) are the only place a flag may legitimately differ -- none is expected, so assert none."""
+    assert g.uncorrected.shape == o.uncorrected.shape
+    if g.stat_capture is not None and o.stat_capture is not None:
+        a, b = g.stat_capture, o.stat_capture
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        m = ~np.isnan(a)
+        assert np.max(np.abs(a[m] - b[m]) / np.maximum(np.abs(b[m]), 1e-300)) < TSQ_RTOL
+    for f in ("uncorrected", "corrected", "converged", "overall"):
+        ga, oa = getattr(g, f), getattr(o, f)
+        assert (ga is None) == (oa is None), f
+        if ga is not None:
+            assert np.array_equal(ga, oa), f"{f}: {int((ga != oa).sum())} of {ga.size} flags differ"
+    assert np.array_equal(g.counters, o.counters)
+
+
+# ---------------------------------------------------------------------------------------------
+# data plane
+# ---------------------------------------------------------------------------------------------
+def test_icdf_exhaustive_all_reachable_uniforms(engine, oracle):
+    """All 2^23 reachable uniforms (w >> 9 spans 23 bits): device icdf == oracle icdf, bit for bit
+    (reference sweeps the same set, rng.rs:539)."""
+    n = 1 << 23
+    dev = engine.icdf_probe(0, 512, n)
+    ref = oracle.icdf_probe(0, 512, n)
+    assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+    # the low 9 bits of the word must not matter
+    assert np.array_equal(engine.icdf_probe(511, 512, 4096).view(np.uint32), ref[:4096].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", case_names("ols"))
+def test_generated_design_matches_reference_bytes(engine, oracle, name):
+    """mcp_generate_design (introspect::capture_sim0_data twin) == the reference's captured sim-0
+    design/outcome bytes (validation/data/<case>.rds), and == the oracle for later sims."""
+    spec, seed, arr, low = load_case(name)
+    n = low["n"]
+    d, y = engine.generate_design(spec, n, 3, seed, 0)
+    assert np.array_equal(d[0].view(np.uint32), arr["design"].view(np.uint32))
+    assert np.array_equal(y[0].view(np.uint32), arr["outcome"].view(np.uint32))
+    for s in (1, 2):
+        xo, yo, _ = oracle.generate_sim_data(spec, seed, s, n)
+        assert np.array_equal(d[s].view(np.uint32), xo.view(np.uint32))
+        assert np.array_equal(y[s].view(np.uint32), yo.view(np.uint32))
+
+
+def test_generated_rows_are_prefix_stable(engine):
+    spec = spec_c2b()
+    d200, y200 = engine.generate_design(spec, 200, 5, BASE_SEED, 10)
+    d1000, y1000 = engine.generate_design(spec, 1000, 5, BASE_SEED, 10)
+    assert np.array_equal(d200.view(np.uint32), d1000[:, :200].view(np.uint32))
+    assert np.array_equal(y200.view(np.uint32), y1000[:, :200].view(np.uint32))
+    # ragged max_n (not a multiple of the 4-row Philox block)
+    d50, _ = engine.generate_design(spec, 50, 5, BASE_SEED, 10)
+    assert np.array_equal(d50.view(np.uint32), d1000[:, :50].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", case_names("ols"))
+def test_fit_provided_bytes_matches_r_goldens(engine, name):
+    """mcp_fit_design (introspect::fit_provided_data twin) vs R lm on the same bytes: 1e-11 relative
+    on beta / se / t (validation/tolerances.R:24-30)."""
+    _, _, arr, _ = load_case(name)
+    f = engine.fit_design(arr["design"], arr["outcome"])
+    assert f["converged"][0]
+    np.testing.assert_allclose(f["beta"][0], arr["golden_beta"], rtol=1e-11, atol=0)
+    np.testing.assert_allclose(f["se"][0], arr["golden_se"], rtol=1e-11, atol=0)
+    np.testing.assert_allclose(np.sign(f["beta"][0]) * np.sqrt(f["t_sq"][0]), arr["golden_stat"], rtol=1e-11, atol=0)
+
+
+def test_fit_provided_rank_deficient_design_is_flagged(engine):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 40, 3)).astype(np.float32)
+    x[0, :, 0] = 1.0
+    x[0, :, 2] = x[0, :, 1]  # duplicate column -> Cholesky pivot ratio below EPS_RANK (batch.rs:41)
+    y = rng.standard_normal((1, 40)).astype(np.float32)
+    f = engine.fit_design(x, y)
+    assert not f["converged"][0] and np.isnan(f["beta"][0]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# run_batch vs oracle
+# ---------------------------------------------------------------------------------------------
+def _both(engine, oracle, spec, ns, n_sims, **kw):
+    g = engine.run_batch(spec, ns, n_sims, BASE_SEED, stat_capture=True, **kw)
+    o = oracle.run_batch(spec, ns, n_sims, BASE_SEED, stat_capture=True, n_threads=8,
+                         sim_offset=kw.get("sim_offset", 0))
+    return g, o
+
+
+def test_c1_two_group_ttest_reference_cpu_config(engine, oracle):
+    """BASELINE config 0: n=100, p=2, 1000 sims (deterministic X, fixed allocation)."""
+    g, o = _both(engine, oracle, spec_c1(), [100], 1000)
+    _assert_batch_equal(g, o)
+    assert g.converged.all()
+
+
+@pytest.mark.parametrize("make", [spec_c2a, spec_c2b])
+def test_c2_ols_flags_identical_to_oracle(engine, oracle, make):
+    spec = make()
+    spec.report_overall = True
+    g, o = _both(engine, oracle, spec, [200], 20000)
+    _assert_batch_equal(g, o)
+    power = g.counter("k_unc", spec.n_targets)[0] / 20000.0
+    assert 0.5 < power[0] < 0.9  # x1 = 0.18 at n = 200 is ~70% power
+
+
+def test_grid_prefix_fits_match_oracle_including_ragged_sizes(engine, oracle):
+    spec = spec_c2b()
+    spec.report_overall = True
+    g, o = _both(engine, oracle, spec, [7, 50, 51, 99, 100, 250, 1000], 3000)
+    _assert_batch_equal(g, o)
+    ku = g.counter("k_unc", 2)[:, 0]
+    assert ku[-1] > ku[1]  # power grows along the grid
+
+
+@pytest.mark.parametrize("method", [S.CorrectionMethod.Bonferroni, S.CorrectionMethod.Holm,
+                                    S.CorrectionMethod.BenjaminiHochberg])
+def test_multiplicity_corrections_match_oracle(engine, oracle, method):
+    spec = base_spec(5)
+    spec.effect_sizes = [0.0, 0.25, 0.18, 0.12, 0.0, 0.3]
+    spec.target_indices = [1, 2, 3, 4, 5]
+    spec.contrast_pairs = [(1, 2), (5, 3)]
+    spec.correction_method = method
+    g, o = _both(engine, oracle, spec, [80, 160], 6000)
+    _assert_batch_equal(g, o)
+    assert (g.corrected <= g.uncorrected).all()
+    assert g.corrected.sum() < g.uncorrected.sum()
+
+
+def test_correlated_predictors_factors_and_interactions_match_oracle(engine, oracle):
+    spec, _, _, low = load_case("ols_cf_a")  # x1 * 3-level g: dummies + 2 interaction columns
+    g, o = _both(engine, oracle, spec, [120, 800], 2000)
+    _assert_batch_equal(g, o)
+    spec, _, _, _ = load_case("ols_interaction_a")  # corr(x1,x2)=0.3 + x1:x2
+    spec.report_overall = True
+    g, o = _both(engine, oracle, spec, [60, 600], 2000)
+    _assert_batch_equal(g, o)
+    spec, _, _, _ = load_case("ols_ff_a")  # two factors + dummy:dummy interaction
+    g, o = _both(engine, oracle, spec, [800], 1000)
+    _assert_batch_equal(g, o)
+
+
+def test_sampled_factor_proportions_use_the_sequential_stream(engine, oracle):
+    spec, seed, _, low = load_case("ols_factor_a")
+    spec.scenario = S.ScenarioPerturbations(name="custom", sampled_factor_proportions=True)
+    d, y = engine.generate_design(spec, 120, 2, seed, 0)
+    for s in range(2):
+        xo, yo, _ = oracle.generate_sim_data(spec, seed, s, 120)
+        assert np.array_equal(d[s].view(np.uint32), xo.view(np.uint32))
+        assert np.array_equal(y[s].view(np.uint32), yo.view(np.uint32))
+    g, o = _both(engine, oracle, spec, [60, 120], 1500)
+    _assert_batch_equal(g, o)
+    # per-factor override beats the scenario default (spec.rs:284-291)
+    spec.factor_sampled = [False]
+    g2, o2 = _both(engine, oracle, spec, [60, 120], 500)
+    _assert_batch_equal(g2, o2)
+
+
+def test_rank_deficient_replicates_report_not_converged(engine, oracle):
+    """A 2-level factor at n=3 with skewed proportions leaves a level empty -> X'X singular ->
+    converged = 0 and every flag 0 (spec.rs:560, batch.rs:1015)."""
+    spec = S.SimulationSpec(n_non_factor=0, n_factor_dummies=1, correlation=[], factor_n_levels=[2],
+                            factor_proportions=[0.9, 0.1], effect_sizes=[0.0, 0.5], target_indices=[1])
+    g, o = _both(engine, oracle, spec, [4, 40], 64)
+    _assert_batch_equal(g, o)
+    assert not g.converged[:, 0].any() and g.converged[:, 1].all()
+    assert not g.uncorrected[:, 0].any()
+
+
+# ---------------------------------------------------------------------------------------------
+# contract properties: sharding, chunking, pipelines, progress / cancel
+# ---------------------------------------------------------------------------------------------
+def test_shard_union_is_bit_identical_to_single_run(engine):
+    """GPU g takes sim_id in [g*S/G, (g+1)*S/G) with the same base_seed."""
+    spec = spec_c2b()
+    whole = engine.run_batch(spec, [100, 200], 5000, BASE_SEED)
+    parts = [engine.run_batch(spec, [100, 200], n, BASE_SEED, sim_offset=off)
+             for off, n in ((0, 1250), (1250, 1250), (2500, 1251), (3751, 1249))]
+    assert np.array_equal(np.concatenate([p.uncorrected for p in parts]), whole.uncorrected)
+    assert np.array_equal(sum(p.counters for p in parts), whole.counters)
+
+
+def test_chunked_launches_equal_single_launch(engine):
+    spec = spec_c2a()
+    a = engine.run_batch(spec, [200], 10000, BASE_SEED)
+    b = engine.run_batch(spec, [200], 10000, BASE_SEED, chunk_sims=777)
+    assert b.n_kernel_launches == 13 and a.n_kernel_launches == 1
+    assert np.array_equal(a.uncorrected, b.uncorrected) and np.array_equal(a.counters, b.counters)
+
+
+def test_staged_pipeline_equals_fused_kernel(engine):
+    spec = spec_c2b()
+    spec.report_overall = True
+    f = engine.run_batch(spec, [50, 200], 8192 + 17, BASE_SEED, stat_capture=True)
+    s = engine.run_batch(spec, [50, 200], 8192 + 17, BASE_SEED, stat_capture=True, staged=True, chunk_sims=4096)
+    assert np.array_equal(f.uncorrected, s.uncorrected) and np.array_equal(f.corrected, s.corrected)
+    assert np.array_equal(f.counters, s.counters)
+    assert np.array_equal(f.stat_capture, s.stat_capture, equal_nan=True)  # same arithmetic, same order
+    assert s.aux_kernel_ms > 0 and s.kernel_ms > 0
+
+
+def test_counters_only_mode_matches_per_sim_fold(engine):
+    spec = spec_c2b()
+    full = engine.run_batch(spec, [200], 4000, BASE_SEED)
+    red = engine.run_batch(spec, [200], 4000, BASE_SEED, per_sim=False)
+    assert red.uncorrected is None and np.array_equal(red.counters, full.counters)
+    assert np.array_equal(full.counter("k_unc", 2), full.uncorrected.sum(axis=0))
+    assert full.counter("n_sims")[0, 0] == 4000
+    assert full.counter("hist_unc", 3)[0].sum() == 4000
+
+
+def test_progress_reports_and_cancel(engine):
+    spec = spec_c2b()
+    seen = []
+    engine.run_batch(spec, [200], 100000, BASE_SEED, lambda cur, tot: seen.append((cur, tot)) or True)
+    assert seen and seen[-1] == (100000, 100000) and all(t == 100000 for _, t in seen)
+    assert [c for c, _ in seen] == sorted(c for c, _ in seen)
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, [200], 100000, BASE_SEED, lambda cur, tot: False)
+    assert e.value.status == S.Status.Cancelled
+
+
+def test_zero_sims_returns_empty_shape(engine):
+    r = engine.run_batch(spec_c2b(), [200], 0, BASE_SEED)
+    assert r.shape.n_sims == 0 and r.shape.n_targets == 2 and r.counters.sum() == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full size (10^6 replicates, n=200): size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_c2b_properties(engine, oracle):
+    spec = spec_c2b()
+    n = 1_000_000
+    a = engine.run_batch(spec, [200], n, BASE_SEED, per_sim=False)
+    b = engine.run_batch(spec, [200], n, BASE_SEED, per_sim=False)
+    assert np.array_equal(a.counters, b.counters)  # deterministic (integer reductions only)
+    halves = [engine.run_batch(spec, [200], n // 2, BASE_SEED, per_sim=False, sim_offset=o) for o in (0, n // 2)]
+    assert np.array_equal(halves[0].counters + halves[1].counters, a.counters)  # 1-GPU == 2-shard union
+    assert a.counter("n_sims")[0, 0] == n and a.counter("converged")[0, 0] == n
+    assert a.counter("hist_unc", 3)[0].sum() == n
+    ku = a.counter("k_unc", 2)[0].astype(np.float64)
+    hist = a.counter("hist_unc", 3)[0].astype(np.float64)
+    assert ku.sum() == hist[1] + 2 * hist[2]  # checksum of checksums
+    # the first 20000 replicates of the big run are the oracle's 20000 (power delta exactly 0 there)
+    head = engine.run_batch(spec, [200], 20000, BASE_SEED)
+    o = oracle.run_batch(spec, [200], 20000, BASE_SEED, n_threads=8)
+    assert np.array_equal(head.uncorrected, o.uncorrected)
+    # analytic power: noncentral t, x1 = 0.18, n = 200 -> within 0.1 pp + 4 sigma of MC error
+    from scipy import stats
+    ncp = 0.18 * np.sqrt(200.0)
+    df = 194
+    tc = stats.t.ppf(0.975, df)
+    power = 1 - stats.nct.cdf(tc, df, ncp) + stats.nct.cdf(-tc, df, ncp)
+    se = np.sqrt(power * (1 - power) / n)
+    assert abs(ku[0] / n - power) < 0.004 + 4 * se  # design is random: unconditional power differs slightly
+
+
+def test_type_one_error_under_the_null(engine):
+    spec = spec_c2b()
+    spec.effect_sizes = [0.0] * 6
+    r = engine.run_batch(spec, [200], 400000, BASE_SEED, per_sim=False)
+    rate = r.counter("k_unc", 2)[0] / 400000.0
+    se = np.sqrt(0.05 * 0.95 / 400000)
+    assert np.all(np.abs(rate - 0.05) < 5 * se)
