@@ -25,7 +25,7 @@ def _assert_batch_equal(g, o, crit_unc=None):
         a, b = g.stat_capture, o.stat_capture
         assert np.array_equal(np.isnan(a), np.isnan(b))
         m = ~np.isnan(a)
-        assert np.max(np.abs(a[m] - b[m]) / np.maximum(np.abs(b[m]), 1e-300)) < TSQ_RTOL
+        assert (not m.any()) or np.max(np.abs(a[m] - b[m]) / np.maximum(np.abs(b[m]), 1e-300)) < TSQ_RTOL
     for f in ("uncorrected", "corrected", "converged", "overall"):
         ga, oa = getattr(g, f), getattr(o, f)
         assert (ga is None) == (oa is None), f
@@ -126,10 +126,14 @@ def test_c2_ols_flags_identical_to_oracle(engine, oracle, make):
 def test_grid_prefix_fits_match_oracle_including_ragged_sizes(engine, oracle):
     spec = spec_c2b()
     spec.report_overall = True
-    g, o = _both(engine, oracle, spec, [7, 50, 51, 99, 100, 250, 1000], 3000)
+    g, o = _both(engine, oracle, spec, [50, 51, 99, 100, 250, 1000], 3000)
     _assert_batch_equal(g, o)
     ku = g.counter("k_unc", 2)[:, 0]
-    assert ku[-1] > ku[1]  # power grows along the grid
+    assert ku[-1] > ku[0]  # power grows along the grid
+    # df = 1 (n = 7, p = 6): X'X is nearly singular, so t^2 carries the conditioning of the normal
+    # equations (observed ~3e-8 relative); decisions must still agree
+    g, o = engine.run_batch(spec, [7, 9, 200], 3000, BASE_SEED), oracle.run_batch(spec, [7, 9, 200], 3000, BASE_SEED)
+    _assert_batch_equal(g, o)
 
 
 @pytest.mark.parametrize("method", [S.CorrectionMethod.Bonferroni, S.CorrectionMethod.Holm,
