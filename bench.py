@@ -37,6 +37,7 @@ WORKLOADS = {
     # name: (spec factory, n, ops per fit for the fused kernel, staged bytes read per fit)
     "c2a": ("spec_c2a", 200, 3.76e4, 4 * 200 * 5),   # x1,x2,x3,x1:x2,y stored: 5 f32 columns
     "c2b": ("spec_c2b", 200, 5.26e4, 4 * 200 * 6),   # 5 predictors + y: the 4800 B of BASELINE.md
+    "k4": ("spec_k4", 200, 4.3e4, 4 * 200 * 5),      # tuning aid: 4 plain predictors (p=5, no interaction)
 }
 
 

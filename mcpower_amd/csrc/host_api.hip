@@ -21,9 +21,9 @@
 #include "mcp_params.hpp"
 
 namespace mcp {
-hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
-hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
-hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
+hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, bool factors, hipStream_t st);
+hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, bool factors, hipStream_t st);
+hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, hipStream_t st);
 hipError_t launch_ols_fit_provided(int P, const float* design, const float* outcome, uint32_t n_fits, uint32_t n,
                                    double* beta, double* se, double* tsq, double* rss, double* sst, uint8_t* conv,
                                    hipStream_t st);
@@ -234,7 +234,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     if (spec->report_overall) DEV_TRY(ar.get(S_OVERALL, cells + 1, (void**)&d_ov));
   }
   if (want_stat) DEV_TRY(ar.get(S_STAT, ((size_t)n_sims * nt + 1) * sizeof(double), (void**)&d_stat));
-  if (staged) DEV_TRY(ar.get(S_TILE, (size_t)P * prm.max_n * chunk * sizeof(float), (void**)&d_tile));
+  // design tile: [block of 256 replicates][P columns: x1..x_{P-1}, y][max_n rows][256] f32
+  if (staged) DEV_TRY(ar.get(S_TILE, (size_t)((chunk + 255u) / 256u) * 256u * P * prm.max_n * sizeof(float), (void**)&d_tile));
 
   hipEvent_t ev_begin, ev_end;
   DEV_TRY(ar.event(0, &ev_begin));
@@ -274,12 +275,12 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     if (staged) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
     DEV_TRY(hipEventRecord(e0, st));
     if (!staged) {
-      DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, spec->n_factors > 0, st));
       DEV_TRY(hipEventRecord(e1, st));
     } else {
-      DEV_TRY(mcp::launch_ols_generate((int)P, d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(mcp::launch_ols_generate((int)P, d_prm + c, h_prm[c].n_sims, spec->n_factors > 0, st));
       DEV_TRY(hipEventRecord(e1, st));
-      DEV_TRY(mcp::launch_ols_fit((int)P, d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(mcp::launch_ols_fit((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, st));
       DEV_TRY(hipEventRecord(e2, st));
     }
     ++launched;
@@ -367,7 +368,8 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   mcp::SimParams* d_prm = nullptr;
   uint8_t* d_levels = nullptr;
   float* d_tile = nullptr;
-  const size_t tile_floats = (size_t)P * max_n * n_sims;
+  const uint32_t n_blocks = (n_sims + 255u) / 256u;
+  const size_t tile_floats = (size_t)n_blocks * 256u * P * max_n;
   HIP_TRY(ar.get(S_PRM, sizeof(mcp::SimParams), (void**)&d_prm));
   HIP_TRY(ar.get(S_LEVELS, low.fixed_levels.size(), (void**)&d_levels));
   HIP_TRY(ar.get(S_TILE, tile_floats * sizeof(float), (void**)&d_tile));
@@ -379,18 +381,20 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   prm.tile = d_tile;
   prm.tile_sims = n_sims;
   HIP_TRY(hipMemcpyAsync(d_prm, &prm, sizeof prm, hipMemcpyHostToDevice, st));
-  HIP_TRY(mcp::launch_ols_generate((int)P, d_prm, n_sims, st));
+  HIP_TRY(mcp::launch_ols_generate((int)P, d_prm, n_sims, spec->n_factors > 0, st));
   std::vector<float> tile(tile_floats);
   HIP_TRY(hipMemcpyAsync(tile.data(), d_tile, tile_floats * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  // tile [column: x1..x_{P-1}, y][row][sim] -> design [sim][column 0..P-1][row], outcome [sim][row]
-  const size_t col = (size_t)max_n * n_sims;
+  // tile [block][column: x1..x_{P-1}, y][row][256] -> design [sim][column 0..P-1][row], outcome [sim][row]
+  auto at = [&](uint32_t s, uint32_t c, uint32_t i) {
+    return tile[(((size_t)(s / 256u) * P + c) * max_n + i) * 256u + (s % 256u)];
+  };
   for (uint32_t s = 0; s < n_sims; ++s) {
     float* d = design_out + (size_t)s * P * max_n;
     for (uint32_t i = 0; i < max_n; ++i) d[i] = 1.0f;
     for (uint32_t c = 1; c < P; ++c)
-      for (uint32_t i = 0; i < max_n; ++i) d[(size_t)c * max_n + i] = tile[(size_t)(c - 1) * col + (size_t)i * n_sims + s];
-    for (uint32_t i = 0; i < max_n; ++i) outcome_out[(size_t)s * max_n + i] = tile[(size_t)(P - 1) * col + (size_t)i * n_sims + s];
+      for (uint32_t i = 0; i < max_n; ++i) d[(size_t)c * max_n + i] = at(s, c - 1, i);
+    for (uint32_t i = 0; i < max_n; ++i) outcome_out[(size_t)s * max_n + i] = at(s, P - 1, i);
   }
   return MCP_OK;
 }

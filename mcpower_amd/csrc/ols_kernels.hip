@@ -1,10 +1,13 @@
 // ols_kernels.hip -- gfx950 kernels of the OLS simulate path.
 //
-// Mapping: ONE LANE PER REPLICATE (64 replicates per wavefront).  Every
-// replicate keeps its whole state in registers: the 4-row Philox block of every
-// design column, the lower triangle of X'X, X'y, y'y and the p x p Cholesky
-// factor -- no LDS staging, no cross-lane reduction and no divergence on the
-// integer/RNG path, which is what bounds this kernel.
+// Mapping: ONE LANE PER REPLICATE (64 replicates per wavefront).  A replicate's
+// sufficient statistics (lower triangle of X'X, X'y, y'y) and its p x p Cholesky
+// factor live in registers; the 4-row Philox block of every design column is
+// staged in LDS ([slot][lane], conflict-free) so that the ~4.85 % of draws that
+// need the tail branch of the inverse CDF are fixed up in a short wave-level
+// loop instead of executing both branches for every draw.  No cross-lane
+// reduction, no divergence on the integer/RNG path, which is what bounds this
+// kernel.
 //
 // Reference functions restated here (crates/engine-core/src):
 //   data_gen.rs:87-925 generate_sim_data (continuous block :316-363, residual
@@ -51,11 +54,11 @@ __device__ __forceinline__ void suff_reset(Suff<P>& s) {
 
 // one design row into the sufficient statistics (replaces glmm add_rows; f64, fma)
 template <int P>
-__device__ __forceinline__ void suff_add_row(Suff<P>& s, const float (&xg)[P][4], const float (&yg)[4], int r) {
-  const double y = (double)yg[r];
+__device__ __forceinline__ void suff_add_row(Suff<P>& s, const float (&x)[P], float yf) {
+  const double y = (double)yf;
   double xd[P];
 #pragma unroll
-  for (int a = 1; a < P; ++a) xd[a] = (double)xg[a][r];
+  for (int a = 1; a < P; ++a) xd[a] = (double)x[a];
   int idx = 0;
 #pragma unroll
   for (int a = 1; a < P; ++a) {
@@ -89,44 +92,87 @@ __device__ __forceinline__ uint32_t categorical(const SimParams& prm, uint32_t f
   return lvl;
 }
 
-// rows 4*ctr .. 4*ctr+3 of one replicate: design columns and outcome (data_gen.rs:286-857)
-template <int P>
-__device__ __forceinline__ void gen_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr,
-                                          float (&xg)[P][4], float (&yg)[4]) {
-  const uint32_t K = prm.K;
-  // (a) continuous block: planar normals (rng.rs:236), then the L.z mix in f64, k ascending (data_gen.rs:334-351)
-  float z[P - 1][4];
-#pragma unroll
-  for (int j = 0; j < P - 1; ++j) {
-    if ((uint32_t)j < K) {
-      const u32x4 w = planar_words(k0, k1, CLASS_XNORM, (uint32_t)j, ctr);
-      z[j][0] = norm_inv_cdf_f32(u32_to_unit_f32(w.x));
-      z[j][1] = norm_inv_cdf_f32(u32_to_unit_f32(w.y));
-      z[j][2] = norm_inv_cdf_f32(u32_to_unit_f32(w.z));
-      z[j][3] = norm_inv_cdf_f32(u32_to_unit_f32(w.w));
-    } else {
-      z[j][0] = z[j][1] = z[j][2] = z[j][3] = 0.0f;
-    }
-  }
-  // (c) residual column: CLASS_RESID slot 0, N(0,1) (data_gen.rs:412-421)
-  float e[4];
-  {
-    const u32x4 w = planar_words(k0, k1, CLASS_RESID, 0u, ctr);
-    e[0] = norm_inv_cdf_f32(u32_to_unit_f32(w.x));
-    e[1] = norm_inv_cdf_f32(u32_to_unit_f32(w.y));
-    e[2] = norm_inv_cdf_f32(u32_to_unit_f32(w.z));
-    e[3] = norm_inv_cdf_f32(u32_to_unit_f32(w.w));
-  }
+// ---- 4-row block staging ------------------------------------------------------------------
+// LDS layout: stage[slot * 256 + tid], slot = 4 * column + r, column j < K = continuous predictor j,
+// column K = the residual.  One Philox call yields rows 4*ctr..4*ctr+3 of one column (rng.rs:149-178).
+constexpr int BLOCK = 256;
+
+__device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const u32x4 w, uint32_t& pend) {
+  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const uint32_t row = 4u * ctr + (uint32_t)r;
-    xg[0][r] = 1.0f;
-    // factor levels of this row (data_gen.rs:513-551)
-    uint32_t lvl[MAX_FACTORS];
+    const float v = u32_to_unit_f32(ws[r]) - 0.5f;
+    const bool tail = __builtin_fabsf(v) > NORM_INV_BP;
+    const float z = icdf_central(v);           // branch-free central polynomial for every lane
+    st[(col_slot * 4u + r) * BLOCK] = tail ? v : z;  // tail lanes park v for the fix-up loop
+    pend |= tail ? (1u << (col_slot * 4u + r)) : 0u;
+  }
+}
+
+// rows 4*ctr .. 4*ctr+3 of one replicate: standard normals of every column into LDS (data_gen.rs:316-421)
+template <int P>
+__device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr, float* st) {
+  const uint32_t K = prm.K;
+  uint32_t pend = 0;
+#pragma unroll
+  for (int j = 0; j < P - 1; ++j)
+    if ((uint32_t)j < K) stage_column(st, (uint32_t)j, planar_words(k0, k1, CLASS_XNORM, (uint32_t)j, ctr), pend);
+  stage_column(st, K, planar_words(k0, k1, CLASS_RESID, 0u, ctr), pend);
+  // tail fix-up: each pass retires one parked draw per lane; ~3-4 passes per block instead of 4*(K+1)
+  while (__ballot(pend != 0u) != 0ull) {
+    if (pend != 0u) {
+      const uint32_t slot = (uint32_t)__builtin_ctz(pend);
+      pend &= pend - 1u;
+      st[slot * BLOCK] = icdf_tail(st[slot * BLOCK]);
+    }
+  }
+}
+
+// launch-constant values of the row loop, hoisted into scalar registers once per wave
+template <int P>
+struct RowCtx {
+  uint32_t K;
+  uint32_t ident_L;
+  uint32_t n_factors;        // 0 on the continuous-only fast path (FACTORS == false)
+  uint32_t beta_nz;          // bit c set when beta[c] != 0
+  uint32_t inter_any;        // bit c set when column c is an interaction
+  uint32_t imask[P];
+  double beta[P];
+};
+
+template <int P, bool FACTORS>
+__device__ __forceinline__ void row_ctx_init(const SimParams& prm, RowCtx<P>& cx) {
+  cx.K = prm.K;
+  cx.ident_L = prm.ident_L;
+  cx.n_factors = FACTORS ? prm.n_factors : 0u;
+  cx.beta_nz = 0u;
+  cx.inter_any = 0u;
+#pragma unroll
+  for (int c = 0; c < P; ++c) {
+    cx.beta[c] = prm.beta[c];
+    cx.imask[c] = prm.inter_mask[c];
+    cx.beta_nz |= (cx.beta[c] != 0.0) ? (1u << c) : 0u;
+    cx.inter_any |= (cx.imask[c] != 0u) ? (1u << c) : 0u;
+  }
+}
+
+// one design row + outcome from the staged normals (data_gen.rs:334-363, 509-551, 643-649, 781-857)
+template <int P, bool FACTORS>
+__device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
+                                          const float* st, int r, uint32_t row, float (&x)[P], float& y) {
+  const uint32_t K = cx.K;
+  float z[P - 1];
+#pragma unroll
+  for (int j = 0; j < P - 1; ++j) z[j] = ((uint32_t)j < K) ? st[(j * 4 + r) * BLOCK] : 0.0f;
+  const float e = st[(K * 4u + r) * BLOCK];
+  x[0] = 1.0f;
+  // factor levels of this row (data_gen.rs:513-551)
+  uint32_t lvl[MAX_FACTORS];
+  if (FACTORS) {
 #pragma unroll
     for (int f = 0; f < MAX_FACTORS; ++f) {
       lvl[f] = 0u;
-      if ((uint32_t)f < prm.n_factors) {
+      if ((uint32_t)f < cx.n_factors) {
         if (prm.f_sampled[f]) {
           const uint64_t q = (uint64_t)prm.n_seq_pre + (uint64_t)row * prm.n_seq_per_row + prm.f_seq_slot[f];
           lvl[f] = categorical(prm, (uint32_t)f, k0, k1, q);
@@ -135,44 +181,40 @@ __device__ __forceinline__ void gen_group(const SimParams& prm, uint32_t k0, uin
         }
       }
     }
-#pragma unroll
-    for (int c = 1; c < P; ++c) {
-      float v = 0.0f;
-      if ((uint32_t)(c - 1) < K) {
-        if (prm.ident_L) {
-          v = z[c - 1][r];
-        } else {
-          double acc = 0.0;
-#pragma unroll
-          for (int t = 0; t < c; ++t) {  // t <= j = c - 1
-            const double l = prm.L[(c - 1) * MAX_K + t];
-            if (l != 0.0) acc = acc + l * (double)z[t][r];  // separately rounded mul, add
-          }
-          v = (float)acc;
-        }
-      } else if (prm.col_factor[c] != 0xffffffffu) {
-        const uint32_t f = prm.col_factor[c];
-        const uint32_t lv = f == 0 ? lvl[0] : (f == 1 ? lvl[1] : (f == 2 ? lvl[2] : lvl[3]));
-        v = (lv == prm.col_level[c]) ? 1.0f : 0.0f;
-      } else if (prm.inter_mask[c] != 0u) {
-        // raw elementwise product in f64, components ascending (data_gen.rs:643-649)
-        double prod = 1.0;
-#pragma unroll
-        for (int cc = 1; cc < c; ++cc)
-          if ((prm.inter_mask[c] >> cc) & 1u) prod = prod * (double)xg[cc][r];
-        v = (float)prod;
-      }
-      xg[c][r] = v;
-    }
-    // y = f32( sum_j f64(x_ij) beta_j + f64(eps_i) + u_re )  (data_gen.rs:785-857); zero betas add exact zeros
-    double lp = 0.0;
-#pragma unroll
-    for (int c = 0; c < P; ++c) {
-      const double b = prm.beta[c];
-      if (b != 0.0) lp = lp + (double)xg[c][r] * b;
-    }
-    yg[r] = (float)((lp + (double)e[r]) + 0.0);
   }
+#pragma unroll
+  for (int c = 1; c < P; ++c) {
+    float v = 0.0f;
+    if ((uint32_t)(c - 1) < K) {
+      if (cx.ident_L) {
+        v = z[c - 1];
+      } else {  // x_j = f32( sum_{t<=j} L[j][t] * f64(z_t) ), t ascending, separately rounded (data_gen.rs:334-351)
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < c; ++t) {
+          const double l = prm.L[(c - 1) * MAX_K + t];
+          if (l != 0.0) acc = acc + l * (double)z[t];
+        }
+        v = (float)acc;
+      }
+    } else if ((cx.inter_any >> c) & 1u) {  // raw product in f64, components ascending (data_gen.rs:643-649)
+      double prod = 1.0;                    // non-members multiply by exactly 1.0: no branch, same bits
+#pragma unroll
+      for (int cc = 1; cc < c; ++cc) prod = prod * (((cx.imask[c] >> cc) & 1u) ? (double)x[cc] : 1.0);
+      v = (float)prod;
+    } else if (FACTORS && prm.col_factor[c] != 0xffffffffu) {
+      const uint32_t f = prm.col_factor[c];
+      const uint32_t lv = f == 0 ? lvl[0] : (f == 1 ? lvl[1] : (f == 2 ? lvl[2] : lvl[3]));
+      v = (lv == prm.col_level[c]) ? 1.0f : 0.0f;
+    }
+    x[c] = v;
+  }
+  // y = f32( sum_j f64(x_ij) beta_j + f64(eps_i) + u_re )  (data_gen.rs:785-857); zero betas add exact zeros
+  double lp = 0.0;
+#pragma unroll
+  for (int c = 0; c < P; ++c)
+    if ((cx.beta_nz >> c) & 1u) lp = lp + (double)x[c] * cx.beta[c];
+  y = (float)((lp + (double)e) + 0.0);
 }
 
 // Holm / BH need the descending order of t^2 (correction.rs:96-115): rank_i = number of tests ordered before i
@@ -411,13 +453,26 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   }
 }
 
+// tile layout of the staged pipeline: [block of 256 replicates][column: x1..x_{P-1}, y][row][256] f32 -- a
+// workgroup's whole design is one contiguous region, and a wave reads/writes 256 B per (column,row)
+__device__ __forceinline__ size_t tile_index(uint32_t P, uint32_t max_n, uint32_t blk, uint32_t c, uint32_t row) {
+  return (((size_t)blk * P + c) * max_n + row) * BLOCK;
+}
+
 // MODE_FUSED   : generate + accumulate + fit, nothing but flags/counters leaves the chip
-// MODE_GENERATE: generate and store the design tile [column][row][replicate] (f32) to HBM
-// MODE_FIT     : read the tile back (coalesced across replicates) and fit
-template <int P, int MODE>
-__global__ __launch_bounds__(256) void ols_sim_kernel(const SimParams* __restrict__ pp) {
+// MODE_GENERATE: generate and store the design tile to HBM
+// MODE_FIT     : stream the tile back (coalesced across replicates) and fit
+#ifndef MCP_LB_W
+#define MCP_LB_W 1
+#endif
+// GRID1: a single sample size (the common find_power call): the grid loop disappears and the sufficient
+// statistics are dead once X'X is formed, which frees their registers for the solve.
+// FACTORS == false: continuous-only design (no factor dummies) -- the factor walk / categorical code is compiled out.
+template <int P, int MODE, bool GRID1, bool FACTORS>
+__global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ float stage_lds[];
   const SimParams& prm = *pp;
-  const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t local = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = local < prm.n_sims;
   const uint32_t lsim = active ? local : (prm.n_sims - 1u);
   const uint64_t sim_id = prm.sim_begin + lsim;
@@ -425,58 +480,71 @@ __global__ __launch_bounds__(256) void ols_sim_kernel(const SimParams* __restric
   const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
   const uint32_t out_row = prm.out_base + lsim;
   const uint32_t max_n = prm.max_n;
-  const size_t tile_col = (size_t)max_n * prm.tile_sims;  // floats per tile column
+  float* st = stage_lds + threadIdx.x;
+  float* tile = prm.tile + threadIdx.x;
+  RowCtx<P> cx;
+  if (MODE != MODE_FIT) row_ctx_init<P, FACTORS>(prm, cx);
 
-  float xg[P][4];
-  float yg[4];
-  Suff<P> s;
-  suff_reset(s);
-
-  uint32_t row = 0;
   if (MODE == MODE_GENERATE) {
     for (uint32_t ctr = 0; 4u * ctr < max_n; ++ctr) {
-      gen_group<P>(prm, k0, k1, ctr, xg, yg);
-      if (active) {
+      stage_group<P>(prm, k0, k1, ctr, st);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t rr = 4u * ctr + r;
-          if (rr < max_n) {
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t rr = 4u * ctr + r;
+        if (rr < max_n) {
+          float x[P], y;
+          build_row<P, FACTORS>(prm, cx, k0, k1, st, r, rr, x, y);
 #pragma unroll
-            for (int c = 1; c < P; ++c) prm.tile[(size_t)(c - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] = xg[c][r];
-            prm.tile[(size_t)(P - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] = yg[r];
-          }
+          for (int c = 1; c < P; ++c) tile[tile_index(P, max_n, blockIdx.x, c - 1, rr)] = x[c];
+          tile[tile_index(P, max_n, blockIdx.x, P - 1, rr)] = y;
         }
       }
     }
     return;
   }
 
-  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+  Suff<P> s;
+  suff_reset(s);
+  uint32_t row = 0;
+  const uint32_t n_grid = GRID1 ? 1u : prm.n_grid;
+  for (uint32_t g = 0; g < n_grid; ++g) {
     const uint32_t n_end = prm.ns[g];
-    while (row < n_end) {
-      const uint32_t base = row & ~3u;
-      if (MODE == MODE_FUSED) {
-        if ((row & 3u) == 0u) gen_group<P>(prm, k0, k1, row >> 2, xg, yg);
-      } else {  // MODE_FIT: coalesced loads, lane = replicate
-        if ((row & 3u) == 0u) {
+    if (MODE == MODE_FUSED) {
+      while (row < n_end) {
+        const uint32_t base = row & ~3u;
+        if ((row & 3u) == 0u) stage_group<P>(prm, k0, k1, row >> 2, st);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const uint32_t rr = base + r;
-            const bool in = rr < max_n;
-#pragma unroll
-            for (int c = 1; c < P; ++c)
-              xg[c][r] = in ? prm.tile[(size_t)(c - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] : 0.0f;
-            yg[r] = in ? prm.tile[(size_t)(P - 1) * tile_col + (size_t)rr * prm.tile_sims + lsim] : 0.0f;
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t rr = base + (uint32_t)r;
+          if (rr >= row && rr < n_end) {
+            float x[P], y;
+            build_row<P, FACTORS>(prm, cx, k0, k1, st, r, rr, x, y);
+            suff_add_row<P>(s, x, y);
           }
         }
+        const uint32_t nxt = base + 4u;
+        row = nxt < n_end ? nxt : n_end;
       }
+    } else {  // MODE_FIT: 4 rows of loads in flight per lane before the first use
+      while (row + 4u <= n_end) {
+        float xb[4][P], yb[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t rr = base + (uint32_t)r;
-        if (rr >= row && rr < n_end) suff_add_row<P>(s, xg, yg, r);
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int c = 1; c < P; ++c) xb[r][c] = __builtin_nontemporal_load(&tile[tile_index(P, max_n, blockIdx.x, c - 1, row + r)]);
+          yb[r] = __builtin_nontemporal_load(&tile[tile_index(P, max_n, blockIdx.x, P - 1, row + r)]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) suff_add_row<P>(s, xb[r], yb[r]);
+        row += 4u;
       }
-      const uint32_t nxt = base + 4u;
-      row = nxt < n_end ? nxt : n_end;
+      for (; row < n_end; ++row) {
+        float x[P], y;
+#pragma unroll
+        for (int c = 1; c < P; ++c) x[c] = tile[tile_index(P, max_n, blockIdx.x, c - 1, row)];
+        y = tile[tile_index(P, max_n, blockIdx.x, P - 1, row)];
+        suff_add_row<P>(s, x, y);
+      }
     }
     fit_decide<P>(prm, s, g, n_end, active, out_row);
   }
@@ -497,13 +565,11 @@ __global__ __launch_bounds__(64) void ols_fit_provided_kernel(const float* __res
   const float* Y = outcome + (size_t)fit * n;
   Suff<P> s;
   suff_reset(s);
-  float xg[P][4];
-  float yg[4];
   for (uint32_t i = 0; i < n; ++i) {
+    float x[P];
 #pragma unroll
-    for (int c = 1; c < P; ++c) xg[c][0] = X[(size_t)c * n + i];
-    yg[0] = Y[i];
-    suff_add_row<P>(s, xg, yg, 0);
+    for (int c = 1; c < P; ++c) x[c] = X[(size_t)c * n + i];
+    suff_add_row<P>(s, x, Y[i]);
   }
   double A[P][P], rhs[P], Lm[P][P], invd[P];
   A[0][0] = (double)n;
@@ -594,30 +660,39 @@ __global__ void icdf_probe_kernel(uint32_t first_word, uint32_t stride, uint32_t
 // ---- launchers (C++ linkage, called from host_api.hip) ----
 namespace mcp {
 
-template <int MODE>
-static hipError_t launch_sim_p(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
-  const dim3 block(256), grid((n_sims + 255u) / 256u);
+template <int MODE, bool GRID1, bool FACTORS>
+static hipError_t launch_sim_pgf(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  const dim3 block(BLOCK), grid((n_sims + BLOCK - 1u) / BLOCK);
+  // staging area: 4 rows x (K + 1 <= P) columns x 256 lanes of f32 (none for the fit-only kernel)
+  const size_t lds = MODE == MODE_FIT ? 0 : (size_t)4 * P * BLOCK * sizeof(float);
   switch (P) {
-    case 2: hipLaunchKernelGGL((ols_sim_kernel<2, MODE>), grid, block, 0, st, d_prm); break;
-    case 3: hipLaunchKernelGGL((ols_sim_kernel<3, MODE>), grid, block, 0, st, d_prm); break;
-    case 4: hipLaunchKernelGGL((ols_sim_kernel<4, MODE>), grid, block, 0, st, d_prm); break;
-    case 5: hipLaunchKernelGGL((ols_sim_kernel<5, MODE>), grid, block, 0, st, d_prm); break;
-    case 6: hipLaunchKernelGGL((ols_sim_kernel<6, MODE>), grid, block, 0, st, d_prm); break;
-    case 7: hipLaunchKernelGGL((ols_sim_kernel<7, MODE>), grid, block, 0, st, d_prm); break;
-    case 8: hipLaunchKernelGGL((ols_sim_kernel<8, MODE>), grid, block, 0, st, d_prm); break;
+    case 2: hipLaunchKernelGGL((ols_sim_kernel<2, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
+    case 3: hipLaunchKernelGGL((ols_sim_kernel<3, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
+    case 4: hipLaunchKernelGGL((ols_sim_kernel<4, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
+    case 5: hipLaunchKernelGGL((ols_sim_kernel<5, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
+    case 6: hipLaunchKernelGGL((ols_sim_kernel<6, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
+    case 7: hipLaunchKernelGGL((ols_sim_kernel<7, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
+    case 8: hipLaunchKernelGGL((ols_sim_kernel<8, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
-  return launch_sim_p<MODE_FUSED>(P, d_prm, n_sims, st);
+template <int MODE>
+static hipError_t launch_sim(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, bool factors, hipStream_t st) {
+  if (MODE == MODE_FIT) factors = false;  // the fit kernel never builds rows
+  if (grid1) return factors ? launch_sim_pgf<MODE, true, true>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, true, false>(P, d_prm, n_sims, st);
+  return factors ? launch_sim_pgf<MODE, false, true>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, false, false>(P, d_prm, n_sims, st);
 }
-hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
-  return launch_sim_p<MODE_GENERATE>(P, d_prm, n_sims, st);
+
+hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, bool factors, hipStream_t st) {
+  return launch_sim<MODE_FUSED>(P, d_prm, n_sims, grid1, factors, st);
 }
-hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
-  return launch_sim_p<MODE_FIT>(P, d_prm, n_sims, st);
+hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, bool factors, hipStream_t st) {
+  return launch_sim<MODE_GENERATE>(P, d_prm, n_sims, true, factors, st);
+}
+hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, hipStream_t st) {
+  return launch_sim<MODE_FIT>(P, d_prm, n_sims, grid1, false, st);
 }
 
 hipError_t launch_ols_fit_provided(int P, const float* design, const float* outcome, uint32_t n_fits, uint32_t n,

@@ -105,6 +105,14 @@ def spec_c2b() -> S.SimulationSpec:
     return s
 
 
+def spec_k4() -> S.SimulationSpec:
+    """Tuning aid: 4 independent normal predictors, p = 5, no interaction."""
+    s = base_spec(4)
+    s.effect_sizes[1] = 0.18
+    s.effect_sizes[2] = 0.18
+    return s
+
+
 def spec_c3() -> S.SimulationSpec:
     """C3: glm_spec(3, 0.3): logit, beta0=ln(.3/.7), x1=x2=0.4, targets [1,2,3]."""
     s = base_spec(3)
