@@ -38,6 +38,8 @@ WORKLOADS = {
     "c2a": ("spec_c2a", 200, 3.76e4, 4 * 200 * 5),   # x1,x2,x3,x1:x2,y stored: 5 f32 columns
     "c2b": ("spec_c2b", 200, 5.26e4, 4 * 200 * 6),   # 5 predictors + y: the 4800 B of BASELINE.md
     "k4": ("spec_k4", 200, 4.3e4, 4 * 200 * 5),      # tuning aid: 4 plain predictors (p=5, no interaction)
+    # C3: logistic IRLS n=500 p=4: 2000 draws + ~5 passes x 500 rows x (exp, log1p, 2 div, 18 fma) ~ 5.0e5 ops
+    "c3": ("spec_c3", 500, 5.0e5, 4 * 500 * 4),
 }
 
 
@@ -47,7 +49,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2a", choices=sorted(WORKLOADS))
-    ap.add_argument("--sims-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--sims-per-gpu", type=int, default=0, help="default: 10^6 (OLS) / 10^5 (c3)")
     ap.add_argument("--pipeline", default="fused", choices=["fused", "staged"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -76,7 +78,7 @@ def main():
     fac, n_obs, ops_per_fit, bytes_per_fit = WORKLOADS[args.workload]
     spec = getattr(helpers, fac)()
     ns = [n_obs]
-    S = args.sims_per_gpu
+    S = args.sims_per_gpu or (100_000 if args.workload == "c3" else 1_000_000)
     staged = args.pipeline == "staged"
 
     def barrier():
@@ -122,22 +124,24 @@ def main():
             "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: OLS n={n_obs} p={spec.n_predictors} "
-                                   f"({'x1,x2,x3 + x1:x2' if args.workload == 'c2a' else 'ols_multi, 5 predictors'}), "
+            "config": {"workload": f"{args.workload}: {'OLS' if args.workload != 'c3' else 'GLM'} n={n_obs} p={spec.n_predictors} "
+                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'c3': 'logit IRLS, 3 predictors'}[args.workload] }), "
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": "1 all-reduce(sum) of counters per step"},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),
         }
+        is_ols = args.workload != "c3"
         if not staged:
             ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "valu", "kernel": f"ols_sim_kernel<{spec.n_predictors},fused>",
+            out["roofline"] = {"bound": "valu", "kernel": (f"ols_sim_kernel<{spec.n_predictors},fused>" if is_ols else f"glm_sim_kernel<{spec.n_predictors}>"),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
                                "traffic": None, "ops_per_fit": ops_per_fit, "avg_launch_ms": avg_launch_ms,
                                "fits_per_launch": fits_per_launch,
                                "note": "fused generate+fit: no design bytes touch HBM; bound is VALU/integer issue "
                                        "(SURVEY.md 8d); HBM-equivalent rate in hbm_equiv_gbs",
                                "hbm_equiv_gbs": bytes_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e9}
+        if not staged and is_ols:
             # the HBM-bound kernel of the path: staged fit over a resident design tile (measured outside the timed region)
             rs = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, staged=True)
             rs = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, staged=True)
@@ -149,7 +153,7 @@ def main():
                                           "frac": gbs / PEAK_HBM_GBS, "traffic": None, "bytes_per_fit": bytes_per_fit,
                                           "avg_launch_ms": fit_ms, "generator_launch_ms": rs.aux_kernel_ms / rs.n_kernel_launches,
                                           "fits_per_launch": fpl}
-        else:
+        if staged:
             gbs = bytes_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": f"ols_sim_kernel<{spec.n_predictors},fit>", "achieved": gbs,
                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,

@@ -1,0 +1,318 @@
+// glm_kernels.hip -- gfx950 kernels of the logistic-GLM (IRLS) simulate path.
+//
+// Mapping: ONE WAVEFRONT PER REPLICATE.  The replicate's n x p design (f32) and outcome are
+// generated straight into LDS ([column][row], lanes read consecutive rows: conflict-free) and stay
+// there for every IRLS pass, so the re-weighting loop never touches HBM.  Rows are spread over the
+// 64 lanes; each pass ends in one butterfly all-reduce of the p(p+1)/2 + p + 1 accumulators
+// (X'WX, X'Wz, deviance), after which every lane holds identical sums and runs the p x p Cholesky
+// solve redundantly -- the iteration count is wave-uniform, so replicates that need more passes
+// do not hold other replicates back (unlike a lane-per-replicate mapping).
+//
+// Reference: crates/engine-core/src/batch.rs:1562-2134 (GLM arm of run_one_sim: refit per grid N
+// from the truth start beta0 = effect_sizes, Wald z^2 vs norm_ppf^2, LRT overall),
+// data_gen.rs:390-398, 859-911 (uniform residual slot, Bernoulli draw).  The IRLS arithmetic
+// replaces glmm 0.1.2's glm_irls_fit (out of tree): published Fisher scoring, R glm.fit's
+// convergence rule |dev - dev_old| / (|dev| + 0.1) < 1e-8, <= 25 passes, |beta| > 30 -> not converged.
+#include <hip/hip_runtime.h>
+#include "mcp_device.hpp"
+#include "mcp_params.hpp"
+#include "mcp_rows.hpp"
+#include "mcp_decide.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mcp {
+
+constexpr int WAVE = 64;
+constexpr int MAX_IRLS_ITERS = 25;
+constexpr double IRLS_EPS = 1e-8;
+constexpr double BETA_CAP = 30.0;  // batch.rs:4550
+constexpr double W_FLOOR = 1e-10;
+constexpr double GLM_NEAR_ZERO = 1e-30;
+
+__device__ __forceinline__ double wave_allreduce_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < WAVE; m <<= 1) v += __shfl_xor(v, m, WAVE);
+  return v;
+}
+
+// LDS layout per block (one wave): design[c][row] for columns x1..x_{P-1} then y[row] (stride n_pad),
+// followed by the 4-row staging area [slot][lane] of stage_group.
+template <int P, bool FACTORS>
+__global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ float lds[];
+  const SimParams& prm = *pp;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lsim = blockIdx.x;  // grid = replicates of this launch
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t out_row = prm.out_base + lsim;
+  const uint32_t max_n = prm.max_n;
+  const uint32_t n_pad = (max_n + 3u) & ~3u;
+  float* design = lds;                       // P columns x n_pad
+  float* st = lds + (size_t)P * n_pad + lane;  // staging, stride WAVE
+
+  // ---- generate the replicate into LDS: lane takes Philox blocks lane, lane + 64, ... ----
+  RowCtx<P> cx;
+  row_ctx_init<P, FACTORS>(prm, cx);
+  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += WAVE) {
+    stage_group<P, WAVE, 1>(prm, k0, k1, ctr, st);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t rr = 4u * ctr + r;
+      if (rr < max_n) {
+        float x[P], y;
+        build_row<P, FACTORS, WAVE, 1>(prm, cx, k0, k1, st, r, rr, x, y);
+#pragma unroll
+        for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
+        design[(size_t)(P - 1) * n_pad + rr] = y;
+      }
+    }
+  }
+  __syncthreads();  // single-wave block: orders the LDS writes above before the cross-lane reads below
+
+  const uint32_t nt = prm.n_tests;
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n = prm.ns[g];
+    // ---- IRLS from the truth start (batch.rs:1945-1951) ----
+    double beta[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) beta[c] = prm.beta[c];
+    double sum_y = 0.0;
+    for (uint32_t i = lane; i < n; i += WAVE) sum_y += (double)design[(size_t)(P - 1) * n_pad + i];
+    sum_y = wave_allreduce_sum(sum_y);
+    const double nd = (double)n;
+    const double pbar = sum_y / nd;
+    const double dev_null = (pbar > 0.0 && pbar < 1.0) ? -2.0 * (sum_y * log(pbar) + (nd - sum_y) * log(1.0 - pbar)) : 0.0;
+
+    double Lm[P][P], invd[P];
+    double dev = __builtin_nan(""), dev_prev = __builtin_inf();
+    bool conv = false;
+    for (int it = 0; it < MAX_IRLS_ITERS; ++it) {
+      double xtwx[P * (P + 1) / 2], xtwz[P], d = 0.0;
+#pragma unroll
+      for (int i = 0; i < P * (P + 1) / 2; ++i) xtwx[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < P; ++i) xtwz[i] = 0.0;
+      for (uint32_t i = lane; i < n; i += WAVE) {
+        double xd[P];
+        xd[0] = 1.0;
+#pragma unroll
+        for (int c = 1; c < P; ++c) xd[c] = (double)design[(size_t)(c - 1) * n_pad + i];
+        const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
+        double eta = 0.0;
+#pragma unroll
+        for (int c = 0; c < P; ++c) eta = __builtin_fma(xd[c], beta[c], eta);
+        const double ea = exp(-__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
+        const double inv = 1.0 / (1.0 + ea);
+        const double pr = eta >= 0.0 ? inv : ea * inv;  // stable sigmoid
+        double w = pr * (1.0 - pr);
+        w = w < W_FLOOR ? W_FLOOR : w;
+        const double z = eta + (yi - pr) / w;
+        // -2 log-likelihood of a Bernoulli observation: log p = -log1p(e^-eta), log(1-p) = -eta - log1p(e^-eta) (eta >= 0)
+        const double l1p = log1p(ea);
+        const double ll = yi > 0.5 ? (eta >= 0.0 ? -l1p : eta - l1p) : (eta >= 0.0 ? -eta - l1p : -l1p);
+        d += -2.0 * ll;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+          const double wxa = w * xd[a];
+#pragma unroll
+          for (int b = 0; b <= a; ++b) {
+            xtwx[idx] = __builtin_fma(wxa, xd[b], xtwx[idx]);
+            ++idx;
+          }
+          xtwz[a] = __builtin_fma(wxa, z, xtwz[a]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < P * (P + 1) / 2; ++i) xtwx[i] = wave_allreduce_sum(xtwx[i]);
+#pragma unroll
+      for (int i = 0; i < P; ++i) xtwz[i] = wave_allreduce_sum(xtwz[i]);
+      dev = wave_allreduce_sum(d);
+      if (!(dev < __builtin_inf())) break;  // NaN / inf deviance
+      const bool done = it > 0 && __builtin_fabs(dev - dev_prev) / (__builtin_fabs(dev) + 0.1) < IRLS_EPS;
+      // Cholesky of X'WX and the weighted least-squares update (all lanes, identical values)
+      bool ok = true;
+      {
+        int idx = 0;
+        double A[P][P];
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+          for (int b = 0; b <= a; ++b) A[a][b] = xtwx[idx++];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          double dd = A[j][j];
+#pragma unroll
+          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lm[j][t], Lm[j][t], dd);
+          ok = ok && (dd > 0.0) && (dd < __builtin_inf());
+          const double ljj = __builtin_sqrt(dd);
+          Lm[j][j] = ljj;
+          invd[j] = 1.0 / ljj;
+#pragma unroll
+          for (int i = j + 1; i < P; ++i) {
+            double v = A[i][j];
+#pragma unroll
+            for (int t = 0; t < j; ++t) v = __builtin_fma(-Lm[i][t], Lm[j][t], v);
+            Lm[i][j] = v * invd[j];
+          }
+        }
+      }
+      if (!ok) break;
+      if (done) {
+        conv = true;
+        break;
+      }
+      double zf[P], nb[P];
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        double v = xtwz[i];
+#pragma unroll
+        for (int t = 0; t < i; ++t) v = __builtin_fma(-Lm[i][t], zf[t], v);
+        zf[i] = v * invd[i];
+      }
+      bool capped = false;
+#pragma unroll
+      for (int i = P - 1; i >= 0; --i) {
+        double v = zf[i];
+#pragma unroll
+        for (int t = i + 1; t < P; ++t) v = __builtin_fma(-Lm[t][i], nb[t], v);
+        nb[i] = v * invd[i];
+        capped = capped || !(__builtin_fabs(nb[i]) <= BETA_CAP);
+      }
+      if (capped) break;
+#pragma unroll
+      for (int i = 0; i < P; ++i) beta[i] = nb[i];
+      dev_prev = dev;
+    }
+
+    // ---- Wald z^2 per target (cov = (X'WX)^-1), decisions, LRT overall ----
+    const double* crow = prm.crit + (size_t)g * prm.crit_stride;
+    double tsq[MAX_T];
+#pragma unroll
+    for (int t = 0; t < MAX_T; ++t) {
+      tsq[t] = __builtin_nan("");
+      if ((uint32_t)t < nt && conv) {
+        const double* c = prm.contrast + t * MAX_P;
+        double est = 0.0, nq = 0.0, u[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          est = __builtin_fma(c[i], beta[i], est);
+          double acc = c[i];
+#pragma unroll
+          for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lm[i][q], u[q], acc);
+          u[i] = acc * invd[i];
+          nq = __builtin_fma(u[i], u[i], nq);
+        }
+        if (nq > GLM_NEAR_ZERO && nq < __builtin_inf()) tsq[t] = est * est / nq;
+      }
+    }
+    uint32_t unc_bits = 0, cor_bits = 0;
+    decide_tests(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
+    if (!conv) {
+      unc_bits = 0;
+      cor_bits = 0;
+    }
+    bool ov = false;
+    if (prm.report_overall && conv && dev < __builtin_inf() && dev_null < __builtin_inf()) {
+      const double lrt = dev_null - dev;
+      ov = (lrt < __builtin_inf()) && (lrt > crow[3 + nt]);
+    }
+    if (lane == 0) {  // the wave's replicate: one writer
+      const size_t cell = (size_t)out_row * prm.n_grid + g;
+#pragma unroll
+      for (int t = 0; t < MAX_T; ++t)
+        if ((uint32_t)t < nt) {
+          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
+          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
+        }
+      prm.conv[cell] = conv ? 1 : 0;
+      if (prm.overall) prm.overall[cell] = ov ? 1 : 0;
+      if (prm.stat && g == 0) {
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t)
+          if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
+      }
+    }
+  }
+}
+
+// Fold the per-replicate flag tensors of one launch into the additive counters
+// (aggregation.rs:84-284): lane per replicate, ballot + popcount, one atomic per wave per counter.
+__global__ __launch_bounds__(256) void fold_flags_kernel(const SimParams* __restrict__ pp) {
+  const SimParams& prm = *pp;
+  const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = local < prm.n_sims;
+  const uint32_t row = prm.out_base + (active ? local : 0u);
+  const uint32_t nt = prm.n_tests;
+  const bool lane0 = (threadIdx.x & 63u) == 0u;
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const size_t cell = (size_t)row * prm.n_grid + g;
+    unsigned long long* ctr = prm.counters + (size_t)g * prm.ctr_stride;
+    uint32_t ku = 0, kc = 0;
+    for (uint32_t t = 0; t < nt; ++t) {
+      const uint32_t u = active ? prm.unc[cell * nt + t] : 0u, c = active ? prm.cor[cell * nt + t] : 0u;
+      ku += u != 0u;
+      kc += c != 0u;
+      const unsigned long long mu = __ballot(u != 0u), mc = __ballot(c != 0u);
+      if (lane0) {
+        if (mu) atomicAdd(ctr + prm.ctr_k_unc + t, (unsigned long long)__popcll(mu));
+        if (mc) atomicAdd(ctr + prm.ctr_k_cor + t, (unsigned long long)__popcll(mc));
+      }
+    }
+    for (uint32_t k = 0; k <= nt; ++k) {
+      const unsigned long long hu = __ballot(active && ku == k), hc = __ballot(active && kc == k);
+      if (lane0) {
+        if (hu) atomicAdd(ctr + prm.ctr_hist_unc + k, (unsigned long long)__popcll(hu));
+        if (hc) atomicAdd(ctr + prm.ctr_hist_cor + k, (unsigned long long)__popcll(hc));
+      }
+    }
+    const unsigned long long mcv = __ballot(active && prm.conv[cell] != 0);
+    const unsigned long long mov = __ballot(active && prm.overall && prm.overall[cell] != 0);
+    const unsigned long long mac = __ballot(active);
+    if (lane0) {
+      if (mcv) atomicAdd(ctr + prm.ctr_conv, (unsigned long long)__popcll(mcv));
+      if (mov) atomicAdd(ctr + prm.ctr_overall, (unsigned long long)__popcll(mov));
+      if (mac) atomicAdd(ctr + prm.ctr_n_sims, (unsigned long long)__popcll(mac));
+    }
+  }
+}
+
+size_t glm_lds_bytes(int P, uint32_t max_n) {
+  const size_t n_pad = (max_n + 3u) & ~3u;
+  return ((size_t)P * n_pad + (size_t)4 * P * WAVE) * sizeof(float);
+}
+
+template <bool FACTORS>
+static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, hipStream_t st) {
+  const size_t lds = glm_lds_bytes(P, max_n);
+  const dim3 block(WAVE), grid(n_sims);
+#define LG(PP)                                                                                                        \
+  case PP: {                                                                                                          \
+    if (lds > 48 * 1024) {                                                                                            \
+      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS>,                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+      if (e != hipSuccess) return e;                                                                                  \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS>), grid, block, lds, st, d_prm);                                   \
+  } break;
+  switch (P) {
+    LG(2) LG(3) LG(4) LG(5) LG(6) LG(7) LG(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef LG
+  return hipGetLastError();
+}
+
+hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, hipStream_t st) {
+  return factors ? launch_glm_f<true>(P, d_prm, n_sims, max_n, st) : launch_glm_f<false>(P, d_prm, n_sims, max_n, st);
+}
+
+hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  hipLaunchKernelGGL(fold_flags_kernel, dim3((n_sims + 255u) / 256u), dim3(256), 0, st, d_prm);
+  return hipGetLastError();
+}
+
+}  // namespace mcp

@@ -28,6 +28,9 @@ hipError_t launch_ols_fit_provided(int P, const float* design, const float* outc
                                    double* beta, double* se, double* tsq, double* rss, double* sst, uint8_t* conv,
                                    hipStream_t st);
 hipError_t launch_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out, hipStream_t st);
+hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, hipStream_t st);
+hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
+size_t glm_lds_bytes(int P, uint32_t max_n);
 }  // namespace mcp
 
 namespace {
@@ -175,7 +178,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   const uint32_t flags = opts ? opts->flags : (uint32_t)MCP_WANT_PER_SIM;
   const bool per_sim = flags & MCP_WANT_PER_SIM;
   const bool want_stat = flags & MCP_WANT_STAT_CAPTURE;
-  const bool staged = flags & MCP_PIPELINE_STAGED;
+  const bool glm = spec->estimator == MCP_EST_GLM;
+  const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
   const uint64_t sim_offset = opts ? opts->sim_offset : 0;
   const uint32_t nt = low.n_tests, P = low.P;
   const size_t cells = (size_t)n_sims * n_ns;
@@ -188,6 +192,10 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
+  if (glm && mcp::glm_lds_bytes((int)P, prm.max_n) > 150u * 1024u) {
+    mcp_free_result(out);
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: GLM design (n x p f32) does not fit one wave's LDS budget");
+  }
 
   hipStream_t st = nullptr;
   rc = ensure_device(&st, opts);
@@ -227,7 +235,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(ar.get(S_CRIT, low.crit.size() * sizeof(double), (void**)&d_crit));
   DEV_TRY(ar.get(S_LEVELS, low.fixed_levels.size(), (void**)&d_levels));
   DEV_TRY(ar.get(S_COUNTERS, (size_t)n_ns * layout.stride * sizeof(uint64_t), (void**)&d_ctr));
-  if (per_sim) {
+  if (per_sim || glm) {  // the wave-per-replicate kernels always write flags; a fold kernel counts them
     DEV_TRY(ar.get(S_UNC, cells * nt + 1, (void**)&d_unc));
     DEV_TRY(ar.get(S_COR, cells * nt + 1, (void**)&d_cor));
     DEV_TRY(ar.get(S_CONV, cells + 1, (void**)&d_conv));
@@ -265,16 +273,21 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(hipMemcpyAsync(d_prm, h_prm.data(), sizeof(mcp::SimParams) * n_chunks, hipMemcpyHostToDevice, st));
 
   // launches, each bracketed by events on the launch stream
-  const size_t ev_per_chunk = staged ? 3 : 2;
+  const size_t ev_per_chunk = (staged || glm) ? 3 : 2;
   bool cancelled = false;
   uint32_t launched = 0;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     hipEvent_t e0, e1, e2 = nullptr;
     DEV_TRY(ar.event(2 + c * ev_per_chunk, &e0));
     DEV_TRY(ar.event(3 + c * ev_per_chunk, &e1));
-    if (staged) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
+    if (staged || glm) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
     DEV_TRY(hipEventRecord(e0, st));
-    if (!staged) {
+    if (glm) {
+      DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, st));
+      DEV_TRY(hipEventRecord(e1, st));
+      DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(hipEventRecord(e2, st));
+    } else if (!staged) {
       DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, spec->n_factors > 0, st));
       DEV_TRY(hipEventRecord(e1, st));
     } else {
@@ -334,7 +347,11 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   for (uint32_t c = 0; c < launched; ++c) {
     hipEvent_t e0 = ar.events[2 + c * ev_per_chunk], e1 = ar.events[3 + c * ev_per_chunk];
     DEV_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (!staged) {
+    if (glm) {
+      kernel_ms += ms;  // simulate kernel
+      DEV_TRY(hipEventElapsedTime(&ms, e1, ar.events[4 + c * ev_per_chunk]));
+      aux_ms += ms;  // counter fold
+    } else if (!staged) {
       kernel_ms += ms;
     } else {
       aux_ms += ms;  // generator

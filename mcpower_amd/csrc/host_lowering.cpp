@@ -158,8 +158,14 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (n_ns > (uint32_t)MAX_GRID) return unsupported("more than " + std::to_string(MAX_GRID) + " sample sizes per call");
   if (spec->n_factors > (uint32_t)MAX_FACTORS) return unsupported("more than " + std::to_string(MAX_FACTORS) + " factors");
   if (spec->n_factor_proportions > (uint32_t)MAX_LEVELS) return unsupported("more than " + std::to_string(MAX_LEVELS) + " factor levels in total");
-  if (spec->estimator != MCP_EST_OLS) return unsupported("estimator Glm / Mle (OLS arm only so far)");
-  if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS) return unsupported("Binary / Count outcomes");
+  if (spec->estimator == MCP_EST_MLE) return unsupported("estimator Mle");
+  if (spec->estimator == MCP_EST_OLS && spec->outcome_kind != MCP_OUTCOME_CONTINUOUS)
+    return unsupported("OLS on Binary / Count outcomes");
+  if (spec->estimator == MCP_EST_GLM) {
+    if (spec->outcome_kind != MCP_OUTCOME_BINARY || spec->link != MCP_LINK_CANONICAL)
+      return unsupported("GLM families other than Binary/logit (probit, Poisson)");
+    if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
+  }
   if (spec->cluster.present) return unsupported("clustered data generation");
   if (!scenario_is_optimistic(spec->scenario)) return unsupported("scenario perturbations (optimistic path only so far)");
   if (spec->residual_dist != MCP_RESID_NORMAL) return unsupported("non-normal residual distributions");

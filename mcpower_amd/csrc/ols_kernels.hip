@@ -21,11 +21,14 @@
 #include <hip/hip_runtime.h>
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
+#include "mcp_rows.hpp"
+#include "mcp_decide.hpp"
 
 #pragma clang fp contract(off)
 
 namespace mcp {
 
+constexpr int BLOCK = 256;
 constexpr double EPS_RANK = 1e-12;         // batch.rs:41
 constexpr double FLOAT_NEAR_ZERO = 1e-30;  // lib.rs:46
 
@@ -72,171 +75,6 @@ __device__ __forceinline__ void suff_add_row(Suff<P>& s, const float (&x)[P], fl
   }
   s.sy += y;
   s.syy = __builtin_fma(y, y, s.syy);
-}
-
-// categorical draw on the sequential stream (rng.rs:112-127)
-__device__ __forceinline__ uint32_t categorical(const SimParams& prm, uint32_t f, uint32_t k0, uint32_t k1, uint64_t q) {
-  const double u = (double)u32_to_unit_f32(sequential_word(k0, k1, q));
-  const uint32_t nl = prm.f_levels[f];
-  const uint32_t off = prm.f_prop_off[f];
-  double acc = 0.0;
-  uint32_t lvl = nl - 1;
-  bool found = false;
-  for (uint32_t i = 0; i < nl; ++i) {
-    acc += prm.f_props[off + i];
-    if (!found && u < acc) {
-      lvl = i;
-      found = true;
-    }
-  }
-  return lvl;
-}
-
-// ---- 4-row block staging ------------------------------------------------------------------
-// LDS layout: stage[slot * 256 + tid], slot = 4 * column + r, column j < K = continuous predictor j,
-// column K = the residual.  One Philox call yields rows 4*ctr..4*ctr+3 of one column (rng.rs:149-178).
-constexpr int BLOCK = 256;
-
-__device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const u32x4 w, uint32_t& pend) {
-  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float v = u32_to_unit_f32(ws[r]) - 0.5f;
-    const bool tail = __builtin_fabsf(v) > NORM_INV_BP;
-    const float z = icdf_central(v);           // branch-free central polynomial for every lane
-    st[(col_slot * 4u + r) * BLOCK] = tail ? v : z;  // tail lanes park v for the fix-up loop
-    pend |= tail ? (1u << (col_slot * 4u + r)) : 0u;
-  }
-}
-
-// rows 4*ctr .. 4*ctr+3 of one replicate: standard normals of every column into LDS (data_gen.rs:316-421)
-template <int P>
-__device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr, float* st) {
-  const uint32_t K = prm.K;
-  uint32_t pend = 0;
-#pragma unroll
-  for (int j = 0; j < P - 1; ++j)
-    if ((uint32_t)j < K) stage_column(st, (uint32_t)j, planar_words(k0, k1, CLASS_XNORM, (uint32_t)j, ctr), pend);
-  stage_column(st, K, planar_words(k0, k1, CLASS_RESID, 0u, ctr), pend);
-  // tail fix-up: each pass retires one parked draw per lane; ~3-4 passes per block instead of 4*(K+1)
-  while (__ballot(pend != 0u) != 0ull) {
-    if (pend != 0u) {
-      const uint32_t slot = (uint32_t)__builtin_ctz(pend);
-      pend &= pend - 1u;
-      st[slot * BLOCK] = icdf_tail(st[slot * BLOCK]);
-    }
-  }
-}
-
-// launch-constant values of the row loop, hoisted into scalar registers once per wave
-template <int P>
-struct RowCtx {
-  uint32_t K;
-  uint32_t ident_L;
-  uint32_t n_factors;        // 0 on the continuous-only fast path (FACTORS == false)
-  uint32_t beta_nz;          // bit c set when beta[c] != 0
-  uint32_t inter_any;        // bit c set when column c is an interaction
-  uint32_t imask[P];
-  double beta[P];
-};
-
-template <int P, bool FACTORS>
-__device__ __forceinline__ void row_ctx_init(const SimParams& prm, RowCtx<P>& cx) {
-  cx.K = prm.K;
-  cx.ident_L = prm.ident_L;
-  cx.n_factors = FACTORS ? prm.n_factors : 0u;
-  cx.beta_nz = 0u;
-  cx.inter_any = 0u;
-#pragma unroll
-  for (int c = 0; c < P; ++c) {
-    cx.beta[c] = prm.beta[c];
-    cx.imask[c] = prm.inter_mask[c];
-    cx.beta_nz |= (cx.beta[c] != 0.0) ? (1u << c) : 0u;
-    cx.inter_any |= (cx.imask[c] != 0u) ? (1u << c) : 0u;
-  }
-}
-
-// one design row + outcome from the staged normals (data_gen.rs:334-363, 509-551, 643-649, 781-857)
-template <int P, bool FACTORS>
-__device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
-                                          const float* st, int r, uint32_t row, float (&x)[P], float& y) {
-  const uint32_t K = cx.K;
-  float z[P - 1];
-#pragma unroll
-  for (int j = 0; j < P - 1; ++j) z[j] = ((uint32_t)j < K) ? st[(j * 4 + r) * BLOCK] : 0.0f;
-  const float e = st[(K * 4u + r) * BLOCK];
-  x[0] = 1.0f;
-  // factor levels of this row (data_gen.rs:513-551)
-  uint32_t lvl[MAX_FACTORS];
-  if (FACTORS) {
-#pragma unroll
-    for (int f = 0; f < MAX_FACTORS; ++f) {
-      lvl[f] = 0u;
-      if ((uint32_t)f < cx.n_factors) {
-        if (prm.f_sampled[f]) {
-          const uint64_t q = (uint64_t)prm.n_seq_pre + (uint64_t)row * prm.n_seq_per_row + prm.f_seq_slot[f];
-          lvl[f] = categorical(prm, (uint32_t)f, k0, k1, q);
-        } else {
-          lvl[f] = row < prm.max_n ? (uint32_t)prm.fixed_levels[(size_t)row * prm.n_factors + f] : 0u;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 1; c < P; ++c) {
-    float v = 0.0f;
-    if ((uint32_t)(c - 1) < K) {
-      if (cx.ident_L) {
-        v = z[c - 1];
-      } else {  // x_j = f32( sum_{t<=j} L[j][t] * f64(z_t) ), t ascending, separately rounded (data_gen.rs:334-351)
-        double acc = 0.0;
-#pragma unroll
-        for (int t = 0; t < c; ++t) {
-          const double l = prm.L[(c - 1) * MAX_K + t];
-          if (l != 0.0) acc = acc + l * (double)z[t];
-        }
-        v = (float)acc;
-      }
-    } else if ((cx.inter_any >> c) & 1u) {  // raw product in f64, components ascending (data_gen.rs:643-649)
-      double prod = 1.0;                    // non-members multiply by exactly 1.0: no branch, same bits
-#pragma unroll
-      for (int cc = 1; cc < c; ++cc) prod = prod * (((cx.imask[c] >> cc) & 1u) ? (double)x[cc] : 1.0);
-      v = (float)prod;
-    } else if (FACTORS && prm.col_factor[c] != 0xffffffffu) {
-      const uint32_t f = prm.col_factor[c];
-      const uint32_t lv = f == 0 ? lvl[0] : (f == 1 ? lvl[1] : (f == 2 ? lvl[2] : lvl[3]));
-      v = (lv == prm.col_level[c]) ? 1.0f : 0.0f;
-    }
-    x[c] = v;
-  }
-  // y = f32( sum_j f64(x_ij) beta_j + f64(eps_i) + u_re )  (data_gen.rs:785-857); zero betas add exact zeros
-  double lp = 0.0;
-#pragma unroll
-  for (int c = 0; c < P; ++c)
-    if ((cx.beta_nz >> c) & 1u) lp = lp + (double)x[c] * cx.beta[c];
-  y = (float)((lp + (double)e) + 0.0);
-}
-
-// Holm / BH need the descending order of t^2 (correction.rs:96-115): rank_i = number of tests ordered before i
-template <int T>
-__device__ __forceinline__ void ranks_desc(const double (&t)[T], uint32_t n, uint32_t (&rank)[T]) {
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    uint32_t rk = 0;
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-      if ((uint32_t)j < n && j != i) {
-        const bool in = t[i] != t[i], jn = t[j] != t[j];
-        bool before;  // j sorts before i
-        if (in && jn) before = j < i;
-        else if (jn) before = false;
-        else if (in) before = true;
-        else before = (t[j] > t[i]) || (t[j] == t[i] && j < i);
-        rk += before ? 1u : 0u;
-      }
-    }
-    rank[i] = rk;
-  }
 }
 
 // Fit the accumulated prefix of n rows and decide every test (batch.rs:956-1142).
@@ -310,7 +148,6 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
 
   // ---- squared statistic per test: (c'beta)^2 / (sigma^2 ||L^-1 c||^2)  (posthoc.rs:86-99) ----
   const double* crow = prm.crit + (size_t)g * prm.crit_stride;
-  const double crit_unc = crow[0];
   const uint32_t nt = prm.n_tests;
   double tsq[MAX_T];
 #pragma unroll
@@ -336,50 +173,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
 
   // ---- decisions (batch.rs:1089-1117, correction.rs:16-92) ----
   uint32_t unc_bits = 0, cor_bits = 0;
-#pragma unroll
-  for (int t = 0; t < MAX_T; ++t)
-    if ((uint32_t)t < nt && tsq[t] > crit_unc) unc_bits |= 1u << t;  // NaN compares false
-  const int method = prm.correction;
-  if (method == 0) {
-    cor_bits = unc_bits;
-  } else if (method == 1 || method == 4) {  // Bonferroni / Tukey: per-target threshold
-#pragma unroll
-    for (int t = 0; t < MAX_T; ++t)
-      if ((uint32_t)t < nt && tsq[t] > crow[1 + t]) cor_bits |= 1u << t;
-  } else {
-    uint32_t rank[MAX_T];
-    ranks_desc<MAX_T>(tsq, nt, rank);
-    uint32_t okb = 0;  // test t clears the threshold of its own rank
-#pragma unroll
-    for (int t = 0; t < MAX_T; ++t) {
-      if ((uint32_t)t < nt) {
-        double cr = crow[1];
-#pragma unroll
-        for (int k = 1; k < MAX_T; ++k) cr = (rank[t] == (uint32_t)k && (uint32_t)k < nt) ? crow[1 + k] : cr;
-        if (tsq[t] > cr) okb |= 1u << t;
-      }
-    }
-    if (method == 2) {  // Holm step-down: pass while every better-ranked test passed
-#pragma unroll
-      for (int t = 0; t < MAX_T; ++t) {
-        if ((uint32_t)t < nt) {
-          bool pass = true;
-#pragma unroll
-          for (int j = 0; j < MAX_T; ++j)
-            if ((uint32_t)j < nt && rank[j] <= rank[t] && !((okb >> j) & 1u)) pass = false;
-          if (pass) cor_bits |= 1u << t;
-        }
-      }
-    } else {  // BH step-up: everything ranked at or above the last passing rank
-      int last = -1;
-#pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
-        if ((uint32_t)t < nt && ((okb >> t) & 1u)) last = (int)rank[t] > last ? (int)rank[t] : last;
-#pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
-        if ((uint32_t)t < nt && (int)rank[t] <= last) cor_bits |= 1u << t;
-    }
-  }
+  decide_tests(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
   if (!conv) {
     unc_bits = 0;
     cor_bits = 0;
@@ -487,13 +281,13 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
 
   if (MODE == MODE_GENERATE) {
     for (uint32_t ctr = 0; 4u * ctr < max_n; ++ctr) {
-      stage_group<P>(prm, k0, k1, ctr, st);
+      stage_group<P, BLOCK, 0>(prm, k0, k1, ctr, st);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const uint32_t rr = 4u * ctr + r;
         if (rr < max_n) {
           float x[P], y;
-          build_row<P, FACTORS>(prm, cx, k0, k1, st, r, rr, x, y);
+          build_row<P, FACTORS, BLOCK, 0>(prm, cx, k0, k1, st, r, rr, x, y);
 #pragma unroll
           for (int c = 1; c < P; ++c) tile[tile_index(P, max_n, blockIdx.x, c - 1, rr)] = x[c];
           tile[tile_index(P, max_n, blockIdx.x, P - 1, rr)] = y;
@@ -512,13 +306,13 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
     if (MODE == MODE_FUSED) {
       while (row < n_end) {
         const uint32_t base = row & ~3u;
-        if ((row & 3u) == 0u) stage_group<P>(prm, k0, k1, row >> 2, st);
+        if ((row & 3u) == 0u) stage_group<P, BLOCK, 0>(prm, k0, k1, row >> 2, st);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const uint32_t rr = base + (uint32_t)r;
           if (rr >= row && rr < n_end) {
             float x[P], y;
-            build_row<P, FACTORS>(prm, cx, k0, k1, st, r, rr, x, y);
+            build_row<P, FACTORS, BLOCK, 0>(prm, cx, k0, k1, st, r, rr, x, y);
             suff_add_row<P>(s, x, y);
           }
         }

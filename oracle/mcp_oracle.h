@@ -87,6 +87,11 @@ int mcpo_generate_sim_data(const mcp_spec* spec, uint64_t base_seed, uint64_t si
 int mcpo_ols_fit(const float* x_colmajor, const float* y, uint32_t n_rows, uint32_t ld, uint32_t p,
                  double* beta, double* se, double* t_sq, double* rss, double* sst, uint8_t* converged);
 
+/* ---- logistic IRLS on provided bytes (glmm glm_irls_fit; published Fisher scoring, see fit_glm.c) ---- */
+int mcpo_glm_fit(const float* x_colmajor, const float* y, uint32_t n_rows, uint32_t ld, uint32_t p,
+                 const double* beta_start, double* beta, double* se, double* z_sq, double* deviance,
+                 double* deviance_null, uint8_t* converged, uint32_t* n_iter);
+
 /* ---- run_batch (batch.rs:199-776) ----------------------------------------
  * Same contract as mcp_run_batch; `n_threads` >= 1 splits the replicate range
  * over pthreads (results identical for any thread count). */

@@ -290,3 +290,65 @@ def test_type_one_error_under_the_null(engine):
     rate = r.counter("k_unc", 2)[0] / 400000.0
     se = np.sqrt(0.05 * 0.95 / 400000)
     assert np.all(np.abs(rate - 0.05) < 5 * se)
+
+
+# ---------------------------------------------------------------------------------------------
+# logistic GLM (IRLS), BASELINE config C3
+# ---------------------------------------------------------------------------------------------
+def test_c3_logistic_flags_identical_to_oracle(engine, oracle):
+    """C3: logit, n=500, p=4, truth start.  z^2 within 1e-9 relative (the IRLS sums are reduced in a
+    different order on the device: lane-strided partials + butterfly), decisions identical."""
+    from helpers import spec_c3
+    spec = spec_c3()
+    spec.report_overall = True
+    g = engine.run_batch(spec, [500], 6000, BASE_SEED, stat_capture=True)
+    o = oracle.run_batch(spec, [500], 6000, BASE_SEED, stat_capture=True, n_threads=8)
+    a, b = g.stat_capture, o.stat_capture
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    m = ~np.isnan(a)
+    assert np.max(np.abs(a[m] - b[m]) / np.abs(b[m])) < 1e-9
+    for f in ("uncorrected", "corrected", "converged", "overall"):
+        assert np.array_equal(getattr(g, f), getattr(o, f)), f
+    assert np.array_equal(g.counters, o.counters)
+    power = g.counter("k_unc", 3)[0] / 6000.0
+    assert power[0] > 0.95 and power[1] > 0.95 and abs(power[2] - 0.05) < 0.02  # x3 is a true null
+
+
+def test_glm_grid_factors_and_corrections_match_oracle(engine, oracle):
+    spec, seed, _, low = load_case("glm_factor_a")          # x1 + 3-level factor, baseline 0.3
+    spec.correction_method = S.CorrectionMethod.Holm
+    g = engine.run_batch(spec, [100, 333, 1000], 1500, seed, stat_capture=True)
+    o = oracle.run_batch(spec, [100, 333, 1000], 1500, seed, stat_capture=True, n_threads=8)
+    for f in ("uncorrected", "corrected", "converged"):
+        assert np.array_equal(getattr(g, f), getattr(o, f)), f
+    assert np.array_equal(g.counters, o.counters)
+    spec, seed, _, _ = load_case("glm_interaction_b")        # x1 * x2, baseline 0.5
+    spec.correction_method = S.CorrectionMethod.BenjaminiHochberg
+    g = engine.run_batch(spec, [250, 1000], 1500, seed)
+    o = oracle.run_batch(spec, [250, 1000], 1500, seed, n_threads=8)
+    assert np.array_equal(g.corrected, o.corrected) and np.array_equal(g.counters, o.counters)
+
+
+def test_glm_separation_reports_not_converged_like_oracle(engine, oracle):
+    """Tiny n with a strong effect: complete separation is common; IRLS must stop at BETA_CAP / the
+    pass limit and report converged = 0 with all flags 0 (batch.rs:2033-2067), identically to the oracle."""
+    from helpers import spec_c3
+    spec = spec_c3()
+    spec.effect_sizes = [0.0, 4.0, 0.0, 0.0]
+    g = engine.run_batch(spec, [12, 40], 2000, BASE_SEED)
+    o = oracle.run_batch(spec, [12, 40], 2000, BASE_SEED, n_threads=8)
+    assert np.array_equal(g.converged, o.converged)
+    assert 0.02 < 1.0 - g.converged[:, 0].mean() < 0.98          # some, not all, separate at n = 12
+    assert not g.uncorrected[g.converged == 0].any()
+    assert np.array_equal(g.uncorrected, o.uncorrected)
+
+
+def test_glm_counters_only_shards_and_determinism(engine):
+    from helpers import spec_c3
+    spec = spec_c3()
+    whole = engine.run_batch(spec, [500], 20000, BASE_SEED, per_sim=False)
+    again = engine.run_batch(spec, [500], 20000, BASE_SEED, per_sim=False, chunk_sims=3001)
+    assert np.array_equal(whole.counters, again.counters)
+    parts = [engine.run_batch(spec, [500], 10000, BASE_SEED, per_sim=False, sim_offset=o) for o in (0, 10000)]
+    assert np.array_equal(parts[0].counters + parts[1].counters, whole.counters)
+    assert whole.counter("n_sims")[0, 0] == 20000
