@@ -40,6 +40,8 @@ WORKLOADS = {
     "k4": ("spec_k4", 200, 4.3e4, 4 * 200 * 5),      # tuning aid: 4 plain predictors (p=5, no interaction)
     # C3: logistic IRLS n=500 p=4: 2000 draws + ~5 passes x 500 rows x (exp, log1p, 2 div, 18 fma) ~ 5.0e5 ops
     "c3": ("spec_c3", 500, 5.0e5, 4 * 500 * 4),
+    # C4: random-intercept REML, 30 x 20: 1800 draws + 30 RE draws + one 600-row pass + ~28 objective evaluations
+    "c4": ("spec_c4", 600, 1.6e5, 4 * 600 * 3),
 }
 
 
@@ -49,7 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2a", choices=sorted(WORKLOADS))
-    ap.add_argument("--sims-per-gpu", type=int, default=0, help="default: 10^6 (OLS) / 10^5 (c3)")
+    ap.add_argument("--sims-per-gpu", type=int, default=0, help="default: 10^6 (OLS) / 10^5 (c3) / 10^4 (c4)")
     ap.add_argument("--pipeline", default="fused", choices=["fused", "staged"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -78,7 +80,7 @@ def main():
     fac, n_obs, ops_per_fit, bytes_per_fit = WORKLOADS[args.workload]
     spec = getattr(helpers, fac)()
     ns = [n_obs]
-    S = args.sims_per_gpu or (100_000 if args.workload == "c3" else 1_000_000)
+    S = args.sims_per_gpu or ({"c3": 100_000, "c4": 10_000}.get(args.workload, 1_000_000))
     staged = args.pipeline == "staged"
 
     def barrier():
@@ -124,17 +126,17 @@ def main():
             "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {'OLS' if args.workload != 'c3' else 'GLM'} n={n_obs} p={spec.n_predictors} "
-                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'c3': 'logit IRLS, 3 predictors'}[args.workload] }), "
+            "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'c4': 'LMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
+                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20'}[args.workload] }), "
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": "1 all-reduce(sum) of counters per step"},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),
         }
-        is_ols = args.workload != "c3"
+        is_ols = args.workload not in ("c3", "c4")
         if not staged:
             ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "valu", "kernel": (f"ols_sim_kernel<{spec.n_predictors},fused>" if is_ols else f"glm_sim_kernel<{spec.n_predictors}>"),
+            out["roofline"] = {"bound": "valu", "kernel": (f"ols_sim_kernel<{spec.n_predictors},fused>" if is_ols else f"{'glm' if args.workload == 'c3' else 'lmm'}_sim_kernel<{spec.n_predictors}>"),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
                                "traffic": None, "ops_per_fit": ops_per_fit, "avg_launch_ms": avg_launch_ms,
                                "fits_per_launch": fits_per_launch,

@@ -272,10 +272,19 @@ __global__ __launch_bounds__(256) void fold_flags_kernel(const SimParams* __rest
     const unsigned long long mcv = __ballot(active && prm.conv[cell] != 0);
     const unsigned long long mov = __ballot(active && prm.overall && prm.overall[cell] != 0);
     const unsigned long long mac = __ballot(active);
+    const unsigned long long mj = __ballot(active && prm.joint && prm.joint[cell] != 0);
+    const unsigned long long mb1 = __ballot(active && prm.boundary && prm.boundary[cell] == 1);
+    const unsigned long long mb2 = __ballot(active && prm.boundary && prm.boundary[cell] == 2);
     if (lane0) {
       if (mcv) atomicAdd(ctr + prm.ctr_conv, (unsigned long long)__popcll(mcv));
       if (mov) atomicAdd(ctr + prm.ctr_overall, (unsigned long long)__popcll(mov));
       if (mac) atomicAdd(ctr + prm.ctr_n_sims, (unsigned long long)__popcll(mac));
+      if (mj) {
+        atomicAdd(ctr + prm.ctr_joint_unc, (unsigned long long)__popcll(mj));
+        atomicAdd(ctr + prm.ctr_joint_cor, (unsigned long long)__popcll(mj));
+      }
+      if (mb1) atomicAdd(ctr + prm.ctr_boundary_1, (unsigned long long)__popcll(mb1));
+      if (mb2) atomicAdd(ctr + prm.ctr_boundary_2, (unsigned long long)__popcll(mb2));
     }
   }
 }

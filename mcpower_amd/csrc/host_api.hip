@@ -31,6 +31,9 @@ hipError_t launch_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, f
 hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, hipStream_t st);
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
 size_t glm_lds_bytes(int P, uint32_t max_n);
+hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
+                          hipStream_t st);
+size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 }  // namespace mcp
 
 namespace {
@@ -56,7 +59,7 @@ struct Arena {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Buf slots[12];
+  Buf slots[16];
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
   int device = -1;
@@ -88,7 +91,7 @@ struct Arena {
 };
 thread_local Arena g_arena;
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1 };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
   int n = 0;
@@ -178,7 +181,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   const uint32_t flags = opts ? opts->flags : (uint32_t)MCP_WANT_PER_SIM;
   const bool per_sim = flags & MCP_WANT_PER_SIM;
   const bool want_stat = flags & MCP_WANT_STAT_CAPTURE;
-  const bool glm = spec->estimator == MCP_EST_GLM;
+  const bool mle = spec->estimator == MCP_EST_MLE;
+  const bool glm = spec->estimator == MCP_EST_GLM || mle;  // wave-per-replicate kernels + flag fold
   const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
   const uint64_t sim_offset = opts ? opts->sim_offset : 0;
   const uint32_t nt = low.n_tests, P = low.P;
@@ -188,11 +192,15 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   mcp::counter_layout(spec, &layout);
   out->layout = layout;
   out->n_sims = n_sims; out->n_sample_sizes = n_ns; out->n_targets = nt; out->n_factors = spec->n_factors;
-  out->n_posthoc_contrasts = 0; out->n_variance_components = 0;
+  out->n_posthoc_contrasts = 0; out->n_variance_components = spec->estimator == MCP_EST_MLE ? 1u : 0u;
   out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
-  if (glm && mcp::glm_lds_bytes((int)P, prm.max_n) > 150u * 1024u) {
+  if (mle && mcp::lmm_lds_bytes((int)P, prm.max_n, prm.n_clusters_max) > 150u * 1024u) {
+    mcp_free_result(out);
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: LMM design + cluster sums do not fit one wave's LDS budget");
+  }
+  if (glm && !mle && mcp::glm_lds_bytes((int)P, prm.max_n) > 150u * 1024u) {
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: GLM design (n x p f32) does not fit one wave's LDS budget");
   }
@@ -241,6 +249,11 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     DEV_TRY(ar.get(S_CONV, cells + 1, (void**)&d_conv));
     if (spec->report_overall) DEV_TRY(ar.get(S_OVERALL, cells + 1, (void**)&d_ov));
   }
+  uint8_t *d_bh = nullptr, *d_joint = nullptr;
+  if (mle) {
+    DEV_TRY(ar.get(S_BOUNDARY, cells + 1, (void**)&d_bh));
+    DEV_TRY(ar.get(S_JOINT, cells + 1, (void**)&d_joint));
+  }
   if (want_stat) DEV_TRY(ar.get(S_STAT, ((size_t)n_sims * nt + 1) * sizeof(double), (void**)&d_stat));
   // design tile: [block of 256 replicates][P columns: x1..x_{P-1}, y][max_n rows][256] f32
   if (staged) DEV_TRY(ar.get(S_TILE, (size_t)((chunk + 255u) / 256u) * 256u * P * prm.max_n * sizeof(float), (void**)&d_tile));
@@ -257,6 +270,10 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   prm.fixed_levels = d_levels;
   prm.crit = d_crit;
   prm.unc = d_unc; prm.cor = d_cor; prm.conv = d_conv; prm.overall = d_ov; prm.stat = d_stat;
+  prm.boundary = d_bh;
+  prm.joint = d_joint;
+  prm.ctr_joint_unc = layout.joint_unc; prm.ctr_joint_cor = layout.joint_cor;
+  prm.ctr_boundary_1 = layout.boundary_1; prm.ctr_boundary_2 = layout.boundary_2;
   prm.counters = d_ctr;
   prm.ctr_stride = layout.stride; prm.ctr_k_unc = layout.k_unc; prm.ctr_k_cor = layout.k_cor;
   prm.ctr_conv = layout.converged; prm.ctr_overall = layout.overall; prm.ctr_hist_unc = layout.hist_unc;
@@ -283,7 +300,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     if (staged || glm) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, st));
+      if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, st));
+      else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
@@ -332,6 +350,11 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
       out->overall = host_alloc<uint8_t>(cells);
       DEV_TRY(hipMemcpyAsync(out->overall, d_ov, cells, hipMemcpyDeviceToHost, st));
     }
+    if (mle) {
+      DEV_TRY(hipMemcpyAsync(out->boundary_hit, d_bh, cells, hipMemcpyDeviceToHost, st));
+      DEV_TRY(hipMemcpyAsync(out->joint_unc, d_joint, cells, hipMemcpyDeviceToHost, st));
+      DEV_TRY(hipMemcpyAsync(out->joint_cor, d_joint, cells, hipMemcpyDeviceToHost, st));
+    }
   }
   if (want_stat) {
     out->stat_capture = host_alloc<double>((size_t)n_sims * nt);
@@ -359,6 +382,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
       kernel_ms += ms;  // fit
     }
   }
+  if (mle && per_sim)  // pinned_components bit 0 = the intercept variance pinned at 0 (spec.rs:566-573)
+    for (size_t i = 0; i < cells; ++i) out->pinned_components[i] = out->boundary_hit[i] == 1 ? 1ull : 0ull;
   out->kernel_ms = kernel_ms;
   out->aux_kernel_ms = aux_ms;
   out->n_kernel_launches = launched;

@@ -158,7 +158,16 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (n_ns > (uint32_t)MAX_GRID) return unsupported("more than " + std::to_string(MAX_GRID) + " sample sizes per call");
   if (spec->n_factors > (uint32_t)MAX_FACTORS) return unsupported("more than " + std::to_string(MAX_FACTORS) + " factors");
   if (spec->n_factor_proportions > (uint32_t)MAX_LEVELS) return unsupported("more than " + std::to_string(MAX_LEVELS) + " factor levels in total");
-  if (spec->estimator == MCP_EST_MLE) return unsupported("estimator Mle");
+  if (spec->estimator == MCP_EST_MLE) {
+    if (spec->cluster.n_slopes || spec->cluster.n_extra_groupings) return unsupported("random slopes / extra groupings (random intercept only)");
+    if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS) return unsupported("Mle on Binary / Count outcomes");
+    if (spec->n_contrast_pairs) return unsupported("contrast pairs under the Mle estimator");
+    if (P > 6) return unsupported("Mle with more than 6 design columns");
+    if (spec->cluster.sizing_value == 0) { err = "invalid spec: cluster sizing value must be > 0"; return MCP_ERR_INVALID_SPEC; }
+    if (spec->cluster.sizing == MCP_CLUSTER_FIXED_SIZE)
+      for (uint32_t g = 0; g < n_ns; ++g)
+        if (ns[g] % spec->cluster.sizing_value) return unsupported("FixedSize clusters with a sample size that is not a multiple of cluster_size");
+  }
   if (spec->estimator == MCP_EST_OLS && spec->outcome_kind != MCP_OUTCOME_CONTINUOUS)
     return unsupported("OLS on Binary / Count outcomes");
   if (spec->estimator == MCP_EST_GLM) {
@@ -166,7 +175,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       return unsupported("GLM families other than Binary/logit (probit, Poisson)");
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
-  if (spec->cluster.present) return unsupported("clustered data generation");
+  if (spec->cluster.present && spec->estimator != MCP_EST_MLE) return unsupported("clustered data generation outside the Mle estimator");
   if (!scenario_is_optimistic(spec->scenario)) return unsupported("scenario perturbations (optimistic path only so far)");
   if (spec->residual_dist != MCP_RESID_NORMAL) return unsupported("non-normal residual distributions");
   for (uint32_t j = 0; j < K; ++j)
@@ -223,6 +232,15 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   }
   prm.n_seq_pre = 0;
   prm.n_seq_per_row = n_sampled;
+  if (spec->cluster.present) {  // data_gen.rs:146-161: one RE draw per cluster present at max_n, before the row loop
+    prm.has_cluster = 1;
+    prm.cluster_fixed_clusters = spec->cluster.sizing == MCP_CLUSTER_FIXED_CLUSTERS ? 1u : 0u;
+    prm.cluster_v = spec->cluster.sizing_value;
+    prm.n_clusters_max = prm.cluster_fixed_clusters ? prm.cluster_v : max_n / prm.cluster_v;
+    prm.tau = std::sqrt(spec->cluster.tau_squared > 0.0 ? spec->cluster.tau_squared : 0.0);
+    prm.n_seq_pre = prm.n_clusters_max;
+  }
+  prm.truth_start = spec->scenario.truth_start ? 1u : 0u;
   low.fixed_levels.assign((size_t)max_n * (spec->n_factors ? spec->n_factors : 1), 0);
   {
     std::vector<uint32_t> counts(spec->n_factor_proportions ? spec->n_factor_proportions : 1, 0u);

@@ -1,0 +1,451 @@
+// lmm_kernels.hip -- gfx950 kernel of the random-intercept LMM (REML) simulate path.
+//
+// Mapping: ONE WAVEFRONT PER REPLICATE, design resident in LDS (as the GLM kernel).  A random
+// intercept's profiled REML deviance depends on the data only through per-cluster sums
+// (n_c, sum x_c, sum y_c) and the global X'X, X'y, y'y (scripts/lme_handcompute_theta1.py:55-93),
+// so one pass (lane = cluster, rows of a cluster walked by its lane) reduces the replicate to
+// n_clusters x (p + 1) doubles in LDS; every objective evaluation of the 1-D minimiser is then a
+// lane-strided sweep over clusters + one butterfly all-reduce + a p x p Cholesky, all wave-uniform.
+//
+// Reference: crates/engine-core/src/batch.rs:1214-1560 (Mle arm), data_gen.rs:146-161 (cluster
+// random-intercept draws on the sequential stream before the row loop), :811-857 (u_re added on the
+// latent scale), engine-contract/src/generation.rs:125-158 (row -> cluster).  The optimiser replaces
+// glmm 0.1.2 fit_on + bobyqa 0.1.1 (out of tree) with Brent's method on theta in [0, 32].
+#include <hip/hip_runtime.h>
+#include "mcp_device.hpp"
+#include "mcp_params.hpp"
+#include "mcp_rows.hpp"
+#include "mcp_decide.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mcp {
+
+constexpr int LWAVE = 64;
+constexpr double THETA_MAX = 32.0;
+constexpr double THETA_BLIND = 1.0;
+constexpr double THETA_TOL = 1e-9;
+constexpr double THETA_ZERO = 1e-6;
+constexpr int BRENT_MAX_ITERS = 100;
+constexpr double LMM_NEAR_ZERO = 1e-30;
+
+__device__ __forceinline__ double lwave_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < LWAVE; m <<= 1) v += __shfl_xor(v, m, LWAVE);
+  return v;
+}
+
+template <int P>
+struct LmmEval {
+  bool ok;
+  double dev, sigma_sq;
+  double beta[P];
+  double Lm[P][P];
+  double invd[P];
+};
+
+// dev(theta) and the REML solution at theta; csum = LDS [cluster][P+1] = {n_c, Sx_1..Sx_{P-1}, Sy}
+template <int P>
+__device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2], const double (&xty)[P], double yty,
+                                             const double* csum, uint32_t ncl, uint32_t n, double theta,
+                                             LmmEval<P>& e) {
+  const uint32_t lane = threadIdx.x;
+  const double th2 = theta * theta;
+  double dA[P * (P + 1) / 2], db[P], dyy = 0.0, ldv = 0.0;
+#pragma unroll
+  for (int i = 0; i < P * (P + 1) / 2; ++i) dA[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < P; ++i) db[i] = 0.0;
+  for (uint32_t c = lane; c < ncl; c += LWAVE) {
+    const double* cs = csum + (size_t)c * (P + 1);
+    const double nc = cs[0];
+    if (nc > 0.0) {
+      const double s = th2 / (1.0 + th2 * nc);
+      double sx[P];
+      sx[0] = nc;
+#pragma unroll
+      for (int a = 1; a < P; ++a) sx[a] = cs[a];
+      const double sy = cs[P];
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        const double ssa = s * sx[a];
+#pragma unroll
+        for (int q = 0; q <= a; ++q) {
+          dA[idx] = __builtin_fma(ssa, sx[q], dA[idx]);
+          ++idx;
+        }
+        db[a] = __builtin_fma(ssa, sy, db[a]);
+      }
+      dyy = __builtin_fma(s * sy, sy, dyy);
+      ldv += log(1.0 + th2 * nc);
+    }
+  }
+  double A[P][P], b[P];
+  {
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+#pragma unroll
+      for (int q = 0; q <= a; ++q) {
+        A[a][q] = xtx[idx] - lwave_sum(dA[idx]);
+        ++idx;
+      }
+      b[a] = xty[a] - lwave_sum(db[a]);
+    }
+  }
+  const double yy = yty - lwave_sum(dyy);
+  const double logdetv = lwave_sum(ldv);
+  e.ok = false;
+  e.dev = __builtin_inf();
+  bool ok = true;
+  double logdetA = 0.0;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    double dd = A[j][j];
+#pragma unroll
+    for (int t = 0; t < j; ++t) dd = __builtin_fma(-e.Lm[j][t], e.Lm[j][t], dd);
+    ok = ok && (dd > 0.0) && (dd < __builtin_inf());
+    const double ljj = __builtin_sqrt(dd);
+    e.Lm[j][j] = ljj;
+    e.invd[j] = 1.0 / ljj;
+    logdetA += 2.0 * log(ljj);
+#pragma unroll
+    for (int i = j + 1; i < P; ++i) {
+      double v = A[i][j];
+#pragma unroll
+      for (int t = 0; t < j; ++t) v = __builtin_fma(-e.Lm[i][t], e.Lm[j][t], v);
+      e.Lm[i][j] = v * e.invd[j];
+    }
+  }
+  if (!ok) return;
+  double zf[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    double v = b[i];
+#pragma unroll
+    for (int t = 0; t < i; ++t) v = __builtin_fma(-e.Lm[i][t], zf[t], v);
+    zf[i] = v * e.invd[i];
+  }
+#pragma unroll
+  for (int i = P - 1; i >= 0; --i) {
+    double v = zf[i];
+#pragma unroll
+    for (int t = i + 1; t < P; ++t) v = __builtin_fma(-e.Lm[t][i], e.beta[t], v);
+    e.beta[i] = v * e.invd[i];
+  }
+  double bxy = 0.0;
+#pragma unroll
+  for (int i = 0; i < P; ++i) bxy = __builtin_fma(e.beta[i], b[i], bxy);
+  const double df = (double)n - (double)P;
+  e.sigma_sq = (yy - bxy) / df;
+  if (!(e.sigma_sq > 0.0) || !(e.sigma_sq < __builtin_inf())) return;
+  e.dev = logdetv + logdetA + df * log(e.sigma_sq);
+  e.ok = e.dev < __builtin_inf() && e.dev > -__builtin_inf();
+}
+
+// LDS layout per block (one wave): design [P columns: x1..x_{P-1}, y][n_pad] f32 | cluster_u [ncl_pad] f32 |
+// csum [ncl_max][P+1] f64 | staging [4P][64] f32
+template <int P, bool FACTORS>
+__global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ double lds_d[];
+  const SimParams& prm = *pp;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lsim = blockIdx.x;
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t out_row = prm.out_base + lsim;
+  const uint32_t max_n = prm.max_n;
+  const uint32_t n_pad = (max_n + 3u) & ~3u;
+  const uint32_t ncl_max = prm.n_clusters_max;
+  const uint32_t ncl_pad = (ncl_max + 1u) & ~1u;
+  const uint32_t cv = prm.cluster_v;
+  double* csum = lds_d;                                                   // ncl_max * (P + 1) doubles (8-byte aligned first)
+  float* design = (float*)(lds_d + (size_t)ncl_max * (P + 1));           // P * n_pad
+  float* cluster_u = design + (size_t)P * n_pad;                         // ncl_pad
+  float* st = cluster_u + ncl_pad + lane;                                // staging, stride 64
+
+  // ---- cluster random intercepts: draw c is word c of the sequential stream (data_gen.rs:146-161) ----
+  for (uint32_t c = lane; c < ncl_max; c += LWAVE) {
+    const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
+    cluster_u[c] = (float)((double)z * prm.tau);
+  }
+  __syncthreads();
+
+  // ---- generate the replicate into LDS ----
+  RowCtx<P> cx;
+  row_ctx_init<P, FACTORS>(prm, cx);
+  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += LWAVE) {
+    stage_group<P, LWAVE, 0>(prm, k0, k1, ctr, st);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t rr = 4u * ctr + r;
+      if (rr < max_n) {
+        const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
+        const double u_re = (double)cluster_u[cid < ncl_max ? cid : 0u];
+        float x[P], y;
+        build_row<P, FACTORS, LWAVE, 0>(prm, cx, k0, k1, st, r, rr, x, y, u_re);
+#pragma unroll
+        for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
+        design[(size_t)(P - 1) * n_pad + rr] = y;
+      }
+    }
+  }
+  __syncthreads();
+
+  const uint32_t nt = prm.n_tests;
+  bool has_prev = false;
+  double theta_carry = 0.0;
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n = prm.ns[g];
+    const uint32_t ncl = prm.cluster_fixed_clusters ? cv : (n + cv - 1u) / cv;
+    // ---- per-cluster sums (lane = cluster) and global X'X, X'y, y'y ----
+    double xtx[P * (P + 1) / 2], xty[P], yty = 0.0;
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) xty[i] = 0.0;
+    for (uint32_t c = lane; c < ncl; c += LWAVE) {
+      double sx[P], sy = 0.0, nc = 0.0;
+#pragma unroll
+      for (int a = 0; a < P; ++a) sx[a] = 0.0;
+      const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
+      const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
+      const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
+      for (uint32_t i = first; i < last; i += step) {
+        double xd[P];
+        xd[0] = 1.0;
+#pragma unroll
+        for (int a = 1; a < P; ++a) xd[a] = (double)design[(size_t)(a - 1) * n_pad + i];
+        const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
+        nc += 1.0;
+        sy += yi;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+          if (a > 0) sx[a] += xd[a];
+#pragma unroll
+          for (int q = 0; q <= a; ++q) {
+            xtx[idx] = __builtin_fma(xd[a], xd[q], xtx[idx]);
+            ++idx;
+          }
+          xty[a] = __builtin_fma(xd[a], yi, xty[a]);
+        }
+        yty = __builtin_fma(yi, yi, yty);
+      }
+      double* cs = csum + (size_t)c * (P + 1);
+      cs[0] = nc;
+#pragma unroll
+      for (int a = 1; a < P; ++a) cs[a] = sx[a];
+      cs[P] = sy;
+    }
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = lwave_sum(xtx[i]);
+#pragma unroll
+    for (int i = 0; i < P; ++i) xty[i] = lwave_sum(xty[i]);
+    yty = lwave_sum(yty);
+    __syncthreads();
+
+    // ---- Brent's minimiser of dev(theta) on [0, THETA_MAX] (fmin), first probe at the start value ----
+    double start = has_prev ? theta_carry : (prm.truth_start ? prm.tau : THETA_BLIND);
+    start = start < 0.01 ? 0.01 : start;  // THETA_TRUTH_FLOOR (batch.rs:1316-1321)
+    LmmEval<P> ev;
+    const double CGOLD = 0.3819660112501051;
+    double a = 0.0, b = THETA_MAX;
+    double x = start;
+    x = (x > a + 1e-3) ? x : a + 1e-3;
+    x = (x < b - 1e-3) ? x : b - 1e-3;
+    double w = x, v = x, e = 0.0, dstep = 0.0;
+    lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, x, ev);
+    double fx = ev.dev, fw = fx, fv = fx;
+    for (int it = 0; it < BRENT_MAX_ITERS; ++it) {
+      const double xm = 0.5 * (a + b);
+      const double tol1 = THETA_TOL * __builtin_fabs(x) + 1e-10, tol2 = 2.0 * tol1;
+      if (__builtin_fabs(x - xm) <= tol2 - 0.5 * (b - a)) break;
+      bool golden = true;
+      if (__builtin_fabs(e) > tol1) {
+        const double r = (x - w) * (fx - fv);
+        double q = (x - v) * (fx - fw);
+        double pq = (x - v) * q - (x - w) * r;
+        q = 2.0 * (q - r);
+        if (q > 0.0) pq = -pq;
+        q = __builtin_fabs(q);
+        const double etemp = e;
+        e = dstep;
+        if (!(__builtin_fabs(pq) >= __builtin_fabs(0.5 * q * etemp) || pq <= q * (a - x) || pq >= q * (b - x))) {
+          dstep = pq / q;
+          const double u = x + dstep;
+          if (u - a < tol2 || b - u < tol2) dstep = (xm - x >= 0.0) ? tol1 : -tol1;
+          golden = false;
+        }
+      }
+      if (golden) {
+        e = (x >= xm) ? a - x : b - x;
+        dstep = CGOLD * e;
+      }
+      const double u = __builtin_fabs(dstep) >= tol1 ? x + dstep : x + (dstep >= 0.0 ? tol1 : -tol1);
+      lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, u, ev);
+      const double fu = ev.dev;
+      if (fu <= fx) {
+        if (u >= x) a = x; else b = x;
+        v = w; fv = fw; w = x; fw = fx; x = u; fx = fu;
+      } else {
+        if (u < x) a = u; else b = u;
+        if (fu <= fw || w == x) { v = w; fv = fw; w = u; fw = fu; }
+        else if (fu <= fv || v == x || v == w) { v = u; fv = fu; }
+      }
+    }
+    // the interior search never evaluates theta = 0: compare with the boundary value
+    double th = x;
+    lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, 0.0, ev);
+    const bool at0_ok = ev.ok;
+    const double dev0 = ev.dev;
+    const bool interior_ok = fx < __builtin_inf() && fx > -__builtin_inf();
+    if (at0_ok && (!interior_ok || dev0 <= fx || th < THETA_ZERO)) {
+      th = 0.0;  // ev already holds the theta = 0 solution
+    } else {
+      lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, th, ev);
+    }
+    bool conv = ev.ok;
+    const uint32_t bh = !ev.ok ? 0u : (th < THETA_ZERO ? 1u : (th > THETA_MAX - 1e-3 ? 2u : 0u));
+    if (bh == 2u) conv = false;
+    if (conv) {
+      theta_carry = th;
+      has_prev = true;
+    }
+
+    // ---- Wald z^2 (cov = sigma^2 (X'V^-1X)^-1), joint Wald chi2 over the targets, decisions ----
+    const double* crow = prm.crit + (size_t)g * prm.crit_stride;
+    double tsq[MAX_T];
+    double U[MAX_T][P];  // L^-1 c_t
+#pragma unroll
+    for (int t = 0; t < MAX_T; ++t) {
+      tsq[t] = __builtin_nan("");
+#pragma unroll
+      for (int i = 0; i < P; ++i) U[t][i] = 0.0;
+      if ((uint32_t)t < nt && conv) {
+        const double* c = prm.contrast + t * MAX_P;
+        double est = 0.0, nq = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          est = __builtin_fma(c[i], ev.beta[i], est);
+          double acc = c[i];
+#pragma unroll
+          for (int q = 0; q < i; ++q) acc = __builtin_fma(-ev.Lm[i][q], U[t][q], acc);
+          U[t][i] = acc * ev.invd[i];
+          nq = __builtin_fma(U[t][i], U[t][i], nq);
+        }
+        const double var = ev.sigma_sq * nq;
+        if (var > LMM_NEAR_ZERO && var < __builtin_inf()) tsq[t] = est * est / var;
+      }
+    }
+    // joint: b_T' Cov_TT^-1 b_T with Cov_ab = sigma^2 U_a.U_b (Cholesky of the nt x nt block)
+    bool joint_sig = false;
+    if (conv && nt > 0) {
+      double Lc[MAX_T][MAX_T], cj[MAX_T];
+      bool jok = true;
+      double qsum = 0.0;
+#pragma unroll
+      for (int j = 0; j < MAX_T; ++j) {
+        if ((uint32_t)j < nt) {
+          double dd = 0.0;
+#pragma unroll
+          for (int i = 0; i < P; ++i) dd = __builtin_fma(U[j][i], U[j][i], dd);
+          dd *= ev.sigma_sq;
+#pragma unroll
+          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j][t], Lc[j][t], dd);
+          jok = jok && (dd > 0.0);
+          Lc[j][j] = __builtin_sqrt(dd);
+#pragma unroll
+          for (int i2 = j + 1; i2 < MAX_T; ++i2) {
+            if ((uint32_t)i2 < nt) {
+              double vv = 0.0;
+#pragma unroll
+              for (int i = 0; i < P; ++i) vv = __builtin_fma(U[i2][i], U[j][i], vv);
+              vv *= ev.sigma_sq;
+#pragma unroll
+              for (int t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2][t], Lc[j][t], vv);
+              Lc[i2][j] = vv / Lc[j][j];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAX_T; ++i) {
+        if ((uint32_t)i < nt) {
+          const double* c = prm.contrast + i * MAX_P;
+          double vv = 0.0;
+#pragma unroll
+          for (int q = 0; q < P; ++q) vv = __builtin_fma(c[q], ev.beta[q], vv);
+#pragma unroll
+          for (int t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i][t], cj[t], vv);
+          cj[i] = vv / Lc[i][i];
+          qsum = __builtin_fma(cj[i], cj[i], qsum);
+        }
+      }
+      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > crow[2 + nt]);
+    }
+    uint32_t unc_bits = 0, cor_bits = 0;
+    decide_tests(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
+    if (!conv) {
+      unc_bits = 0;
+      cor_bits = 0;
+    }
+    if (lane == 0) {
+      const size_t cell = (size_t)out_row * prm.n_grid + g;
+#pragma unroll
+      for (int t = 0; t < MAX_T; ++t)
+        if ((uint32_t)t < nt) {
+          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
+          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
+        }
+      prm.conv[cell] = conv ? 1 : 0;
+      prm.boundary[cell] = (uint8_t)bh;
+      prm.joint[cell] = joint_sig ? 1 : 0;
+      if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1449-1451
+      if (prm.stat && g == 0) {
+#pragma unroll
+        for (int t = 0; t < MAX_T; ++t)
+          if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
+      }
+    }
+    __syncthreads();  // csum is rebuilt for the next grid point
+  }
+}
+
+size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max) {
+  const size_t n_pad = (max_n + 3u) & ~3u;
+  const size_t ncl_pad = (ncl_max + 1u) & ~(size_t)1u;
+  return (size_t)ncl_max * (P + 1) * sizeof(double) + ((size_t)P * n_pad + ncl_pad + (size_t)4 * P * LWAVE) * sizeof(float);
+}
+
+template <bool FACTORS>
+static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max,
+                               hipStream_t st) {
+  const size_t lds = lmm_lds_bytes(P, max_n, ncl_max);
+  const dim3 block(LWAVE), grid(n_sims);
+#define LL(PP)                                                                                                        \
+  case PP: {                                                                                                          \
+    if (lds > 48 * 1024) {                                                                                            \
+      hipError_t e = hipFuncSetAttribute((const void*)lmm_sim_kernel<PP, FACTORS>,                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+      if (e != hipSuccess) return e;                                                                                  \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((lmm_sim_kernel<PP, FACTORS>), grid, block, lds, st, d_prm);                                   \
+  } break;
+  switch (P) {
+    LL(2) LL(3) LL(4) LL(5) LL(6)
+    default: return hipErrorInvalidValue;
+  }
+#undef LL
+  return hipGetLastError();
+}
+
+hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
+                          hipStream_t st) {
+  return factors ? launch_lmm_f<true>(P, d_prm, n_sims, max_n, ncl_max, st)
+                 : launch_lmm_f<false>(P, d_prm, n_sims, max_n, ncl_max, st);
+}
+
+}  // namespace mcp

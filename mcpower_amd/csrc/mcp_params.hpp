@@ -72,8 +72,13 @@ struct SimParams {
   uint8_t* conv;                     // [n_sims_total][n_grid] or null
   uint8_t* overall;
   double* stat;                      // [n_sims_total][n_tests] or null
+  uint8_t* boundary;                 // [n_sims_total][n_grid] boundary_hit (Mle arm) or null
+  uint8_t* joint;                    // [n_sims_total][n_grid] joint Wald chi2 decision (Mle arm) or null
   unsigned long long* counters;      // [n_grid][ctr_stride]
   uint32_t ctr_stride, ctr_k_unc, ctr_k_cor, ctr_conv, ctr_overall, ctr_hist_unc, ctr_hist_cor, ctr_n_sims;
+  uint32_t ctr_joint_unc, ctr_joint_cor, ctr_boundary_1, ctr_boundary_2;
+  uint32_t truth_start;              // scenario.truth_start (Mle start theta)
+  uint32_t _pad_tail;
 
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;

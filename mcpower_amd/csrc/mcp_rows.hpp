@@ -105,7 +105,8 @@ __device__ __forceinline__ void row_ctx_init(const SimParams& prm, RowCtx<P>& cx
 // one design row + outcome from the staged normals (data_gen.rs:334-363, 509-551, 643-649, 781-857)
 template <int P, bool FACTORS, int STRIDE, int OUTCOME>
 __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
-                                          const float* st, int r, uint32_t row, float (&x)[P], float& y) {
+                                          const float* st, int r, uint32_t row, float (&x)[P], float& y,
+                                          double u_re = 0.0) {
   const uint32_t K = cx.K;
   float z[P - 1];
 #pragma unroll
@@ -161,9 +162,9 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
   for (int c = 0; c < P; ++c)
     if ((cx.beta_nz >> c) & 1u) lp = lp + (double)x[c] * cx.beta[c];
   if (OUTCOME == 0) {
-    y = (float)((lp + (double)e) + 0.0);
+    y = (float)((lp + (double)e) + u_re);  // u_re = 0.0 without a cluster (data_gen.rs:814-857)
   } else {  // Bernoulli(sigmoid(eta)): 1{u < sigma(eta)} with the pre-drawn uniform (data_gen.rs:890-911)
-    const double eta = lp + 0.0;
+    const double eta = lp + u_re;
     const double pr = eta >= 0.0 ? 1.0 / (1.0 + exp(-eta)) : exp(eta) / (1.0 + exp(eta));
     y = ((double)e < pr) ? 1.0f : 0.0f;
   }

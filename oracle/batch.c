@@ -211,6 +211,8 @@ static void* worker(void* arg) {
                         R->joint_unc + cell0, R->joint_cor + cell0,
                         R->stat_capture ? R->stat_capture + (size_t)s * nt : NULL);
       if (rc) { jb->rc = rc; break; }
+      for (uint32_t g = 0; g < n_ns; ++g) /* bit 0 = intercept variance pinned at 0 (spec.rs:566-573) */
+        R->pinned_components[cell0 + g] = R->boundary_hit[cell0 + g] == 1 ? 1u : 0u;
     }
   }
   mcpo_ws_free(ws);

@@ -92,6 +92,12 @@ int mcpo_glm_fit(const float* x_colmajor, const float* y, uint32_t n_rows, uint3
                  const double* beta_start, double* beta, double* se, double* z_sq, double* deviance,
                  double* deviance_null, uint8_t* converged, uint32_t* n_iter);
 
+/* ---- random-intercept REML on provided bytes (glmm fit_on; closed-form profiled deviance, see fit_lmm.c) ---- */
+int mcpo_lmm_fit(const float* x_colmajor, const float* y, const uint32_t* cluster_ids, uint32_t n_rows, uint32_t ld,
+                 uint32_t p, uint32_t n_clusters, double theta_start, double* beta, double* se, double* z_sq,
+                 double* theta_hat, double* sigma_sq, double* tau_sq, uint8_t* converged, uint8_t* boundary_hit,
+                 uint32_t* n_eval);
+
 /* ---- run_batch (batch.rs:199-776) ----------------------------------------
  * Same contract as mcp_run_batch; `n_threads` >= 1 splits the replicate range
  * over pthreads (results identical for any thread count). */

@@ -61,6 +61,7 @@ def lib() -> C.CDLL:
         L.mcpo_build_crit_table.restype = C.c_int
         L.mcpo_ols_fit.restype = C.c_int
         L.mcpo_glm_fit.restype = C.c_int
+        L.mcpo_lmm_fit.restype = C.c_int
         _lib = L
     return _lib
 
@@ -197,6 +198,27 @@ def glm_fit(design: np.ndarray, outcome: np.ndarray, beta_start=None):
     _check(rc)
     return dict(beta=beta, se=se, z_sq=zsq, deviance=dev.value, deviance_null=dev0.value,
                 converged=bool(conv.value), n_iter=nit.value)
+
+
+def lmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, theta_start: float = 0.0):
+    """Random-intercept REML on provided bytes: design (n, p), outcome (n,), 0-based cluster ids (n,)."""
+    n, p = design.shape
+    x = np.ascontiguousarray(design.T, dtype=np.float32)
+    y = np.ascontiguousarray(outcome, dtype=np.float32)
+    ids = np.ascontiguousarray(cluster_ids, dtype=np.uint32)
+    ncl = int(ids.max()) + 1
+    beta, se, zsq = (np.zeros(p) for _ in range(3))
+    th, s2, t2 = C.c_double(), C.c_double(), C.c_double()
+    conv, bh, ne = C.c_uint8(), C.c_uint8(), C.c_uint32()
+    pd = C.POINTER(C.c_double)
+    rc = lib().mcpo_lmm_fit(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                            ids.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(n), C.c_uint32(n), C.c_uint32(p),
+                            C.c_uint32(ncl), C.c_double(theta_start), beta.ctypes.data_as(pd), se.ctypes.data_as(pd),
+                            zsq.ctypes.data_as(pd), C.byref(th), C.byref(s2), C.byref(t2), C.byref(conv), C.byref(bh),
+                            C.byref(ne))
+    _check(rc)
+    return dict(beta=beta, se=se, z_sq=zsq, theta=th.value, sigma_sq=s2.value, tau_sq=t2.value,
+                converged=bool(conv.value), boundary_hit=int(bh.value), n_eval=ne.value)
 
 
 def run_batch(spec: S.SimulationSpec, sample_sizes, n_sims: int, base_seed: int, *, sim_offset: int = 0,

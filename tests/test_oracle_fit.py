@@ -129,3 +129,43 @@ def test_run_batch_shapes_thread_invariance_and_counters(oracle):
     b = oracle.run_batch(spec, [50, 100, 200], 200, BASE_SEED, sim_offset=100)
     assert np.array_equal(a.counters + b.counters, r1.counters)
     assert np.array_equal(np.concatenate([a.uncorrected, b.uncorrected]), r1.uncorrected)
+
+
+@pytest.mark.parametrize("name", case_names("logit"))
+def test_glm_irls_matches_r_goldens(oracle, name):
+    """Oracle IRLS vs R `glm` on the reference's own bytes: gate 1e-4 relative on beta / se / z
+    (validation/tolerances.R:29-31, estimate_rel_iter); observed <= 2e-5."""
+    spec, seed, arr, low = load_case(name)
+    f = oracle.glm_fit(arr["design"], arr["outcome"], spec.effect_sizes)  # truth start (batch.rs:1945-1951)
+    assert f["converged"] and 2 <= f["n_iter"] <= 25
+    np.testing.assert_allclose(f["beta"], arr["golden_beta"], rtol=1e-4, atol=0)
+    np.testing.assert_allclose(f["se"], arr["golden_se"], rtol=1e-4, atol=0)
+    np.testing.assert_allclose(f["beta"] / f["se"], arr["golden_stat"], rtol=1e-4, atol=0)
+    cold = oracle.glm_fit(arr["design"], arr["outcome"], None)           # start-independent optimum
+    np.testing.assert_allclose(cold["beta"], f["beta"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", case_names("lme"))
+def test_lmm_reml_matches_lme4_goldens(oracle, name):
+    """Oracle profiled-REML fit vs lme4 1.1.38 REML on the reference's own bytes: gate 1e-4 relative on
+    beta / se / Wald z (tolerances.R:29-31); observed <= 6e-8."""
+    spec, seed, arr, low = load_case(name)
+    ids = arr["cluster_ids"].astype(np.int64)
+    ids = ids - ids.min()
+    f = oracle.lmm_fit(arr["design"], arr["outcome"], ids, np.sqrt(low["cluster"]["tau_squared"]))
+    assert f["converged"] and f["boundary_hit"] == 0 and f["n_eval"] < 60
+    np.testing.assert_allclose(f["beta"], arr["golden_beta"], rtol=1e-4, atol=0)
+    np.testing.assert_allclose(f["se"], arr["golden_se"], rtol=1e-4, atol=0)
+    np.testing.assert_allclose(f["beta"] / f["se"], arr["golden_stat"], rtol=1e-4, atol=0)
+    blind = oracle.lmm_fit(arr["design"], arr["outcome"], ids, 0.0)      # blind start reaches the same optimum
+    assert abs(blind["theta"] - f["theta"]) < 1e-6
+
+
+def test_glm_and_lmm_run_batch_smoke(oracle):
+    from helpers import spec_c3, spec_c4
+    r = oracle.run_batch(spec_c3(), [500], 300, BASE_SEED, n_threads=4)
+    assert r.converged.all() and r.counter("k_unc", 3)[0, 0] > 250
+    r = oracle.run_batch(spec_c4(), [300, 600], 200, BASE_SEED, n_threads=4)
+    assert r.converged.all() and (r.boundary_hit == 0).all()
+    assert r.counter("joint_unc")[1, 0] >= r.counter("joint_unc")[0, 0]
+    assert r.shape.n_variance_components == 1
