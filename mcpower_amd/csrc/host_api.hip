@@ -21,8 +21,9 @@
 #include "mcp_params.hpp"
 
 namespace mcp {
-hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, bool factors, hipStream_t st);
-hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, bool factors, hipStream_t st);
+hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, hipStream_t st);
+hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
+hipError_t launch_scenario_design(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
 hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, hipStream_t st);
 hipError_t launch_ols_fit_provided(int P, const float* design, const float* outcome, uint32_t n_fits, uint32_t n,
                                    double* beta, double* se, double* tsq, double* rss, double* sst, uint8_t* conv,
@@ -59,7 +60,7 @@ struct Arena {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Buf slots[16];
+  Buf slots[20];
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
   int device = -1;
@@ -91,7 +92,7 @@ struct Arena {
 };
 thread_local Arena g_arena;
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3 };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
   int n = 0;
@@ -256,6 +257,22 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   }
   if (want_stat) DEV_TRY(ar.get(S_STAT, ((size_t)n_sims * nt + 1) * sizeof(double), (void**)&d_stat));
   // design tile: [block of 256 replicates][P columns: x1..x_{P-1}, y][max_n rows][256] f32
+  // general path: per-replicate design records (lower factor, marginal / residual codes, per-study effects)
+  const bool scen = prm.scen_active;
+  const int flavor = scen ? 2 : (spec->n_factors > 0 ? 1 : 0);
+  double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr;
+  uint32_t* d_scen_meta = nullptr;
+  if (scen) {
+    const uint32_t K = spec->n_non_factor;
+    DEV_TRY(ar.get(S_SCEN_L, (size_t)(K * (K + 1) / 2 + 1) * chunk * sizeof(double), (void**)&d_scen_L));
+    DEV_TRY(ar.get(S_SCEN_META, (size_t)chunk * sizeof(uint32_t), (void**)&d_scen_meta));
+    if (low.need_beta_eff) DEV_TRY(ar.get(S_SCEN_BETA, (size_t)P * chunk * sizeof(double), (void**)&d_scen_beta));
+    if (low.need_t3) {
+      const std::vector<double> t3 = mcp::build_t3_table();
+      DEV_TRY(ar.get(S_T3, t3.size() * sizeof(double), (void**)&d_t3));
+      DEV_TRY(hipMemcpy(d_t3, t3.data(), t3.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   if (staged) DEV_TRY(ar.get(S_TILE, (size_t)((chunk + 255u) / 256u) * 256u * P * prm.max_n * sizeof(float), (void**)&d_tile));
 
   hipEvent_t ev_begin, ev_end;
@@ -280,6 +297,11 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   prm.ctr_hist_cor = layout.hist_cor; prm.ctr_n_sims = layout.n_sims;
   prm.tile = d_tile;
   prm.tile_sims = chunk;
+  prm.scen_L = d_scen_L;
+  prm.scen_meta = d_scen_meta;
+  prm.scen_beta = d_scen_beta;
+  prm.scen_stride = chunk;
+  prm.t3_table = d_t3;
   std::vector<mcp::SimParams> h_prm(n_chunks, prm);
   for (uint32_t c = 0; c < n_chunks; ++c) {
     const uint32_t b = c * chunk;
@@ -298,6 +320,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     DEV_TRY(ar.event(2 + c * ev_per_chunk, &e0));
     DEV_TRY(ar.event(3 + c * ev_per_chunk, &e1));
     if (staged || glm) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
+    if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
       if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, st));
@@ -306,10 +329,10 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
     } else if (!staged) {
-      DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, spec->n_factors > 0, st));
+      DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, flavor, st));
       DEV_TRY(hipEventRecord(e1, st));
     } else {
-      DEV_TRY(mcp::launch_ols_generate((int)P, d_prm + c, h_prm[c].n_sims, spec->n_factors > 0, st));
+      DEV_TRY(mcp::launch_ols_generate((int)P, d_prm + c, h_prm[c].n_sims, flavor, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_ols_fit((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, st));
       DEV_TRY(hipEventRecord(e2, st));
@@ -422,8 +445,24 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   prm.fixed_levels = d_levels;
   prm.tile = d_tile;
   prm.tile_sims = n_sims;
+  const bool scen = prm.scen_active;
+  if (scen) {
+    const uint32_t K = spec->n_non_factor;
+    double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr;
+    uint32_t* d_scen_meta = nullptr;
+    HIP_TRY(ar.get(S_SCEN_L, (size_t)(K * (K + 1) / 2 + 1) * n_sims * sizeof(double), (void**)&d_scen_L));
+    HIP_TRY(ar.get(S_SCEN_META, (size_t)n_sims * sizeof(uint32_t), (void**)&d_scen_meta));
+    if (low.need_beta_eff) HIP_TRY(ar.get(S_SCEN_BETA, (size_t)P * n_sims * sizeof(double), (void**)&d_scen_beta));
+    if (low.need_t3) {
+      const std::vector<double> t3 = mcp::build_t3_table();
+      HIP_TRY(ar.get(S_T3, t3.size() * sizeof(double), (void**)&d_t3));
+      HIP_TRY(hipMemcpy(d_t3, t3.data(), t3.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    prm.scen_L = d_scen_L; prm.scen_meta = d_scen_meta; prm.scen_beta = d_scen_beta; prm.scen_stride = n_sims; prm.t3_table = d_t3;
+  }
   HIP_TRY(hipMemcpyAsync(d_prm, &prm, sizeof prm, hipMemcpyHostToDevice, st));
-  HIP_TRY(mcp::launch_ols_generate((int)P, d_prm, n_sims, spec->n_factors > 0, st));
+  if (scen) HIP_TRY(mcp::launch_scenario_design(d_prm, n_sims, st));
+  HIP_TRY(mcp::launch_ols_generate((int)P, d_prm, n_sims, scen ? 2 : (spec->n_factors > 0 ? 1 : 0), st));
   std::vector<float> tile(tile_floats);
   HIP_TRY(hipMemcpyAsync(tile.data(), d_tile, tile_floats * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -209,6 +209,26 @@ double f_ppf(double p, double dfn, double dfd) {
       });
 }
 
+// standardized t(3) PPF table of the HighKurtosis marginal (marginals/t3.rs:44-80): 2048 knots on
+// [0.00121, 0.99879], scaled to unit variance by the trapezoid moments of the clamped table
+std::vector<double> build_t3_table() {
+  const int n = 2048;
+  const double pmin = 0.00121, pmax = 0.99879, denom = n - 1;
+  std::vector<double> v(n);
+  for (int i = 0; i < n; ++i) v[i] = t_ppf(pmin + (pmax - pmin) * double(i) / denom, 3.0);
+  const double du = (pmax - pmin) / denom;
+  double m1 = pmin * v[0] + (1.0 - pmax) * v[n - 1];
+  double m2 = pmin * v[0] * v[0] + (1.0 - pmax) * v[n - 1] * v[n - 1];
+  for (int i = 0; i + 1 < n; ++i) {
+    const double a = v[i], b = v[i + 1];
+    m1 += du * (a + b) / 2.0;
+    m2 += du * (a * a + a * b + b * b) / 3.0;
+  }
+  const double sd = std::sqrt(m2 - m1 * m1);
+  for (double& x : v) x /= sd;
+  return v;
+}
+
 // CritValueTable::build_with_tukey_k (critvals.rs:827-1012).  Row layout per sample size:
 // [t_crit_sq_uncorrected, correction_t_crit_sq[0..m), posthoc_t_crit_sq, joint_t_crit_sq, overall_crit]
 int build_crit_rows(int estimator, int correction, double alpha, double posthoc_alpha, uint32_t n_predictors,

@@ -22,7 +22,10 @@ struct Lowered {
   std::vector<uint8_t> fixed_levels;  // [max_n][n_factors]
   std::vector<double> crit;           // [n_grid][n_tests + 4]
   uint32_t P = 0, n_tests = 0;
+  bool need_t3 = false;        // a HighKurtosis marginal can occur: upload the t(3) PPF table
+  bool need_beta_eff = false;  // heterogeneity > 0: per-study effects are part of the design record
 };
+std::vector<double> build_t3_table();
 int validate_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, std::string& err);
 int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParams& prm, Lowered& low, std::string& err);
 void counter_layout(const mcp_spec* spec, mcp_counter_layout* L);

@@ -176,16 +176,26 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
   if (spec->cluster.present && spec->estimator != MCP_EST_MLE) return unsupported("clustered data generation outside the Mle estimator");
-  if (!scenario_is_optimistic(spec->scenario)) return unsupported("scenario perturbations (optimistic path only so far)");
-  if (spec->residual_dist != MCP_RESID_NORMAL) return unsupported("non-normal residual distributions");
-  for (uint32_t j = 0; j < K; ++j)
-    if (spec->var_types[j] != MCP_DIST_NORMAL) return unsupported("non-normal predictor marginals");
+  // general ("scenario") data-generating path: anything beyond N(0,1) predictors + N(0,1) residual + fixed design
+  bool general = !scenario_is_optimistic(spec->scenario) || spec->residual_dist != MCP_RESID_NORMAL;
+  for (uint32_t j = 0; j < K; ++j) {
+    const int vt = spec->var_types[j];
+    if (vt == MCP_DIST_UPLOADED_DATA || vt == MCP_DIST_UPLOADED_BINARY || vt == MCP_DIST_UPLOADED_FACTOR)
+      return unsupported("uploaded-data marginals");
+    if (vt != MCP_DIST_NORMAL) general = true;
+  }
+  if (general && spec->estimator != MCP_EST_OLS) return unsupported("scenario perturbations / non-normal shapes under Glm / Mle (OLS only so far)");
+  if (general && K > 6) return unsupported("general data-generating path with more than 6 continuous predictors");
+  if (spec->scenario.has_lme) return unsupported("LME scenario knobs (random-effect distribution, ICC jitter)");
   if (spec->n_bootstrap_frame_map || spec->upload_normal_rows || spec->upload_data_rows) return unsupported("uploaded data");
   if (spec->n_between_var_indices) return unsupported("cluster-level (between) predictors");
   if (spec->n_posthoc) return unsupported("post-hoc contrasts");
   if (spec->n_fit_columns && spec->n_fit_columns < P) return unsupported("reduced test design (fit_columns)");
   if (spec->n_factors && spec->factor_min_level_count > 0) return unsupported("sparse-factor exclusion");
-  if (spec->heteroskedasticity_driver >= 0 && spec->scenario.heteroskedasticity_ratio != 1.0) return unsupported("heteroskedasticity");
+  if (spec->heteroskedasticity_driver >= (int32_t)(1 + K + spec->n_factor_dummies)) {
+    err = "invalid spec: heteroskedasticity_driver out of range";
+    return MCP_ERR_INVALID_SPEC;
+  }
 
   prm.max_n = max_n;
   prm.n_grid = n_ns;
@@ -279,6 +289,104 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   prm.crit_stride = nt + 4;
   prm.outcome_kind = (uint32_t)spec->outcome_kind;
   prm.estimator = (uint32_t)spec->estimator;
+
+  // ---- general path constants (data_gen.rs:709-776, 990-1093) ----
+  prm.scen_active = general ? 1u : 0u;
+  prm.scen_optimistic = scenario_is_optimistic(spec->scenario) ? 1u : 0u;
+  if (general) {
+    const mcp_scenario& sc = spec->scenario;
+    for (uint32_t i = 0; i < K * K; ++i) prm.corr[i] = spec->correlation[i];
+    for (uint32_t j = 0; j < K; ++j) {
+      prm.var_types[j] = (uint32_t)spec->var_types[j];
+      prm.var_pinned[j] = (j < spec->n_var_pinned && spec->var_pinned[j]) ? 1u : 0u;
+      prm.var_params[j] = j < spec->n_var_params ? spec->var_params[j] : 0.5;
+    }
+    prm.resid_spec_dist = (uint32_t)spec->residual_dist;
+    prm.residual_pinned = spec->residual_pinned ? 1u : 0u;
+    prm.corr_noise_sd = sc.correlation_noise_sd;
+    prm.dist_change_prob = sc.distribution_change_prob;
+    prm.resid_change_prob = sc.residual_change_prob;
+    if (sc.n_new_distributions > 8 || sc.n_residual_dists > 8) return unsupported("swap menus longer than 8 entries");
+    prm.n_new_dist = sc.n_new_distributions;
+    prm.n_resid_dists = sc.n_residual_dists;
+    bool need_t3 = false, may_chi = false, may_unif = false;
+    for (uint32_t i = 0; i < sc.n_new_distributions; ++i) {
+      prm.new_dist[i] = sc.new_distributions[i];
+      if (sc.new_distributions[i] >= MCP_DIST_UPLOADED_DATA) return unsupported("uploaded-data marginals in the swap menu");
+      if (sc.distribution_change_prob > 0.0 && sc.new_distributions[i] == MCP_DIST_HIGH_KURTOSIS) need_t3 = true;
+    }
+    for (uint32_t j = 0; j < K; ++j)
+      if (spec->var_types[j] == MCP_DIST_HIGH_KURTOSIS) need_t3 = true;
+    auto note_resid = [&](int rd) {
+      if (rd == MCP_RESID_HIGH_KURTOSIS || rd == MCP_RESID_RIGHT_SKEWED || rd == MCP_RESID_LEFT_SKEWED) may_chi = true;
+      if (rd == MCP_RESID_UNIFORM) may_unif = true;
+    };
+    note_resid(spec->residual_dist);
+    for (uint32_t i = 0; i < sc.n_residual_dists; ++i) {
+      prm.resid_dists[i] = sc.residual_dists[i];
+      if (sc.residual_change_prob > 0.0 && spec->residual_dist == MCP_RESID_NORMAL && !spec->residual_pinned)
+        note_resid(sc.residual_dists[i]);
+    }
+    if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS) may_chi = may_unif = false;
+    const double df = sc.residual_df > 3.0 ? sc.residual_df : 3.0;  // data_gen.rs:424
+    prm.resid_df = df;
+    long dfi = std::lround(df);
+    if (dfi < 1) dfi = 1;
+    if (may_chi && dfi > 64) return unsupported("residual df above 64");
+    prm.resid_extra_cols = may_chi ? (uint32_t)dfi + 1u : 0u;
+    prm.resid_may_uniform = may_unif ? 1u : 0u;
+    low.need_t3 = need_t3;
+    prm.het_total = sc.heterogeneity > 0.0 ? sc.heterogeneity : 0.0;
+    low.need_beta_eff = prm.het_total > 1e-30;
+    // heteroskedasticity (data_gen.rs:753-776) with the population moments of spec.rs:436-515
+    const double lambda = sc.heteroskedasticity_ratio > 1.0 ? sc.heteroskedasticity_ratio : 1.0;
+    const double gamma = std::log(lambda) / 4.0;
+    double center = 0.0, sd = 0.0;
+    if (gamma > 1e-30 && spec->outcome_kind == MCP_OUTCOME_CONTINUOUS) {
+      const uint32_t pm = 1 + K + spec->n_factor_dummies;
+      std::vector<double> mu(pm, 0.0), sdv(pm, 0.0);
+      mu[0] = 1.0;
+      for (uint32_t j = 0; j < K; ++j) {
+        if (spec->var_types[j] == MCP_DIST_BINARY) {
+          const double pp = j < spec->n_var_params ? spec->var_params[j] : 0.5;
+          mu[1 + j] = pp;
+          sdv[1 + j] = std::sqrt(std::fmax(pp * (1.0 - pp), 0.0));
+        } else {
+          sdv[1 + j] = 1.0;
+        }
+      }
+      uint32_t c2 = 1 + K, off = 0;
+      for (uint32_t f = 0; f < spec->n_factors; ++f) {
+        const uint32_t nl = (uint32_t)spec->factor_n_levels[f];
+        for (uint32_t d = 0; d + 1 < nl; ++d) {
+          const double pp = spec->factor_proportions[off + d + 1];
+          mu[c2 + d] = pp;
+          sdv[c2 + d] = std::sqrt(std::fmax(pp * (1.0 - pp), 0.0));
+        }
+        c2 += nl - 1;
+        off += nl;
+      }
+      if (spec->heteroskedasticity_driver < 0) {
+        double m = 0.0, v = 0.0;
+        for (uint32_t j = 0; j < pm; ++j) m += spec->effect_sizes[j] * mu[j];
+        for (uint32_t j = 0; j < pm; ++j) v += spec->effect_sizes[j] * spec->effect_sizes[j] * sdv[j] * sdv[j];
+        for (uint32_t j = 0; j < K; ++j)
+          for (uint32_t t = j + 1; t < K; ++t)
+            v += 2.0 * spec->effect_sizes[1 + j] * spec->effect_sizes[1 + t] * spec->correlation[t * K + j] * sdv[1 + j] * sdv[1 + t];
+        center = m;
+        sd = std::sqrt(std::fmax(v, 0.0));
+      } else {
+        center = mu[spec->heteroskedasticity_driver];
+        sd = sdv[spec->heteroskedasticity_driver];
+      }
+    }
+    prm.apply_hsk = (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS && gamma > 1e-30 && sd > 1e-30) ? 1u : 0u;
+    prm.hsk_driver = spec->heteroskedasticity_driver;
+    prm.hsk_gamma = gamma;
+    prm.hsk_center = center;
+    prm.hsk_inv_std = prm.apply_hsk ? 1.0 / sd : 0.0;
+    prm.hsk_inv_norm = std::exp(-gamma * gamma / 2.0);
+  }
 
   const int rc = build_crit_rows(spec->estimator, spec->correction_method, spec->alpha, spec->posthoc_alpha, P, nt, ns,
                                  n_ns, low.crit, err);

@@ -80,6 +80,34 @@ struct SimParams {
   uint32_t truth_start;              // scenario.truth_start (Mle start theta)
   uint32_t _pad_tail;
 
+  // ---- general DGP ("scenario") path: per-replicate design drawn from the scenario stream
+  //      (data_gen.rs:990-1093, scenarios.rs:50-186), non-normal marginals / residuals, per-study
+  //      beta jitter and heteroskedastic residual scaling (data_gen.rs:709-776, 876-888) ----
+  uint32_t scen_active;            // 1: kernels take the general path and read the per-replicate design records
+  uint32_t scen_optimistic;        // scenario.is_optimistic(): records are the spec's own L / types for every replicate
+  uint32_t resid_extra_cols;       // 0, or df_int + 1: CLASS_RESID normal columns 0..df_int are generated
+  uint32_t resid_may_uniform;      // a Uniform residual can occur: the slot-0 uniform is kept next to the normal
+  uint32_t resid_spec_dist;        // spec.residual_dist
+  uint32_t residual_pinned;
+  double resid_df;                 // max(scenario.residual_df, 3)
+  double het_total;                // scenario.heterogeneity (0 = off)
+  uint32_t apply_hsk;
+  int32_t hsk_driver;              // -1 = linear predictor
+  double hsk_gamma, hsk_center, hsk_inv_std, hsk_inv_norm;
+  double corr_noise_sd, dist_change_prob, resid_change_prob;
+  uint32_t n_new_dist, n_resid_dists;
+  int32_t new_dist[8], resid_dists[8];
+  uint32_t var_types[MAX_K];
+  uint32_t var_pinned[MAX_K];
+  double var_params[MAX_K];
+  double corr[MAX_K * MAX_K];      // base correlation, column-major
+  double* scen_L;                  // [K(K+1)/2][scen_stride] row-major lower factor entries per replicate
+  uint32_t* scen_meta;             // [scen_stride]: 4 bits per predictor marginal | residual dist << 28 | status << 31
+  double* scen_beta;               // [P][scen_stride] per-study effects (heterogeneity > 0) or null
+  uint32_t scen_stride;
+  uint32_t _pad_scen;
+  const double* t3_table;          // 2048-knot standardized t(3) PPF table (marginals/t3.rs) or null
+
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;
   uint32_t tile_sims;

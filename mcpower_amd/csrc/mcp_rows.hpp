@@ -5,6 +5,7 @@
 #pragma once
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
+#include "mcp_scenario.hpp"
 
 #pragma clang fp contract(off)
 
@@ -48,15 +49,24 @@ __device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const
 // rows 4*ctr .. 4*ctr+3 of one replicate: standard normals of every column into LDS (data_gen.rs:316-421)
 // OUTCOME: 0 = continuous (normal residual), 1 = binary logit (the residual slot holds the Uniform(0,1) draw,
 // data_gen.rs:390-398)
-template <int P, int STRIDE, int OUTCOME>
-__device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr, float* st) {
+template <int P, int STRIDE, int OUTCOME, bool SCEN = false>
+__device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr, float* st,
+                                            uint32_t scen_meta = 0u) {
   const uint32_t K = prm.K;
   uint32_t pend = 0;
+  float eu[4] = {0.f, 0.f, 0.f, 0.f};  // slot-0 uniforms (Uniform residual, data_gen.rs:485-501)
 #pragma unroll
   for (int j = 0; j < P - 1; ++j)
     if ((uint32_t)j < K) stage_column<STRIDE>(st, (uint32_t)j, planar_words(k0, k1, CLASS_XNORM, (uint32_t)j, ctr), pend);
   if (OUTCOME == 0) {
-    stage_column<STRIDE>(st, K, planar_words(k0, k1, CLASS_RESID, 0u, ctr), pend);
+    const u32x4 w0 = planar_words(k0, k1, CLASS_RESID, 0u, ctr);
+    stage_column<STRIDE>(st, K, w0, pend);
+    if (SCEN) {
+      eu[0] = u32_to_unit_f32(w0.x);
+      eu[1] = u32_to_unit_f32(w0.y);
+      eu[2] = u32_to_unit_f32(w0.z);
+      eu[3] = u32_to_unit_f32(w0.w);
+    }
   } else {
     const u32x4 w = planar_words(k0, k1, CLASS_RESID, 0u, ctr);
     st[(K * 4u + 0u) * STRIDE] = u32_to_unit_f32(w.x);
@@ -72,6 +82,74 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
       st[slot * STRIDE] = icdf_tail(st[slot * STRIDE]);
     }
   }
+  if (SCEN && OUTCOME == 0) {
+    // residual shapes (data_gen.rs:412-501): slot 0 = z; t / chi-square forms add the normals of slots 1..df.
+    // The realized distribution is per replicate (scenario swap), the column count is launch-uniform.
+    const uint32_t rd = (scen_meta >> 28) & 7u;
+    const double df = prm.resid_df;
+    double chi_hk[4] = {0.0, 0.0, 0.0, 0.0}, chi_sk[4] = {0.0, 0.0, 0.0, 0.0};
+    float z0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z0[r] = st[(K * 4u + r) * STRIDE];
+    if (prm.resid_extra_cols) {
+      const uint32_t dfi = prm.resid_extra_cols - 1u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) chi_sk[r] = (double)z0[r] * (double)z0[r];  // skewed forms start at slot 0
+      for (uint32_t s = 1; s <= dfi; ++s) {
+        uint32_t pd = 0;
+        stage_column<STRIDE>(st, K + 1u, planar_words(k0, k1, CLASS_RESID, s, ctr), pd);
+        while (__ballot(pd != 0u) != 0ull) {
+          if (pd != 0u) {
+            const uint32_t slot = (uint32_t)__builtin_ctz(pd);
+            pd &= pd - 1u;
+            st[slot * STRIDE] = icdf_tail(st[slot * STRIDE]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double g = (double)st[((K + 1u) * 4u + r) * STRIDE];
+          chi_hk[r] = chi_hk[r] + g * g;             // HighKurtosis: slots 1..df
+          if (s < dfi) chi_sk[r] = chi_sk[r] + g * g;  // Right/LeftSkewed: slots 0..df-1
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float e = z0[r];
+      if (rd == 1u) {  // HighKurtosis: t(df) standardized
+        const double z = (double)z0[r];
+        const double denom = __builtin_sqrt(chi_hk[r] / df);
+        const double t = denom <= 0.0 ? z : z / denom;
+        e = (float)(t * (1.0 / __builtin_sqrt(df / (df - 2.0))));
+      } else if (rd == 2u || rd == 3u) {  // Right / LeftSkewed: centered scaled chi-square
+        const double sign = rd == 3u ? -1.0 : 1.0;
+        e = (float)(sign * (chi_sk[r] - df) * (1.0 / __builtin_sqrt(2.0 * df)));
+      } else if (rd == 4u) {  // Uniform(-sqrt3, sqrt3)
+        e = (float)((2.0 * (double)eu[r] - 1.0) * SQRT3);
+      }
+      st[(K * 4u + r) * STRIDE] = e;
+    }
+  }
+}
+
+// per-replicate design record of the general ("scenario") path, loaded once per lane
+template <int P>
+struct ScenLane {
+  double Lp[(P - 1) * P / 2 > 0 ? (P - 1) * P / 2 : 1];  // row-major lower factor: idx(j, t) = j(j+1)/2 + t
+  double beta_eff[P];
+  uint32_t meta;  // 4 bits per predictor marginal | residual dist << 28
+};
+
+template <int P>
+__device__ __forceinline__ void scen_lane_load(const SimParams& prm, uint32_t lsim, ScenLane<P>& sl) {
+  const uint32_t K = prm.K;
+  sl.meta = prm.scen_meta[lsim];
+#pragma unroll
+  for (int i = 0; i < (P - 1) * P / 2; ++i)
+    sl.Lp[i] = ((uint32_t)i < K * (K + 1u) / 2u) ? prm.scen_L[(size_t)i * prm.scen_stride + lsim] : 0.0;
+#pragma unroll
+  for (int c = 0; c < P; ++c)
+    sl.beta_eff[c] = prm.scen_beta ? prm.scen_beta[(size_t)c * prm.scen_stride + lsim] : prm.beta[c];
 }
 
 // launch-constant values of the row loop, hoisted into scalar registers once per wave
@@ -103,10 +181,10 @@ __device__ __forceinline__ void row_ctx_init(const SimParams& prm, RowCtx<P>& cx
 }
 
 // one design row + outcome from the staged normals (data_gen.rs:334-363, 509-551, 643-649, 781-857)
-template <int P, bool FACTORS, int STRIDE, int OUTCOME>
+template <int P, bool FACTORS, int STRIDE, int OUTCOME, bool SCEN = false>
 __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
                                           const float* st, int r, uint32_t row, float (&x)[P], float& y,
-                                          double u_re = 0.0) {
+                                          double u_re = 0.0, const ScenLane<P>* sl = nullptr) {
   const uint32_t K = cx.K;
   float z[P - 1];
 #pragma unroll
@@ -133,7 +211,14 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
   for (int c = 1; c < P; ++c) {
     float v = 0.0f;
     if ((uint32_t)(c - 1) < K) {
-      if (cx.ident_L) {
+      if (SCEN) {  // per-replicate factor and marginal (data_gen.rs:334-363)
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < c; ++t) acc = acc + sl->Lp[(c - 1) * c / 2 + t] * (double)z[t];
+        v = (float)acc;
+        const uint32_t vt = (sl->meta >> (4 * (c - 1))) & 15u;
+        if (vt != 0u) v = (float)apply_marginal(vt, (double)v, prm.var_params[c - 1], prm.t3_table);
+      } else if (cx.ident_L) {
         v = z[c - 1];
       } else {  // x_j = f32( sum_{t<=j} L[j][t] * f64(z_t) ), t ascending, separately rounded (data_gen.rs:334-351)
         double acc = 0.0;
@@ -161,6 +246,27 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
 #pragma unroll
   for (int c = 0; c < P; ++c)
     if ((cx.beta_nz >> c) & 1u) lp = lp + (double)x[c] * cx.beta[c];
+  if (SCEN) {
+    const double lp_clean = lp;
+    if (prm.het_total > SCEN_NEAR_ZERO) {  // per-study effects (data_gen.rs:727-751, 785-796)
+      double lpe = 0.0;
+#pragma unroll
+      for (int c = 0; c < P; ++c) lpe = lpe + (double)x[c] * sl->beta_eff[c];
+      lp = lpe;
+    }
+    if (OUTCOME == 0 && prm.apply_hsk) {  // Var(eps_i) = exp(gamma z_i) / exp(gamma^2 / 2) (data_gen.rs:798-809, 876-888)
+      double drv = lp_clean;
+      if (prm.hsk_driver >= 0) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) drv = (c == prm.hsk_driver) ? (double)x[c] : drv;
+      }
+      const double arg = prm.hsk_gamma * ((drv - prm.hsk_center) * prm.hsk_inv_std);
+      const double mult = exp(arg) * prm.hsk_inv_norm;
+      const float es = (float)((double)e * __builtin_sqrt(mult));
+      y = (float)((lp + u_re) + (double)es);
+      return;
+    }
+  }
   if (OUTCOME == 0) {
     y = (float)((lp + (double)e) + u_re);  // u_re = 0.0 without a cluster (data_gen.rs:814-857)
   } else {  // Bernoulli(sigmoid(eta)): 1{u < sigma(eta)} with the pre-drawn uniform (data_gen.rs:890-911)

@@ -261,9 +261,13 @@ __device__ __forceinline__ size_t tile_index(uint32_t P, uint32_t max_n, uint32_
 #endif
 // GRID1: a single sample size (the common find_power call): the grid loop disappears and the sufficient
 // statistics are dead once X'X is formed, which frees their registers for the solve.
-// FACTORS == false: continuous-only design (no factor dummies) -- the factor walk / categorical code is compiled out.
-template <int P, int MODE, bool GRID1, bool FACTORS>
+// FLAVOR 0: continuous-only design (the factor walk / categorical code is compiled out);
+// FLAVOR 1: + factor dummies; FLAVOR 2: general path (per-replicate scenario design, non-normal marginals /
+// residuals, per-study effects, heteroskedastic scaling) on top of FLAVOR 1.
+template <int P, int MODE, bool GRID1, int FLAVOR>
 __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParams* __restrict__ pp) {
+  constexpr bool FACTORS = FLAVOR >= 1;
+  constexpr bool SCEN = FLAVOR == 2;
   extern __shared__ float stage_lds[];
   const SimParams& prm = *pp;
   const uint32_t local = blockIdx.x * BLOCK + threadIdx.x;
@@ -278,16 +282,18 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
   float* tile = prm.tile + threadIdx.x;
   RowCtx<P> cx;
   if (MODE != MODE_FIT) row_ctx_init<P, FACTORS>(prm, cx);
+  ScenLane<P> sl;
+  if (SCEN && MODE != MODE_FIT) scen_lane_load<P>(prm, lsim, sl);
 
   if (MODE == MODE_GENERATE) {
     for (uint32_t ctr = 0; 4u * ctr < max_n; ++ctr) {
-      stage_group<P, BLOCK, 0>(prm, k0, k1, ctr, st);
+      stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const uint32_t rr = 4u * ctr + r;
         if (rr < max_n) {
           float x[P], y;
-          build_row<P, FACTORS, BLOCK, 0>(prm, cx, k0, k1, st, r, rr, x, y);
+          build_row<P, FACTORS, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, 0.0, &sl);
 #pragma unroll
           for (int c = 1; c < P; ++c) tile[tile_index(P, max_n, blockIdx.x, c - 1, rr)] = x[c];
           tile[tile_index(P, max_n, blockIdx.x, P - 1, rr)] = y;
@@ -306,13 +312,13 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
     if (MODE == MODE_FUSED) {
       while (row < n_end) {
         const uint32_t base = row & ~3u;
-        if ((row & 3u) == 0u) stage_group<P, BLOCK, 0>(prm, k0, k1, row >> 2, st);
+        if ((row & 3u) == 0u) stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, row >> 2, st, SCEN ? sl.meta : 0u);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const uint32_t rr = base + (uint32_t)r;
           if (rr >= row && rr < n_end) {
             float x[P], y;
-            build_row<P, FACTORS, BLOCK, 0>(prm, cx, k0, k1, st, r, rr, x, y);
+            build_row<P, FACTORS, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, 0.0, &sl);
             suff_add_row<P>(s, x, y);
           }
         }
@@ -454,39 +460,43 @@ __global__ void icdf_probe_kernel(uint32_t first_word, uint32_t stride, uint32_t
 // ---- launchers (C++ linkage, called from host_api.hip) ----
 namespace mcp {
 
-template <int MODE, bool GRID1, bool FACTORS>
+template <int MODE, bool GRID1, int FLAVOR>
 static hipError_t launch_sim_pgf(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
   const dim3 block(BLOCK), grid((n_sims + BLOCK - 1u) / BLOCK);
-  // staging area: 4 rows x (K + 1 <= P) columns x 256 lanes of f32 (none for the fit-only kernel)
-  const size_t lds = MODE == MODE_FIT ? 0 : (size_t)4 * P * BLOCK * sizeof(float);
+  // staging area: 4 rows x (K + 1 <= P) columns x 256 lanes of f32 (+1 scratch column on the general path;
+  // none for the fit-only kernel)
+  const size_t lds = MODE == MODE_FIT ? 0 : (size_t)4 * (P + (FLAVOR == 2 ? 1 : 0)) * BLOCK * sizeof(float);
   switch (P) {
-    case 2: hipLaunchKernelGGL((ols_sim_kernel<2, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
-    case 3: hipLaunchKernelGGL((ols_sim_kernel<3, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
-    case 4: hipLaunchKernelGGL((ols_sim_kernel<4, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
-    case 5: hipLaunchKernelGGL((ols_sim_kernel<5, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
-    case 6: hipLaunchKernelGGL((ols_sim_kernel<6, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
-    case 7: hipLaunchKernelGGL((ols_sim_kernel<7, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
-    case 8: hipLaunchKernelGGL((ols_sim_kernel<8, MODE, GRID1, FACTORS>), grid, block, lds, st, d_prm); break;
+    case 2: hipLaunchKernelGGL((ols_sim_kernel<2, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
+    case 3: hipLaunchKernelGGL((ols_sim_kernel<3, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
+    case 4: hipLaunchKernelGGL((ols_sim_kernel<4, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
+    case 5: hipLaunchKernelGGL((ols_sim_kernel<5, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
+    case 6: hipLaunchKernelGGL((ols_sim_kernel<6, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
+    case 7: hipLaunchKernelGGL((ols_sim_kernel<7, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
+    case 8: hipLaunchKernelGGL((ols_sim_kernel<8, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 
+// flavor: 0 continuous-only, 1 factors, 2 general (scenario) path -- the general path has no GRID1 specialisation
 template <int MODE>
-static hipError_t launch_sim(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, bool factors, hipStream_t st) {
-  if (MODE == MODE_FIT) factors = false;  // the fit kernel never builds rows
-  if (grid1) return factors ? launch_sim_pgf<MODE, true, true>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, true, false>(P, d_prm, n_sims, st);
-  return factors ? launch_sim_pgf<MODE, false, true>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, false, false>(P, d_prm, n_sims, st);
+static hipError_t launch_sim(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, hipStream_t st) {
+  if (MODE == MODE_FIT) flavor = 0;  // the fit kernel never builds rows
+  if (flavor == 2) return launch_sim_pgf<MODE, false, 2>(P, d_prm, n_sims, st);
+  if (grid1) return flavor ? launch_sim_pgf<MODE, true, 1>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, true, 0>(P, d_prm, n_sims, st);
+  return flavor ? launch_sim_pgf<MODE, false, 1>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, false, 0>(P, d_prm, n_sims, st);
 }
 
-hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, bool factors, hipStream_t st) {
-  return launch_sim<MODE_FUSED>(P, d_prm, n_sims, grid1, factors, st);
+hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, hipStream_t st) {
+  return launch_sim<MODE_FUSED>(P, d_prm, n_sims, grid1, flavor, st);
 }
-hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, bool factors, hipStream_t st) {
-  return launch_sim<MODE_GENERATE>(P, d_prm, n_sims, true, factors, st);
+hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st) {
+  return flavor == 2 ? launch_sim_pgf<MODE_GENERATE, false, 2>(P, d_prm, n_sims, st)
+                     : launch_sim<MODE_GENERATE>(P, d_prm, n_sims, true, flavor, st);
 }
 hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, hipStream_t st) {
-  return launch_sim<MODE_FIT>(P, d_prm, n_sims, grid1, false, st);
+  return launch_sim<MODE_FIT>(P, d_prm, n_sims, grid1, 0, st);
 }
 
 hipError_t launch_ols_fit_provided(int P, const float* design, const float* outcome, uint32_t n_fits, uint32_t n,

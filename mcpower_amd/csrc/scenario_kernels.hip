@@ -1,0 +1,97 @@
+// scenario_kernels.hip -- per-replicate design records of the general data-generating path.
+//
+// One thread per replicate draws the scenario design exactly as populate_design does
+// (crates/engine-core/src/data_gen.rs:990-1093): perturbed correlation (scenarios.rs:67-122) -> PSD repair
+// + Cholesky (correlation.rs:82-190) -> marginal swaps (scenarios.rs:127-157) -> residual swap (:163-186),
+// all on the scenario stream SimRng(base_seed, sim_id ^ 0x5C5C...) (scenarios.rs:50), plus the per-study
+// effects beta_eff on the heterogeneity stream (sim_id ^ 0x4848..., data_gen.rs:727-751).  The records
+// (lower factor, marginal / residual codes, beta_eff) are written replicate-minor so the simulate kernel
+// loads them coalesced.  This is cold, branchy, dynamically indexed code -- a few hundred flops per
+// replicate against ~10^5 in the simulate kernel -- so it lives in its own launch.
+#include <hip/hip_runtime.h>
+#include "mcp_device.hpp"
+#include "mcp_params.hpp"
+#include "mcp_scenario.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mcp {
+
+__global__ __launch_bounds__(256) void scenario_design_kernel(const SimParams* __restrict__ pp) {
+  const SimParams& prm = *pp;
+  const uint32_t lsim = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lsim >= prm.n_sims) return;
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint32_t K = prm.K, P = prm.P;
+  double L[MAX_K * MAX_K];  // column-major
+  uint32_t vt[MAX_K];
+  uint32_t rd = prm.resid_spec_dist;
+  bool ok = true;
+  for (uint32_t j = 0; j < K; ++j) vt[j] = prm.var_types[j];
+  if (prm.scen_optimistic) {
+    for (uint32_t i = 0; i < K * K; ++i) L[i] = prm.corr[i];
+    ok = K == 0 || chol_colmajor(L, K);
+  } else {
+    SeqRng rng;
+    rng.init(prm.base_seed, sim_id ^ STREAM_TAG_SCENARIO);
+    if (prm.corr_noise_sd == 0.0) {
+      for (uint32_t i = 0; i < K * K; ++i) L[i] = prm.corr[i];
+    } else {  // scenarios.rs:67-122
+      double noise[MAX_K * MAX_K];
+      for (uint32_t j = 0; j < K; ++j)
+        for (uint32_t i = 0; i < K; ++i) noise[j * K + i] = (double)rng.next_normal() * prm.corr_noise_sd;
+      for (uint32_t j = 0; j < K; ++j)
+        for (uint32_t i = 0; i < K; ++i) {
+          const double sym = 0.5 * (noise[j * K + i] + noise[i * K + j]);
+          const double v = prm.corr[j * K + i] + sym;
+          L[j * K + i] = v < -0.8 ? -0.8 : (v > 0.8 ? 0.8 : v);
+        }
+      for (uint32_t i = 0; i < K; ++i) L[i * K + i] = 1.0;
+    }
+    ok = K == 0 || psd_repair_and_factor(L, K);
+    if (prm.dist_change_prob > 0.0 && prm.n_new_dist > 0) {  // scenarios.rs:127-157
+      for (uint32_t j = 0; j < K; ++j) {
+        const double u = (double)rng.next_uniform();
+        if (vt[j] == 0u && !prm.var_pinned[j] && u < prm.dist_change_prob) {
+          uint32_t pick = (uint32_t)((double)rng.next_uniform() * (double)prm.n_new_dist);
+          pick = pick > prm.n_new_dist - 1u ? prm.n_new_dist - 1u : pick;
+          vt[j] = (uint32_t)prm.new_dist[pick];
+        }
+      }
+    }
+    if (prm.resid_change_prob > 0.0 && prm.n_resid_dists > 0) {  // scenarios.rs:163-186
+      const double u = (double)rng.next_uniform();
+      if (u < prm.resid_change_prob && prm.resid_spec_dist == 0u && !prm.residual_pinned) {
+        uint32_t pick = (uint32_t)((double)rng.next_uniform() * (double)prm.n_resid_dists);
+        pick = pick > prm.n_resid_dists - 1u ? prm.n_resid_dists - 1u : pick;
+        rd = (uint32_t)prm.resid_dists[pick];
+      }
+    }
+  }
+  uint32_t meta = (rd & 7u) << 28;
+  for (uint32_t j = 0; j < K; ++j) meta |= (vt[j] & 15u) << (4u * j);
+  if (!ok) meta |= 0x80000000u;  // EngineError::CorrelationNotPSD for this replicate
+  prm.scen_meta[lsim] = meta;
+  for (uint32_t j = 0; j < K; ++j)
+    for (uint32_t t = 0; t <= j; ++t) prm.scen_L[(size_t)(j * (j + 1u) / 2u + t) * prm.scen_stride + lsim] = L[t * K + j];
+  if (prm.scen_beta) {  // per-study effects, clipped toward zero, never across it (data_gen.rs:727-751)
+    SeqRng hr;
+    hr.init(prm.base_seed, sim_id ^ STREAM_TAG_HET);
+    const double int_sd = prm.outcome_kind == 0u ? 0.0 : prm.het_total;
+    for (uint32_t j = 0; j < P; ++j) {
+      const double bj = prm.beta[j];
+      const double sj = j == 0 ? int_sd : prm.het_total * __builtin_fabs(bj);
+      const double raw = bj + (double)hr.next_normal() * sj;
+      double be = raw;
+      if (j != 0 && bj != 0.0) be = bj > 0.0 ? (raw > 0.0 ? raw : 0.0) : (raw < 0.0 ? raw : 0.0);
+      prm.scen_beta[(size_t)j * prm.scen_stride + lsim] = be;
+    }
+  }
+}
+
+hipError_t launch_scenario_design(const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  hipLaunchKernelGGL(scenario_design_kernel, dim3((n_sims + 255u) / 256u), dim3(256), 0, st, d_prm);
+  return hipGetLastError();
+}
+
+}  // namespace mcp

@@ -138,3 +138,25 @@ def spec_c4() -> S.SimulationSpec:
 
 USER_SEED = 2137
 BASE_SEED = splitmix64(USER_SEED)  # find_power.rs:259
+
+
+def preset(name: str) -> S.ScenarioPerturbations:
+    """Frozen scenario presets of the reference bench (crates/engine-core/src/bin/throughput.rs:76-132)."""
+    menus = dict(new_distributions=[S.Distribution.RightSkewed, S.Distribution.LeftSkewed, S.Distribution.Uniform],
+                 residual_dists=[S.ResidualDist.HighKurtosis, S.ResidualDist.RightSkewed])
+    if name == "optimistic":
+        return S.ScenarioPerturbations(name=name, residual_df=10.0, truth_start=True, **menus)
+    if name == "realistic":
+        return S.ScenarioPerturbations(name=name, heterogeneity=0.2, heteroskedasticity_ratio=2.0,
+                                       correlation_noise_sd=0.15, distribution_change_prob=0.5,
+                                       residual_change_prob=0.5, residual_df=8.0, sampled_factor_proportions=True,
+                                       **menus)
+    if name == "doomer":
+        return S.ScenarioPerturbations(name=name, heterogeneity=0.4, heteroskedasticity_ratio=4.0,
+                                       correlation_noise_sd=0.3, distribution_change_prob=0.8,
+                                       residual_change_prob=0.8, residual_df=5.0, sampled_factor_proportions=True,
+                                       **menus)
+    raise KeyError(name)
+
+
+C5_GRID = list(range(50, 1001, 50))  # BASELINE C5: N = 50, 100, ..., 1000

@@ -427,3 +427,93 @@ def test_lmm_fixed_size_clusters_and_shards(engine, oracle):
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(spec, [210], 10, BASE_SEED)      # not a multiple of cluster_size
     assert e.value.status == S.Status.Unsupported
+
+
+# ---------------------------------------------------------------------------------------------
+# general data-generating path: scenario presets, non-normal shapes, BASELINE C5
+# ---------------------------------------------------------------------------------------------
+def _design_mismatch(engine, oracle, spec, n, n_sims, seed=BASE_SEED):
+    d, y = engine.generate_design(spec, n, n_sims, seed, 0)
+    bad_x = bad_y = 0
+    worst = 0.0
+    for s in range(n_sims):
+        xo, yo, _ = oracle.generate_sim_data(spec, seed, s, n)
+        mx = d[s].view(np.uint32) != xo.view(np.uint32)
+        my = y[s].view(np.uint32) != yo.view(np.uint32)
+        bad_x += int(mx.sum())
+        bad_y += int(my.sum())
+        if mx.any():
+            worst = max(worst, float(np.max(np.abs(d[s][mx] - xo[mx]) / np.maximum(np.abs(xo[mx]), 1e-30))))
+        if my.any():
+            worst = max(worst, float(np.max(np.abs(y[s][my] - yo[my]) / np.maximum(np.abs(yo[my]), 1e-30))))
+    return bad_x, bad_y, worst, d.size + y.size
+
+
+def test_scenario_design_records_match_oracle_bytes(engine, oracle):
+    """Per-replicate scenario design (perturbed + repaired correlation, marginal / residual swaps, beta jitter,
+    heteroskedastic scaling).  Everything up to the f64 transform plane is the same arithmetic as the oracle;
+    the transcendental kernels differ (ocml vs glibc, both <= 1 ULP), so an f32 value may differ in its last
+    bit when the f64 result sits on a rounding boundary: allow <= 1e-5 of the values to move by one f32 ulp."""
+    from helpers import preset
+    for name in ("realistic", "doomer"):
+        spec = spec_c2b()
+        spec.scenario = preset(name)
+        bx, by, worst, total = _design_mismatch(engine, oracle, spec, 120, 48)
+        assert bx + by <= max(2, total * 1e-5) and worst < 2.5e-7, (name, bx, by, worst)
+
+
+@pytest.mark.parametrize("dist", [S.Distribution.Binary, S.Distribution.RightSkewed, S.Distribution.LeftSkewed,
+                                  S.Distribution.HighKurtosis, S.Distribution.Uniform])
+def test_user_specified_marginals_match_oracle(engine, oracle, dist):
+    spec = base_spec(3)
+    c = np.eye(3)
+    c[0, 1] = c[1, 0] = 0.4
+    spec.correlation = c.flatten().tolist()
+    spec.var_types = [S.Distribution.Normal, dist, dist]
+    spec.var_params = [0.0, 0.3, 0.5]
+    spec.effect_sizes = [0.0, 0.2, 0.3, 0.1]
+    bx, by, worst, total = _design_mismatch(engine, oracle, spec, 101, 16)
+    assert bx + by <= max(2, total * 1e-5) and worst < 2.5e-7, (dist, bx, by, worst)
+
+
+@pytest.mark.parametrize("rd,df", [(S.ResidualDist.HighKurtosis, 5.0), (S.ResidualDist.RightSkewed, 8.0),
+                                   (S.ResidualDist.LeftSkewed, 3.0), (S.ResidualDist.Uniform, 0.0)])
+def test_residual_shapes_match_oracle(engine, oracle, rd, df):
+    spec = spec_c2a()
+    spec.residual_dist = rd
+    spec.residual_pinned = True
+    spec.scenario = S.ScenarioPerturbations(name="custom", residual_df=df)
+    bx, by, worst, total = _design_mismatch(engine, oracle, spec, 64, 16)
+    assert bx == 0 and by <= 2 and worst < 2.5e-7, (rd, bx, by, worst)  # sqrt / div only: f64-exact on both sides
+
+
+def test_scenario_presets_run_batch_matches_oracle(engine, oracle):
+    from helpers import preset
+    for name in ("realistic", "doomer"):
+        spec = spec_c2b()
+        spec.scenario = preset(name)
+        spec.report_overall = True
+        g = engine.run_batch(spec, [50, 200, 500], 3000, BASE_SEED, stat_capture=True)
+        o = oracle.run_batch(spec, [50, 200, 500], 3000, BASE_SEED, stat_capture=True, n_threads=8)
+        a, b = g.stat_capture, o.stat_capture
+        m = ~np.isnan(b)
+        # one-ulp f32 differences in single design values move t^2 by ~1e-7 relative at most
+        assert np.quantile(np.abs(a[m] - b[m]) / np.abs(b[m]), 0.999) < 1e-6
+        assert (g.uncorrected != o.uncorrected).sum() <= 2 and (g.overall != o.overall).sum() <= 2
+        assert np.abs(g.counters.astype(np.int64) - o.counters.astype(np.int64)).max() <= 2
+    # power drops from optimistic to doomer (what the scenarios are for)
+    opt = spec_c2b()
+    p_opt = engine.run_batch(opt, [200], 20000, BASE_SEED, per_sim=False).counter("k_unc", 2)[0, 0]
+    p_doom = g.counter("k_unc", 2)[1, 0] / 3000 * 20000
+    assert p_doom < p_opt
+
+
+def test_c5_grid_sweep_optimistic_matches_oracle(engine, oracle):
+    """BASELINE C5 shape: C2b design on the grid N = 50..1000 (20 points) -- prefix fits on shared draws."""
+    from helpers import C5_GRID
+    spec = spec_c2b()
+    g = engine.run_batch(spec, C5_GRID, 1000, BASE_SEED, stat_capture=True)
+    o = oracle.run_batch(spec, C5_GRID, 1000, BASE_SEED, stat_capture=True, n_threads=8)
+    _assert_batch_equal(g, o)
+    ku = g.counter("k_unc", 2)[:, 0]
+    assert (np.diff(ku.astype(np.int64)) >= -25).all() and ku[-1] > 0.99 * 1000
