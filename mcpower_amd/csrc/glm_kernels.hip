@@ -250,7 +250,9 @@ __global__ __launch_bounds__(256) void fold_flags_kernel(const SimParams* __rest
   const bool lane0 = (threadIdx.x & 63u) == 0u;
   for (uint32_t g = 0; g < prm.n_grid; ++g) {
     const size_t cell = (size_t)row * prm.n_grid + g;
-    unsigned long long* ctr = prm.counters + (size_t)g * prm.ctr_stride;
+    unsigned long long* ctr = prm.counters +
+                            (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % CTR_COPIES) * prm.ctr_copy_stride +
+                            (size_t)g * prm.ctr_stride;
     uint32_t ku = 0, kc = 0;
     for (uint32_t t = 0; t < nt; ++t) {
       const uint32_t u = active ? prm.unc[cell * nt + t] : 0u, c = active ? prm.cor[cell * nt + t] : 0u;
@@ -287,6 +289,22 @@ __global__ __launch_bounds__(256) void fold_flags_kernel(const SimParams* __rest
       if (mb2) atomicAdd(ctr + prm.ctr_boundary_2, (unsigned long long)__popcll(mb2));
     }
   }
+}
+
+// final[i] = sum over copies of counters[copy][i]
+__global__ void reduce_counter_copies_kernel(const unsigned long long* __restrict__ copies, uint32_t copy_stride,
+                                             uint32_t n, unsigned long long* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long s = 0;
+  for (int c = 0; c < CTR_COPIES; ++c) s += copies[(size_t)c * copy_stride + i];
+  out[i] = s;
+}
+
+hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
+                                  unsigned long long* out, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_counter_copies_kernel, dim3((n + 127u) / 128u), dim3(128), 0, st, copies, copy_stride, n, out);
+  return hipGetLastError();
 }
 
 size_t glm_lds_bytes(int P, uint32_t max_n) {

@@ -35,6 +35,8 @@ size_t glm_lds_bytes(int P, uint32_t max_n);
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
                           hipStream_t st);
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
+hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
+                                  unsigned long long* out, hipStream_t st);
 }  // namespace mcp
 
 namespace {
@@ -243,7 +245,10 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(ar.get(S_PRM, sizeof(mcp::SimParams) * n_chunks, (void**)&d_prm));
   DEV_TRY(ar.get(S_CRIT, low.crit.size() * sizeof(double), (void**)&d_crit));
   DEV_TRY(ar.get(S_LEVELS, low.fixed_levels.size(), (void**)&d_levels));
-  DEV_TRY(ar.get(S_COUNTERS, (size_t)n_ns * layout.stride * sizeof(uint64_t), (void**)&d_ctr));
+  const uint32_t n_ctr = n_ns * layout.stride;
+  const uint32_t copy_stride = (n_ctr + 15u) & ~15u;  // whole 128-byte lines per copy
+  const size_t ctr_words = (size_t)copy_stride * (mcp::CTR_COPIES + 1);  // copies, then the reduced vector
+  DEV_TRY(ar.get(S_COUNTERS, ctr_words * sizeof(uint64_t), (void**)&d_ctr));
   if (per_sim || glm) {  // the wave-per-replicate kernels always write flags; a fold kernel counts them
     DEV_TRY(ar.get(S_UNC, cells * nt + 1, (void**)&d_unc));
     DEV_TRY(ar.get(S_COR, cells * nt + 1, (void**)&d_cor));
@@ -281,7 +286,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(hipEventRecord(ev_begin, st));
   DEV_TRY(hipMemcpyAsync(d_crit, low.crit.data(), low.crit.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DEV_TRY(hipMemcpyAsync(d_levels, low.fixed_levels.data(), low.fixed_levels.size(), hipMemcpyHostToDevice, st));
-  DEV_TRY(hipMemsetAsync(d_ctr, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t), st));
+  DEV_TRY(hipMemsetAsync(d_ctr, 0, ctr_words * sizeof(uint64_t), st));
 
   prm.base_seed = base_seed;
   prm.fixed_levels = d_levels;
@@ -292,6 +297,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   prm.ctr_joint_unc = layout.joint_unc; prm.ctr_joint_cor = layout.joint_cor;
   prm.ctr_boundary_1 = layout.boundary_1; prm.ctr_boundary_2 = layout.boundary_2;
   prm.counters = d_ctr;
+  prm.ctr_copy_stride = copy_stride;
   prm.ctr_stride = layout.stride; prm.ctr_k_unc = layout.k_unc; prm.ctr_k_cor = layout.k_cor;
   prm.ctr_conv = layout.converged; prm.ctr_overall = layout.overall; prm.ctr_hist_unc = layout.hist_unc;
   prm.ctr_hist_cor = layout.hist_cor; prm.ctr_n_sims = layout.n_sims;
@@ -354,7 +360,9 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   }
 
   // results
-  DEV_TRY(hipMemcpyAsync(out->counters, d_ctr, (size_t)n_ns * layout.stride * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  unsigned long long* d_ctr_final = d_ctr + (size_t)copy_stride * mcp::CTR_COPIES;
+  DEV_TRY(mcp::launch_reduce_counters(d_ctr, copy_stride, n_ctr, d_ctr_final, st));
+  DEV_TRY(hipMemcpyAsync(out->counters, d_ctr_final, (size_t)n_ctr * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   if (per_sim) {
     out->uncorrected = host_alloc<uint8_t>(cells * nt);
     out->corrected = host_alloc<uint8_t>(cells * nt);
@@ -434,7 +442,8 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   uint8_t* d_levels = nullptr;
   float* d_tile = nullptr;
   const uint32_t n_blocks = (n_sims + 255u) / 256u;
-  const size_t tile_floats = (size_t)n_blocks * 256u * P * max_n;
+  const uint32_t n_quads = (max_n + 3u) >> 2;
+  const size_t tile_floats = (size_t)n_blocks * 256u * P * n_quads * 4u;
   HIP_TRY(ar.get(S_PRM, sizeof(mcp::SimParams), (void**)&d_prm));
   HIP_TRY(ar.get(S_LEVELS, low.fixed_levels.size(), (void**)&d_levels));
   HIP_TRY(ar.get(S_TILE, tile_floats * sizeof(float), (void**)&d_tile));
@@ -466,9 +475,9 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   std::vector<float> tile(tile_floats);
   HIP_TRY(hipMemcpyAsync(tile.data(), d_tile, tile_floats * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  // tile [block][column: x1..x_{P-1}, y][row][256] -> design [sim][column 0..P-1][row], outcome [sim][row]
+  // tile [block][column: x1..x_{P-1}, y][row quad][256][4] -> design [sim][column 0..P-1][row], outcome [sim][row]
   auto at = [&](uint32_t s, uint32_t c, uint32_t i) {
-    return tile[(((size_t)(s / 256u) * P + c) * max_n + i) * 256u + (s % 256u)];
+    return tile[((((size_t)(s / 256u) * P + c) * n_quads + (i >> 2)) * 256u + (s % 256u)) * 4u + (i & 3u)];
   };
   for (uint32_t s = 0; s < n_sims; ++s) {
     float* d = design_out + (size_t)s * P * max_n;

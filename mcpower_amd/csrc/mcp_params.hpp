@@ -16,6 +16,10 @@ constexpr int MAX_GRID = 64;     // sample-size grid points per call
 constexpr int MAX_T = 8;         // tests per fit (marginal targets + contrast pairs)
 constexpr int MAX_FACTORS = 4;
 constexpr int MAX_LEVELS = 16;   // sum of levels over all factors
+// Same-address atomics serialise in L2 at ~90 per microsecond (MI355X_MICROARCH.md, "dequeue"); with one
+// atomic per wave per counter a 10^6-replicate launch would spend ~1.8 ms there.  Spreading the adds over
+// 256 copies, each on its own cache lines, takes that off the critical path; a tiny kernel sums the copies.
+constexpr int CTR_COPIES = 256;
 
 struct SimParams {
   uint64_t base_seed;
@@ -74,7 +78,9 @@ struct SimParams {
   double* stat;                      // [n_sims_total][n_tests] or null
   uint8_t* boundary;                 // [n_sims_total][n_grid] boundary_hit (Mle arm) or null
   uint8_t* joint;                    // [n_sims_total][n_grid] joint Wald chi2 decision (Mle arm) or null
-  unsigned long long* counters;      // [n_grid][ctr_stride]
+  unsigned long long* counters;      // [CTR_COPIES][n_grid][ctr_stride]: replicated, a wave adds into copy (wave id % CTR_COPIES)
+  uint32_t ctr_copy_stride;          // u64 words between copies (a multiple of 16 = 128 B, so copies never share a line)
+  uint32_t _pad_ctr;
   uint32_t ctr_stride, ctr_k_unc, ctr_k_cor, ctr_conv, ctr_overall, ctr_hist_unc, ctr_hist_cor, ctr_n_sims;
   uint32_t ctr_joint_unc, ctr_joint_cor, ctr_boundary_1, ctr_boundary_2;
   uint32_t truth_start;              // scenario.truth_start (Mle start theta)

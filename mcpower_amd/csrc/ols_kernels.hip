@@ -209,7 +209,9 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   }
 
   // ---- additive counters (aggregation.rs:84-284): one atomic per wave per counter ----
-  unsigned long long* ctr = prm.counters + (size_t)g * prm.ctr_stride;
+  unsigned long long* ctr = prm.counters +
+                            (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % CTR_COPIES) * prm.ctr_copy_stride +
+                            (size_t)g * prm.ctr_stride;
   const bool lane0 = (threadIdx.x & 63u) == 0u;
   const uint32_t ub = active ? unc_bits : 0u, cb = active ? cor_bits : 0u;
 #pragma unroll
@@ -247,10 +249,11 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   }
 }
 
-// tile layout of the staged pipeline: [block of 256 replicates][column: x1..x_{P-1}, y][row][256] f32 -- a
-// workgroup's whole design is one contiguous region, and a wave reads/writes 256 B per (column,row)
-__device__ __forceinline__ size_t tile_index(uint32_t P, uint32_t max_n, uint32_t blk, uint32_t c, uint32_t row) {
-  return (((size_t)blk * P + c) * max_n + row) * BLOCK;
+// tile layout of the staged pipeline: [block of 256 replicates][column: x1..x_{P-1}, y][row quad][256 lanes][4 rows]
+// f32 -- a lane owns 16 contiguous bytes per (column, row quad), so generator stores and fit loads are
+// dwordx4 (1 KiB per wave instruction) and a workgroup's whole design is one contiguous region.
+__device__ __forceinline__ size_t tile_quad_index(uint32_t P, uint32_t n_quads, uint32_t blk, uint32_t c, uint32_t quad) {
+  return ((((size_t)blk * P + c) * n_quads + quad) * BLOCK) * 4u;  // + tid * 4 + r
 }
 
 // MODE_FUSED   : generate + accumulate + fit, nothing but flags/counters leaves the chip
@@ -279,26 +282,28 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
   const uint32_t out_row = prm.out_base + lsim;
   const uint32_t max_n = prm.max_n;
   float* st = stage_lds + threadIdx.x;
-  float* tile = prm.tile + threadIdx.x;
   RowCtx<P> cx;
   if (MODE != MODE_FIT) row_ctx_init<P, FACTORS>(prm, cx);
   ScenLane<P> sl;
   if (SCEN && MODE != MODE_FIT) scen_lane_load<P>(prm, lsim, sl);
 
+  const uint32_t n_quads = (max_n + 3u) >> 2;
   if (MODE == MODE_GENERATE) {
-    for (uint32_t ctr = 0; 4u * ctr < max_n; ++ctr) {
+    for (uint32_t ctr = 0; ctr < n_quads; ++ctr) {
       stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
+      float q[P][4];  // [column: x1..x_{P-1}, y][row of the quad]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint32_t rr = 4u * ctr + r;
-        if (rr < max_n) {
-          float x[P], y;
-          build_row<P, FACTORS, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, 0.0, &sl);
+        float x[P], y;
+        build_row<P, FACTORS, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, 4u * ctr + r, x, y, 0.0, &sl);
 #pragma unroll
-          for (int c = 1; c < P; ++c) tile[tile_index(P, max_n, blockIdx.x, c - 1, rr)] = x[c];
-          tile[tile_index(P, max_n, blockIdx.x, P - 1, rr)] = y;
-        }
+        for (int c = 1; c < P; ++c) q[c - 1][r] = x[c];
+        q[P - 1][r] = y;
       }
+#pragma unroll
+      for (int c = 0; c < P; ++c)
+        *reinterpret_cast<float4*>(prm.tile + tile_quad_index(P, n_quads, blockIdx.x, c, ctr) + threadIdx.x * 4u) =
+            make_float4(q[c][0], q[c][1], q[c][2], q[c][3]);
     }
     return;
   }
@@ -325,25 +330,33 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
         const uint32_t nxt = base + 4u;
         row = nxt < n_end ? nxt : n_end;
       }
-    } else {  // MODE_FIT: 4 rows of loads in flight per lane before the first use
-      while (row + 4u <= n_end) {
-        float xb[4][P], yb[4];
+    } else {  // MODE_FIT: dwordx4 loads, lane = replicate; whole row quads take the vector path
+      while (row < n_end) {
+        if ((row & 3u) == 0u && row + 4u <= n_end) {
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          f32x4 v[P];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+          for (int c = 0; c < P; ++c)
+            v[c] = __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4*>(prm.tile + tile_quad_index(P, n_quads, blockIdx.x, c, row >> 2) + threadIdx.x * 4u));
 #pragma unroll
-          for (int c = 1; c < P; ++c) xb[r][c] = __builtin_nontemporal_load(&tile[tile_index(P, max_n, blockIdx.x, c - 1, row + r)]);
-          yb[r] = __builtin_nontemporal_load(&tile[tile_index(P, max_n, blockIdx.x, P - 1, row + r)]);
+          for (int r = 0; r < 4; ++r) {
+            float x[P];
+#pragma unroll
+            for (int c = 1; c < P; ++c) x[c] = r == 0 ? v[c - 1].x : (r == 1 ? v[c - 1].y : (r == 2 ? v[c - 1].z : v[c - 1].w));
+            const float y = r == 0 ? v[P - 1].x : (r == 1 ? v[P - 1].y : (r == 2 ? v[P - 1].z : v[P - 1].w));
+            suff_add_row<P>(s, x, y);
+          }
+          row += 4u;
+        } else {  // ragged grid boundary: one row
+          float x[P];
+#pragma unroll
+          for (int c = 1; c < P; ++c)
+            x[c] = prm.tile[tile_quad_index(P, n_quads, blockIdx.x, c - 1, row >> 2) + threadIdx.x * 4u + (row & 3u)];
+          const float y = prm.tile[tile_quad_index(P, n_quads, blockIdx.x, P - 1, row >> 2) + threadIdx.x * 4u + (row & 3u)];
+          suff_add_row<P>(s, x, y);
+          row += 1u;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) suff_add_row<P>(s, xb[r], yb[r]);
-        row += 4u;
-      }
-      for (; row < n_end; ++row) {
-        float x[P], y;
-#pragma unroll
-        for (int c = 1; c < P; ++c) x[c] = tile[tile_index(P, max_n, blockIdx.x, c - 1, row)];
-        y = tile[tile_index(P, max_n, blockIdx.x, P - 1, row)];
-        suff_add_row<P>(s, x, y);
       }
     }
     fit_decide<P>(prm, s, g, n_end, active, out_row);
