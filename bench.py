@@ -50,6 +50,29 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(workload, kernel_tag):
+    """HBM bytes per launch of `kernel_tag` from the newest committed rocprofv3 PMC summary (profiles/*_pmc.csv,
+    collected in separate --pmc passes by tools/profile_bench.sh).  gfx950 correction from
+    /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE (KiB) reports exactly half of a wide coalesced streaming
+    read, so reads = 2 x FETCH_SIZE x 1024; WRITE_SIZE (KiB) is exact for 16-B-per-lane stores."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc.csv")))
+    if not files:
+        return None
+    fetch = write = None
+    for r in csv.DictReader(open(files[-1])):
+        if kernel_tag in r["kernel"]:
+            if r["counter"] == "FETCH_SIZE":
+                fetch = float(r["mean_per_dispatch"])
+            if r["counter"] == "WRITE_SIZE":
+                write = float(r["mean_per_dispatch"])
+    if fetch is None or write is None:
+        return None
+    return {"bytes_per_launch": 2.0 * fetch * 1024.0 + write * 1024.0, "read_bytes": 2.0 * fetch * 1024.0,
+            "write_bytes": write * 1024.0, "source": os.path.basename(files[-1])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +171,9 @@ def main():
             ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "valu", "kernel": (f"ols_sim_kernel<{spec.n_predictors},fused>" if is_ols else f"{'glm' if args.workload == 'c3' else 'lmm'}_sim_kernel<{spec.n_predictors}>"),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
-                               "traffic": None, "ops_per_fit": ops_per_fit, "avg_launch_ms": avg_launch_ms,
+                               "traffic": (pmc_traffic(args.workload, f"ols_sim_kernel<{spec.n_predictors}, 0,")
+                                           if (is_ols and not is_c5 and S == 1_000_000) else None),
+                               "ops_per_fit": ops_per_fit, "avg_launch_ms": avg_launch_ms,
                                "fits_per_launch": fits_per_launch,
                                "note": "fused generate+fit: no design bytes touch HBM; bound is VALU/integer issue "
                                        "(SURVEY.md 8d); HBM-equivalent rate in hbm_equiv_gbs",
@@ -160,9 +185,11 @@ def main():
             fit_ms = rs.kernel_ms / rs.n_kernel_launches
             fpl = S / rs.n_kernel_launches
             gbs = bytes_per_fit * fpl / (fit_ms * 1e-3) / 1e9
+            tr = pmc_traffic(args.workload, f"ols_sim_kernel<{spec.n_predictors}, 2,") if S == 1_000_000 else None
             out["roofline_staged_fit"] = {"bound": "hbm", "kernel": f"ols_sim_kernel<{spec.n_predictors},fit>",
                                           "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                          "frac": gbs / PEAK_HBM_GBS, "traffic": None, "bytes_per_fit": bytes_per_fit,
+                                          "frac": gbs / PEAK_HBM_GBS, "traffic": tr, "bytes_per_fit": bytes_per_fit,
+                                          "algorithmic_bytes_per_launch": bytes_per_fit * fpl,
                                           "avg_launch_ms": fit_ms, "generator_launch_ms": rs.aux_kernel_ms / rs.n_kernel_launches,
                                           "fits_per_launch": fpl}
         if staged:
