@@ -205,7 +205,7 @@ def main():
             t1 = time.perf_counter()
             oracle.run_batch(spec, ns, 50_000, helpers.BASE_SEED, n_threads=cores)
             rate = 50_000 / (time.perf_counter() - t1)
-            sample = int(min(max(rate * args.cpu_seconds, 50_000), 4_000_000))
+            sample = int(min(max(rate * args.cpu_seconds, 50_000), 40_000_000))
             t1 = time.perf_counter()
             o = oracle.run_batch(spec, ns, sample, helpers.BASE_SEED, n_threads=cores)
             dt = time.perf_counter() - t1

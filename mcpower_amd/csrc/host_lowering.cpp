@@ -191,7 +191,30 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (spec->n_between_var_indices) return unsupported("cluster-level (between) predictors");
   if (spec->n_posthoc) return unsupported("post-hoc contrasts");
   if (spec->n_fit_columns && spec->n_fit_columns < P) return unsupported("reduced test design (fit_columns)");
-  if (spec->n_factors && spec->factor_min_level_count > 0) return unsupported("sparse-factor exclusion");
+  // sparse-factor exclusion (batch.rs:903-915, 2451-2496) is decided per (replicate, N) from level counts.  With
+  // the deterministic allocation walk the counts are the same for every replicate, so the host can prove that
+  // no factor is ever excluded on this grid -- then the run is identical to factor_min_level_count = 0.
+  if (spec->n_factors && spec->factor_min_level_count > 0) {
+    std::vector<uint32_t> counts(spec->n_factor_proportions, 0u);
+    std::vector<uint32_t> off(spec->n_factors, 0u);
+    for (uint32_t f = 0, o = 0; f < spec->n_factors; ++f) { off[f] = o; o += (uint32_t)spec->factor_n_levels[f]; }
+    for (uint32_t f = 0; f < spec->n_factors; ++f) {
+      int sampled = spec->scenario.sampled_factor_proportions;
+      if (f < spec->n_factor_sampled && spec->factor_sampled[f] >= 0) sampled = spec->factor_sampled[f];
+      if (sampled) return unsupported("sparse-factor exclusion with sampled factor proportions (per-replicate reduced fits)");
+    }
+    uint32_t g = 0;
+    for (uint32_t i = 0; i < max_n && g < n_ns; ++i) {
+      for (uint32_t f = 0; f < spec->n_factors; ++f)
+        fixed_level_next(spec->factor_proportions + off[f], counts.data() + off[f], (uint32_t)spec->factor_n_levels[f]);
+      while (g < n_ns && i + 1 == ns[g]) {
+        for (uint32_t c = 0; c < spec->n_factor_proportions; ++c)
+          if (counts[c] < spec->factor_min_level_count)
+            return unsupported("sparse-factor exclusion fires on this grid (a level has fewer than factor_min_level_count rows at N = " + std::to_string(ns[g]) + ")");
+        ++g;
+      }
+    }
+  }
   if (spec->heteroskedasticity_driver >= (int32_t)(1 + K + spec->n_factor_dummies)) {
     err = "invalid spec: heteroskedasticity_driver out of range";
     return MCP_ERR_INVALID_SPEC;

@@ -96,7 +96,25 @@ static int validate(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns) {
   }
   if (!mcpo_spec_supported(spec) || p > MCPO_MAX_P) { mcpo_set_error("unsupported: uploads / bootstrap / slopes / extra groupings"); return MCP_ERR_UNSUPPORTED; }
   if (spec->n_fit_columns && spec->n_fit_columns < p) { mcpo_set_error("unsupported: fit_columns reduced fit"); return MCP_ERR_UNSUPPORTED; }
-  if (spec->n_factors && spec->factor_min_level_count > 0) { mcpo_set_error("unsupported: sparse-factor exclusion"); return MCP_ERR_UNSUPPORTED; }
+  if (spec->n_factors && spec->factor_min_level_count > 0) {
+    /* supported only when the deterministic allocation walk proves that no level is ever sparse on this grid */
+    uint32_t counts[MCPO_MAX_LEVELS] = {0}, g = 0, offs[16] = {0};
+    if (spec->n_factor_proportions > MCPO_MAX_LEVELS || spec->n_factors > 16) { mcpo_set_error("unsupported: too many factor levels"); return MCP_ERR_UNSUPPORTED; }
+    for (uint32_t f = 0, o = 0; f < spec->n_factors; ++f) { offs[f] = o; o += (uint32_t)spec->factor_n_levels[f]; }
+    for (uint32_t f = 0; f < spec->n_factors; ++f) {
+      int sampled = spec->scenario.sampled_factor_proportions;
+      if (f < spec->n_factor_sampled && spec->factor_sampled[f] >= 0) sampled = spec->factor_sampled[f];
+      if (sampled) { mcpo_set_error("unsupported: sparse-factor exclusion with sampled proportions"); return MCP_ERR_UNSUPPORTED; }
+    }
+    for (uint32_t i = 0; i < ns[n_ns - 1] && g < n_ns; ++i) {
+      for (uint32_t f = 0; f < spec->n_factors; ++f) mcpo_fixed_level_next(spec->factor_proportions + offs[f], counts + offs[f], (uint32_t)spec->factor_n_levels[f]);
+      while (g < n_ns && i + 1 == ns[g]) {
+        for (uint32_t c = 0; c < spec->n_factor_proportions; ++c)
+          if (counts[c] < spec->factor_min_level_count) { mcpo_set_error("unsupported: sparse-factor exclusion fires on this grid"); return MCP_ERR_UNSUPPORTED; }
+        ++g;
+      }
+    }
+  }
   if (spec->correction_method == MCP_CORR_TUKEY_HSD) { mcpo_set_error("unsupported: Tukey HSD thresholds"); return MCP_ERR_UNSUPPORTED; }
   return MCP_OK;
 }

@@ -165,8 +165,13 @@ static int psd_repair_and_factor(double* m, uint32_t k) {
   return mcpo_chol_colmajor(m, k);
 }
 
-/* data_gen.rs:943-961 */
+uint32_t mcpo_fixed_level_next(const double* probs, uint32_t* counts, uint32_t n_levels);
 static uint32_t fixed_level_next(const double* probs, uint32_t* counts, uint32_t n_levels) {
+  return mcpo_fixed_level_next(probs, counts, n_levels);
+}
+
+/* data_gen.rs:943-961 */
+uint32_t mcpo_fixed_level_next(const double* probs, uint32_t* counts, uint32_t n_levels) {
   double total = 0.0;
   uint32_t assigned = 0;
   for (uint32_t g = 0; g < n_levels; ++g) {

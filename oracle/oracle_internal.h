@@ -53,5 +53,6 @@ void mcpo_fit_suff(const mcpo_suff* s, mcpo_olsfit_t* fit);
 /* squared statistic of c'beta; NaN when not well formed (posthoc.rs:86-99) */
 double mcpo_contrast_t_sq(const mcpo_olsfit_t* fit, const double* c);
 
+uint32_t mcpo_fixed_level_next(const double* probs, uint32_t* counts, uint32_t n_levels);
 void mcpo_set_error(const char* fmt, ...);
 #endif

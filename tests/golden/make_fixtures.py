@@ -242,6 +242,18 @@ def make_cases():
 # quantile known answers restated from crates/engine-core/src/critvals.rs tests (:1807-1926) are checked
 # against scipy in tests/test_oracle_critvals.py; the per-case `crit` goldens above pin t_ppf/norm_ppf to R.
 
+def make_contracts():
+    """The msgpack `Vec<SimulationContract>` blobs the reference's own port tests hold
+    (ports/r/tests/testthat/_golden, written by its gen_golden.py / gen_two_factor_golden.py):
+    copied byte for byte as the input fixtures of the `_engine.find_power` shim tests."""
+    os.makedirs(f"{HERE}/contracts", exist_ok=True)
+    for name in ("ols_contract", "two_factor_accumulation_contract"):
+        blob = open(f"{REF}/ports/r/tests/testthat/_golden/{name}.msgpack", "rb").read()
+        with open(f"{HERE}/contracts/{name}.msgpack", "wb") as f:
+            f.write(blob)
+
+
 if __name__ == "__main__":
     make_rng_kat()
     make_cases()
+    make_contracts()
