@@ -371,3 +371,458 @@ def find_power(contracts_bytes: bytes, sample_size: int, n_sims: int, base_seed:
         pr["grid_warnings"].extend(factor_preflight_warnings(spec, sample_size))
         out[sc["label"]] = power_result_to_host(pr, sc["label"])
     return {"scenarios": out, "comparison": {}}
+
+
+# ---------------------------------------------------------------------------------------------
+# grid.rs / fit.rs / find_sample_size.rs
+# ---------------------------------------------------------------------------------------------
+MIN_ROWS_PER_CLUSTER = 2          # configs/config.json limits.min_rows_per_cluster
+Z_GATE = 2.0                      # fit.rs:27
+MIN_HINT_POWER = 0.5              # fit.rs:33
+EXTRAPOLATION_CAP = 2.0           # fit.rs:38
+MAX_GRID_PER_CALL = 64            # device limit of one run_batch call (mcp_params.hpp MAX_GRID)
+
+
+def _ceil_to(x: int, a: int) -> int:
+    a = max(a, 1)
+    return -(-x // a) * a
+
+
+def _floor_to(x: int, a: int) -> int:
+    a = max(a, 1)
+    return (x // a) * a
+
+
+def _round_to(x: int, a: int) -> int:
+    a = max(a, 1)
+    return ((x + a // 2) // a) * a
+
+
+def _rust_round(v: float) -> int:
+    """f64::round: half away from zero (Python's round() is half-to-even)."""
+    return int(math.floor(v + 0.5)) if v >= 0 else -int(math.floor(-v + 0.5))
+
+
+def build_grid(from_req: int, to_req: int, by: Tuple[str, int], mode: str, atom: int, hard_min: int):
+    """`build_grid` (grid.rs:37-156). `by` = ("fixed", step) | ("auto", count); mode "linear" | "log".
+    -> (grid, warnings)."""
+    if atom == 0:
+        raise OrchestratorError("InvalidClusterAtom", "invalid cluster atom: atom must be >= 1")
+    if from_req < 1 or to_req < from_req:
+        raise OrchestratorError("InvalidGridBounds", f"invalid grid bounds: from={from_req}, to={to_req}")
+    warnings: List[str] = []
+    snapped_from = max(_ceil_to(from_req, atom), _ceil_to(hard_min, atom))
+    snapped_to = _floor_to(to_req, atom)
+    if snapped_from > from_req:
+        warnings.append(f"raised `from` from {from_req} to {snapped_from} so each cluster keeps enough rows (atom={atom})")
+    if snapped_to < to_req:
+        warnings.append(f"lowered `to` from {to_req} to {snapped_to} (nearest multiple of the cluster atom {atom})")
+    if snapped_to < snapped_from:
+        raise OrchestratorError(
+            "ClusterGridEmpty",
+            f"after cluster snapping the [{snapped_from},{snapped_to}] range is empty (atom={atom}); "
+            f"widen bounds or reduce n_clusters/cluster_size")
+    max_feasible = (snapped_to - snapped_from) // atom + 1
+    if max_feasible < 2:
+        raise OrchestratorError(
+            "ClusterGridSinglePoint",
+            f"range admits one sample size (snapped [{snapped_from},{snapped_to}], atom={atom}); nothing to search")
+    if max_feasible < 4:
+        warnings.append(f"only {max_feasible} grid points after cluster snapping; required-N (and model-based "
+                        f"crossing) will be coarse")
+    kind, value = by
+    if mode == "linear":
+        if kind == "fixed":
+            step = max(_ceil_to(value, atom), atom)
+        else:
+            c = min(max(value, 2), max_feasible)
+            span = snapped_to - snapped_from
+            denom = atom * (c - 1)
+            step = atom * max((span + denom // 2) // denom, 1)
+        grid = list(range(snapped_from, snapped_to + 1, step))
+        if grid[-1] != snapped_to:
+            grid.append(snapped_to)
+    else:
+        c = min(max(value, 2), max_feasible)
+        lo, hi = math.log10(snapped_from), math.log10(snapped_to)
+        raw = []
+        for i in range(c):
+            t = i / (c - 1)
+            v = _rust_round(10.0 ** (lo + t * (hi - lo)))
+            raw.append(min(max(_round_to(v, atom), snapped_from), snapped_to))
+        raw[0], raw[-1] = snapped_from, snapped_to
+        grid = sorted(set(raw))
+    return grid, warnings
+
+
+def as_proportion(p: float) -> float:
+    return p / 100.0 if p > 1.0 else p
+
+
+def pava(y: Sequence[float]) -> List[float]:
+    """Pool-adjacent-violators, unweighted; only strict decreases pool (fit.rs:135-155)."""
+    means: List[float] = []
+    lens: List[int] = []
+    for v in y:
+        means.append(float(v))
+        lens.append(1)
+        while len(means) >= 2 and means[-2] > means[-1]:
+            m1, l1 = means.pop(), lens.pop()
+            l0 = lens[-1]
+            means[-1] = (means[-1] * l0 + m1 * l1) / (l0 + l1)
+            lens[-1] = l0 + l1
+    out: List[float] = []
+    for m, l in zip(means, lens):
+        out.extend([m] * l)
+    return out
+
+
+def _crossing(grid, fitted, target) -> Optional[float]:
+    if fitted[0] >= target:
+        return float(grid[0])
+    for i in range(1, len(fitted)):
+        if fitted[i] >= target:
+            x0, x1 = float(grid[i - 1]), float(grid[i])
+            y0, y1 = fitted[i - 1], fitted[i]
+            return x0 + (target - y0) * (x1 - x0) / (y1 - y0)
+    return None
+
+
+def _ceil_to_atom(n: float, atom: int) -> int:
+    a = max(atom, 1)
+    n_int = int(max(math.ceil(n - 1e-9), 1.0))
+    return -(-n_int // a) * a
+
+
+def _norm_ppf(p: float) -> float:
+    from . import engine
+
+    return engine.norm_ppf(p)
+
+
+def _probit_hint(grid, p_hat, fitted, n_sims: float, target: float, atom: int) -> Optional[int]:
+    """`probit_hint` (fit.rs:196-247): WLS of probit(p) on sqrt(N), delta-method weights."""
+    if fitted[-1] < MIN_HINT_POWER:
+        return None
+    clamp_lo, clamp_hi = 0.5 / n_sims, 1.0 - 0.5 / n_sims
+    sw = swx = swy = swxx = swxy = 0.0
+    for n, ph in zip(grid, p_hat):
+        p = min(max(ph, clamp_lo), clamp_hi)
+        z = _norm_ppf(p)
+        pdf = math.exp(-0.5 * z * z) / math.sqrt(2.0 * math.pi)
+        w = n_sims * pdf * pdf / (p * (1.0 - p))
+        x = math.sqrt(float(n))
+        sw += w
+        swx += w * x
+        swy += w * z
+        swxx += w * x * x
+        swxy += w * x * z
+    denom = sw * swxx - swx * swx
+    if not math.isfinite(denom) or denom <= 0.0:
+        return None
+    slope = (sw * swxy - swx * swy) / denom
+    if not math.isfinite(slope) or slope <= 0.0:
+        return None
+    intercept = (swy - slope * swx) / sw
+    sqrt_n = (_norm_ppf(target) - intercept) / slope
+    if not math.isfinite(sqrt_n) or sqrt_n <= 0.0:
+        return None
+    n_cross = sqrt_n * sqrt_n
+    if n_cross > EXTRAPOLATION_CAP * float(grid[-1]):
+        return None
+    return _ceil_to_atom(n_cross, atom)
+
+
+def fit_crossing(grid: Sequence[int], counts: Sequence[int], n_sims: int, target_power: float, atom: int) -> dict:
+    """`fit_crossing` (fit.rs:46-111) -> the status-tagged map of `crossing_fit_to_host`
+    (result_host.rs:296-322)."""
+    if n_sims == 0 or len(grid) == 0:
+        return {"status": "not_reached", "n_approx": None}
+    target = as_proportion(target_power)
+    n_f = float(n_sims)
+    p_hat = [k / n_f for k in counts]
+    # monotonicity gate (fit.rs:116-131)
+    max_drop, pair = 0.0, None
+    for i in range(len(p_hat)):
+        for j in range(i + 1, len(p_hat)):
+            d = p_hat[i] - p_hat[j]
+            if d > max_drop:
+                max_drop, pair = d, (p_hat[i], p_hat[j])
+    if pair is not None:
+        pi, pj = pair
+        se = math.sqrt((pi * (1.0 - pi) + pj * (1.0 - pj)) / n_f)
+        if max_drop > Z_GATE * se:
+            return {"status": "non_monotone", "max_violation": max_drop}
+    fitted = pava(p_hat)
+    if fitted[0] >= target:
+        return {"status": "at_or_below_min", "n_min": int(grid[0])}
+    if fitted[-1] < target:
+        return {"status": "not_reached", "n_approx": _probit_hint(grid, p_hat, fitted, n_f, target, atom)}
+    n_star = _crossing(grid, fitted, target)
+    hi_band = pava([wilson_ci(k, n_sims)[1] for k in counts])
+    lo_band = pava([wilson_ci(k, n_sims)[0] for k in counts])
+    ci_lo = None if hi_band[0] >= target else _crossing(grid, hi_band, target)
+    ci_hi = _crossing(grid, lo_band, target)
+    return {"status": "fitted", "n_star": n_star, "n_achievable": _ceil_to_atom(n_star, atom), "ci_lo": ci_lo,
+            "ci_hi": ci_hi}
+
+
+def first_n_at_target(powers_corrected, sample_sizes, target_power: float, target_index: int) -> Optional[int]:
+    p_target = as_proportion(target_power)
+    for row, n in zip(powers_corrected, sample_sizes):
+        if row[target_index] >= p_target:
+            return int(n)
+    return None
+
+
+def first_n_joint_at_target(histograms, n_sims: int, sample_sizes, target_power: float, k: int) -> Optional[int]:
+    if n_sims == 0:
+        return None
+    p_target = as_proportion(target_power)
+    for hist, n in zip(histograms, sample_sizes):
+        if sum(hist[k:]) / n_sims >= p_target:
+            return int(n)
+    return None
+
+
+def derive_sample_size_outputs(per_n: Sequence[dict], sample_sizes: Sequence[int], target_power: float, atom: int) -> dict:
+    """`derive_sample_size_outputs` (grid.rs:232-330)."""
+    powers = [pr["power_corrected"] for pr in per_n]
+    n_targets = len(per_n[0]["power_corrected"]) if per_n else 0
+    n_sims = per_n[0]["n_sims"] if per_n else 0
+    first_achieved = [first_n_at_target(powers, sample_sizes, target_power, t) for t in range(n_targets)]
+    fitted = [fit_crossing(sample_sizes, [pr["success_counts_corrected"][t] for pr in per_n], n_sims, target_power, atom)
+              for t in range(n_targets)]
+    hists = [pr["success_count_histogram_corrected"] for pr in per_n]
+    joint_n_sims = sum(hists[0]) if hists else 0
+    n_joint = max(len(hists[0]) - 1, 0) if hists else 0
+    first_joint = [first_n_joint_at_target(hists, joint_n_sims, sample_sizes, target_power, k)
+                   for k in range(1, n_joint + 1)]
+    fitted_joint = [fit_crossing(sample_sizes, [sum(h[k:]) for h in hists], joint_n_sims, target_power, atom)
+                    for k in range(1, n_joint + 1)]
+    first_overall, fitted_overall = None, None
+    if per_n and per_n[0]["overall_significant_rate"] is not None:
+        p_target = as_proportion(target_power)
+        first_overall = next((int(n) for n, pr in zip(sample_sizes, per_n)
+                              if (pr["overall_significant_rate"] or 0.0) >= p_target), None)
+        fitted_overall = fit_crossing(sample_sizes, [pr["overall_significant_count"] for pr in per_n], n_sims,
+                                      target_power, atom)
+    return dict(first_achieved=first_achieved, first_joint_achieved=first_joint, fitted=fitted,
+                fitted_joint=fitted_joint, first_overall_achieved=first_overall, fitted_overall=fitted_overall)
+
+
+def min_inclusion_n(probs: Sequence[float], k_min: int, n_max: int) -> Optional[int]:
+    """`min_inclusion_n` (data_gen.rs:977-986)."""
+    total = 0.0
+    for p in probs:
+        total += p
+    counts = [0] * len(probs)
+    for n in range(1, n_max + 1):
+        t = float(n)
+        best, best_deficit = 0, -math.inf
+        for g, p in enumerate(probs):
+            deficit = (p / total) * t - counts[g]
+            if deficit > best_deficit:
+                best_deficit, best = deficit, g
+        counts[best] += 1
+        if all(c >= k_min for c in counts):
+            return n
+    return None
+
+
+def factor_preflight_sample_size(spec: S.SimulationSpec, grid: Sequence[int]) -> List[str]:
+    """`factor_preflight_sample_size` (find_power.rs:127-178)."""
+    k_min = spec.factor_min_level_count
+    if not grid or k_min == 0 or len(spec.upload_data) > 0:
+        return []
+    lo, hi = grid[0], grid[-1]
+    out, off = [], 0
+    for f, nl in enumerate(spec.factor_n_levels):
+        l = max(int(nl), 0)
+        sampled = spec.factor_sampled[f] if f < len(spec.factor_sampled) else None
+        if sampled is None:
+            sampled = spec.scenario.sampled_factor_proportions
+        if not sampled:
+            probs = spec.factor_proportions[off:off + l]
+            if any(c < k_min for c in fixed_allocation_counts(probs, lo)):
+                n_inc = min_inclusion_n(probs, k_min, hi)
+                if n_inc is not None:
+                    out.append(f"factor {f + 1}: levels reach the {k_min}-observation minimum only at N >= {n_inc}; "
+                               f"grid points below that exclude the factor and report power 0 for its effects")
+                else:
+                    out.append(f"factor {f + 1}: a level stays under the {k_min}-observation minimum across the whole "
+                               f"[{lo}, {hi}] range; the factor is excluded everywhere and its effects report power 0")
+        off += l
+    return out
+
+
+def resolve_cluster_grid_params(contracts: Sequence[dict]) -> Tuple[int, int, List[str]]:
+    """`resolve_cluster_grid_params` (find_sample_size.rs:18-69) -> (atom, hard_min, warnings)."""
+    cluster = None
+    for c in contracts:
+        cl = c["generation"].get("cluster")
+        if cl is not None:
+            if cluster is None:
+                cluster = cl
+            else:
+                a, b = K.cluster_atom({"generation": {"cluster": cluster}}), K.cluster_atom({"generation": {"cluster": cl}})
+                if a != b:
+                    raise OrchestratorError(
+                        "MixedClusterAtoms",
+                        f"scenarios in this call disagree on the cluster atom ({a} vs {b}); a single shared grid "
+                        f"cannot be a multiple of every atom")
+    if cluster is None:
+        return 1, 1, []
+    atom = K.cluster_atom({"generation": {"cluster": cluster}})
+    skind, sbody = K._variant(cluster["sizing"])
+    warnings = []
+    if skind == "FixedClusters":
+        n = max(int(sbody["n_clusters"]), 1)
+        if n < MIN_CLUSTERS:
+            warnings.append(f"only {n} clusters (< {MIN_CLUSTERS}); τ² estimates may be unstable")
+        return atom, n * MIN_ROWS_PER_CLUSTER, warnings
+    cs = int(sbody["cluster_size"])
+    if cs < MIN_ROWS_PER_CLUSTER:
+        raise OrchestratorError(
+            "ClusterSizeTooSmall",
+            f"FixedSize cluster regime needs cluster_size >= {MIN_ROWS_PER_CLUSTER} (no within-cluster information "
+            f"below that); got {cs}")
+    return atom, MIN_CLUSTERS * cs, warnings
+
+
+def sample_size_method_from_host_args(method: str, by: Optional[int], by_kind: Optional[str], mode: Optional[str]):
+    """`SampleSizeMethod::from_host_args` (result.rs:552-575); errors are ValueError like the PyO3 shell."""
+    if method != "grid":
+        raise ValueError(f'unknown method "{method}"')
+    if by is None:
+        raise ValueError("grid method requires `by`")
+    kind = "fixed" if by_kind is None else by_kind
+    if kind not in ("fixed", "auto"):
+        raise ValueError(f'unknown by_kind "{kind}"')
+    m = "linear" if mode is None else mode
+    if m not in ("linear", "log"):
+        raise ValueError(f'unknown mode "{m}"')
+    return (kind, int(by)), m
+
+
+def sample_size_result_to_host(ssr: dict, label: str) -> dict:
+    """`sample_size_result_to_host` (result_host.rs:150-293), Python rendering of each leaf."""
+    grid = ssr["grid_or_trace"]
+    first = grid[0] if grid else None
+    rows = len(first["boundary_hit"]) if first else 0
+    bh = [[pr["boundary_hit"][sim] for pr in grid] for sim in range(rows)]
+    fitted_overall = [] if ssr["fitted_overall"] is None else [ssr["fitted_overall"]]
+    return {
+        "n_sims": first["n_sims"] if first else 0,
+        "n_sample_sizes": len(grid),
+        "n_targets": len(first["target_indices"]) if first else 0,
+        "target_indices": list(first["target_indices"]) if first else [],
+        "contrast_pairs": [[p, n] for p, n in first["contrast_pairs"]] if first else [],
+        "power_uncorrected": [list(pr["power_uncorrected"]) for pr in grid],
+        "power_corrected": [list(pr["power_corrected"]) for pr in grid],
+        "ci_uncorrected": [list(pr["ci_uncorrected"]) for pr in grid],
+        "ci_corrected": [list(pr["ci_corrected"]) for pr in grid],
+        "convergence_rate": [pr["convergence_rate"] for pr in grid],
+        "sample_sizes": [pr["n"] for pr in grid],
+        "first_achieved": dict(enumerate(ssr["first_achieved"])),
+        "success_count_histogram_uncorrected": [list(pr["success_count_histogram_uncorrected"]) for pr in grid],
+        "success_count_histogram_corrected": [list(pr["success_count_histogram_corrected"]) for pr in grid],
+        "grid_warnings": list(ssr["grid_warnings"]),
+        "factor_exclusion_counts": [list(pr["factor_exclusion_counts"]) for pr in grid],
+        "factor_separation_counts": [list(pr["factor_separation_counts"]) for pr in grid],
+        "first_joint_achieved": dict(enumerate(ssr["first_joint_achieved"])),
+        "first_overall_achieved": ssr["first_overall_achieved"],
+        "target_power": ssr["target_power"],
+        "scenario": label,
+        "boundary_hit": bh,
+        "fitted": dict(enumerate(ssr["fitted"])),
+        "fitted_joint": dict(enumerate(ssr["fitted_joint"])),
+        "fitted_overall": dict(enumerate(fitted_overall)),
+        "cluster_atom": ssr["cluster_atom"],
+    }
+
+
+def _run_grid(runner, spec: S.SimulationSpec, grid: Sequence[int], n_sims: int, seed: int, sink) -> S.BatchResult:
+    """One `run_batch` over the whole grid (find_sample_size.rs:196-209).  A grid longer than one device
+    call carries is split into consecutive calls; only allowed where the rows of a replicate do not depend
+    on the largest N of the call (unclustered designs: prefix-stable rows, no cross-N fit state)."""
+    if len(grid) <= MAX_GRID_PER_CALL:
+        return runner(spec, list(grid), n_sims, seed, sink)
+    if spec.cluster is not None:
+        raise S.EngineError(S.Status.Unsupported,
+                            f"a clustered grid of {len(grid)} sample sizes exceeds the {MAX_GRID_PER_CALL} one "
+                            f"run_batch call carries; use a coarser step")
+    parts = [runner(spec, list(grid[i:i + MAX_GRID_PER_CALL]), n_sims, seed, sink)
+             for i in range(0, len(grid), MAX_GRID_PER_CALL)]
+
+    def cat(name):
+        arrs = [getattr(p, name) for p in parts]
+        return None if any(a is None for a in arrs) else np.concatenate(arrs, axis=1)
+
+    first = parts[0]
+    shape = S.ResultShape(first.shape.n_sims, len(grid), first.shape.n_targets, first.shape.n_factors,
+                          first.shape.n_posthoc_contrasts, first.shape.n_variance_components)
+    return S.BatchResult(
+        shape=shape, uncorrected=cat("uncorrected"), corrected=cat("corrected"), posthoc_unc=cat("posthoc_unc"),
+        posthoc_cor=cat("posthoc_cor"), converged=cat("converged"), boundary_hit=cat("boundary_hit"),
+        pinned_components=cat("pinned_components"), joint_unc=cat("joint_unc"), joint_cor=cat("joint_cor"),
+        overall=cat("overall"), factor_excluded=cat("factor_excluded"), tau_squared_hat=cat("tau_squared_hat"),
+        stat_capture=first.stat_capture, counters=np.concatenate([p.counters for p in parts], axis=0),
+        layout=first.layout, device_ms=sum(p.device_ms for p in parts), kernel_ms=sum(p.kernel_ms for p in parts),
+        aux_kernel_ms=sum(p.aux_kernel_ms for p in parts),
+        n_kernel_launches=sum(p.n_kernel_launches for p in parts))
+
+
+def find_sample_size(contracts_bytes: bytes, target_power: float, lo: int, hi: int, n_sims: int, base_seed: int,
+                     method: str, by: Optional[int] = None, by_kind: Optional[str] = None, mode: Optional[str] = None,
+                     tol_n: Optional[int] = None, progress: Optional[Callable[[int, int], bool]] = None, *,
+                     _runner=None) -> Dict[str, Any]:
+    """`_engine.find_sample_size(...)` (engine-py/src/lib.rs:88-135 over find_sample_size.rs:72-152):
+    every grid N is fitted on the same nested-prefix replicates in one device call per scenario."""
+    del tol_n  # bisection-only in the reference; kept for signature stability
+    contracts = K.decode_contracts(contracts_bytes)
+    by_value, grid_mode = sample_size_method_from_host_args(method, by, by_kind, mode)
+    scenarios = lower_contracts(contracts, base_seed)
+    atom, hard_min, grid_warnings = resolve_cluster_grid_params(contracts)
+    grid, build_warnings = build_grid(int(lo), int(hi), by_value, grid_mode, atom, hard_min)
+    grid_warnings = grid_warnings + build_warnings
+    runner = _runner or _default_runner
+    fits_per_sim = len(grid)
+    total = int(n_sims) * len(scenarios) * fits_per_sim
+    cancelled = [False]
+
+    out: Dict[str, Any] = {}
+    for idx, sc in enumerate(scenarios):
+        if cancelled[0]:
+            raise OrchestratorError("Cancelled", f"cancelled at scenario {idx}, n=None")
+        offset = idx * int(n_sims) * fits_per_sim
+
+        def sink(current: int, _batch_total: int, _offset=offset) -> bool:
+            if cancelled[0]:
+                return False
+            if progress is not None:
+                try:
+                    keep = progress(_offset + int(current) * fits_per_sim, total)
+                    keep = True if keep is None else bool(keep)
+                except Exception:
+                    keep = False
+                if not keep:
+                    cancelled[0] = True
+            return not cancelled[0]
+
+        spec: S.SimulationSpec = sc["spec"]
+        try:
+            batch = _run_grid(runner, spec, grid, int(n_sims), sc["base_seed"], sink if progress is not None else None)
+        except S.EngineError as e:
+            if e.status == S.Status.Cancelled:
+                raise OrchestratorError("Cancelled", f"cancelled at scenario {idx}, n=None") from e
+            raise
+        aggs = aggregate_batch(batch, sc["report_target_indices"], sc["report_contrast_pairs"], spec.estimator,
+                               _posthoc_blocks(spec))
+        for pr, n in zip(aggs, grid):
+            pr["n"] = int(n)
+        d = derive_sample_size_outputs(aggs, grid, float(target_power), atom)
+        ssr = dict(grid_or_trace=aggs, cluster_atom=atom, target_power=float(target_power),
+                   grid_warnings=grid_warnings + factor_preflight_sample_size(spec, grid), **d)
+        out[sc["label"]] = sample_size_result_to_host(ssr, sc["label"])
+    return {"scenarios": out, "comparison": {}}
