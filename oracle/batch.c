@@ -6,10 +6,10 @@
  *   tensors :357-385), run_one_sim :795 (OLS arm :871-1213, GLM arm :1562-2144,
  *   MLE arm :1214-1560), build_posthoc_contrasts :2189, build_crit_tables :2334,
  * and crates/engine-orchestrator/src/aggregation.rs:61-330 for the counters.
- * The sparse-factor exclusion / reduced-fit rounds (batch.rs:925-1013,
- * :2451-2562) are not restated: specs that enable them
- * (factor_min_level_count > 0 with factors, or fit_columns) are rejected with
- * MCP_ERR_UNSUPPORTED.
+ * Sparse-factor exclusion and test_formula reduced fits (batch.rs:925-1013, :2418-2562) go through
+ * exclusion.c: the OLS arm gathers the kept rows/cols of the sufficient statistics, the GLM / MLE arms
+ * gather the kept design columns, and every df-dependent threshold of such a round comes from a table
+ * rebuilt at p_red fitted columns.
  */
 #include <math.h>
 #include <pthread.h>
@@ -30,11 +30,11 @@ void mcpo_set_error(const char* fmt, ...) {
 
 /* implemented in fit_glm.c / fit_lmm.c */
 int mcpo_glm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
-                 const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* overall,
-                 double* stat_row);
+                 const double* crit, uint32_t crit_stride, mcpo_red_cache* cache, uint8_t* unc, uint8_t* cor,
+                 uint8_t* conv, uint8_t* overall, uint8_t* fx, double* stat_row);
 int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
-                 uint8_t* joint_unc, uint8_t* joint_cor, double* stat_row);
+                 uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row);
 
 static uint32_t total_posthoc_contrasts(const mcp_spec* spec) {
   uint32_t tot = 0;
@@ -95,27 +95,11 @@ static int validate(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns) {
     if (mcpo_chol_colmajor(tmp, k)) { mcpo_set_error("correlation matrix is not positive semi-definite"); return MCP_ERR_CORRELATION_NOT_PSD; }
   }
   if (!mcpo_spec_supported(spec) || p > MCPO_MAX_P) { mcpo_set_error("unsupported: uploads / bootstrap / slopes / extra groupings"); return MCP_ERR_UNSUPPORTED; }
-  if (spec->n_fit_columns && spec->n_fit_columns < p) { mcpo_set_error("unsupported: fit_columns reduced fit"); return MCP_ERR_UNSUPPORTED; }
-  if (spec->n_factors && spec->factor_min_level_count > 0) {
-    /* supported only when the deterministic allocation walk proves that no level is ever sparse on this grid */
-    uint32_t counts[MCPO_MAX_LEVELS] = {0}, g = 0, offs[16] = {0};
-    if (spec->n_factor_proportions > MCPO_MAX_LEVELS || spec->n_factors > 16) { mcpo_set_error("unsupported: too many factor levels"); return MCP_ERR_UNSUPPORTED; }
-    for (uint32_t f = 0, o = 0; f < spec->n_factors; ++f) { offs[f] = o; o += (uint32_t)spec->factor_n_levels[f]; }
-    for (uint32_t f = 0; f < spec->n_factors; ++f) {
-      int sampled = spec->scenario.sampled_factor_proportions;
-      if (f < spec->n_factor_sampled && spec->factor_sampled[f] >= 0) sampled = spec->factor_sampled[f];
-      if (sampled) { mcpo_set_error("unsupported: sparse-factor exclusion with sampled proportions"); return MCP_ERR_UNSUPPORTED; }
-    }
-    for (uint32_t i = 0; i < ns[n_ns - 1] && g < n_ns; ++i) {
-      for (uint32_t f = 0; f < spec->n_factors; ++f) mcpo_fixed_level_next(spec->factor_proportions + offs[f], counts + offs[f], (uint32_t)spec->factor_n_levels[f]);
-      while (g < n_ns && i + 1 == ns[g]) {
-        for (uint32_t c = 0; c < spec->n_factor_proportions; ++c)
-          if (counts[c] < spec->factor_min_level_count) { mcpo_set_error("unsupported: sparse-factor exclusion fires on this grid"); return MCP_ERR_UNSUPPORTED; }
-        ++g;
-      }
-    }
+  for (uint32_t i = 0; i < spec->n_fit_columns; ++i) {
+    if (spec->fit_columns[i] >= p) { mcpo_set_error("invalid spec: fit_columns entry out of range"); return MCP_ERR_INVALID_SPEC; }
+    if (i && spec->fit_columns[i] <= spec->fit_columns[i - 1]) { mcpo_set_error("invalid spec: fit_columns must be strictly increasing"); return MCP_ERR_INVALID_SPEC; }
   }
-  if (spec->correction_method == MCP_CORR_TUKEY_HSD) { mcpo_set_error("unsupported: Tukey HSD thresholds"); return MCP_ERR_UNSUPPORTED; }
+  if (spec->n_factor_proportions > MCPO_MAX_LEVELS || spec->n_factors > 16) { mcpo_set_error("unsupported: too many factor levels"); return MCP_ERR_UNSUPPORTED; }
   return MCP_OK;
 }
 
@@ -131,41 +115,73 @@ typedef struct job {
   mcp_batch_result* out;
   uint32_t flags;
   int rc;
+  mcpo_red_cache cache; /* reduced-model thresholds, per worker */
 } job;
 
-static void ols_arm(const job* jb, const mcpo_ws* ws, uint32_t s) {
+static int ols_arm(job* jb, const mcpo_ws* ws, uint32_t s) {
   const mcp_spec* spec = jb->spec;
-  const uint32_t p = jb->p, nt = jb->nt, n_ns = jb->n_ns, npc = jb->npc, cs = nt + 4;
+  const uint32_t p = jb->p, nt = jb->nt, n_ns = jb->n_ns, npc = jb->npc, cs = nt + 4, nf = spec->n_factors;
   mcp_batch_result* R = jb->out;
-  mcpo_suff suff;
+  mcpo_suff suff, sred;
   mcpo_olsfit_t fit;
   mcpo_suff_reset(&suff, p);
   uint32_t last_n = 0;
   double all_t[MCPO_MAX_P * 2];
+  uint32_t prefix_counts[MCPO_MAX_LEVELS] = {0}, kept[MCPO_MAX_P];
+  int32_t remap[MCPO_MAX_P];
+  uint8_t flags[16] = {0};
+  const int test_reduces = spec->n_fit_columns && spec->n_fit_columns < p; /* batch.rs:869 */
   for (uint32_t g = 0; g < n_ns; ++g) {
     uint32_t n = jb->ns[g];
     mcpo_suff_add_rows(&suff, ws->x, ws->y, jb->max_n, last_n, n); /* batch.rs:883-917 */
+    if (nf && spec->factor_min_level_count > 0)                      /* incremental, cumulative counts */
+      mcpo_update_factor_exclusions(ws->x, jb->max_n, spec, last_n, n, prefix_counts, flags);
     last_n = n;
-    mcpo_fit_suff(&suff, &fit);
+    int any_excl = 0;
+    for (uint32_t f = 0; f < nf; ++f) any_excl |= flags[f] != 0;
+    const int reduced = any_excl || test_reduces;
+    uint32_t p_red = p;
+    const double* crow = jb->crit + (size_t)g * cs;
+    const double* prow = jb->post_corr ? jb->post_corr + (size_t)g * npc : NULL;
+    if (!reduced) {
+      for (uint32_t c = 0; c < p; ++c) remap[c] = (int32_t)c;
+      mcpo_fit_suff(&suff, &fit);
+    } else { /* gather the kept rows/cols of the sufficient statistics, batch.rs:970-1013 */
+      p_red = mcpo_build_exclusion_remap(spec, flags, kept, remap);
+      mcpo_suff_reset(&sred, p_red);
+      for (uint32_t rj = 0; rj < p_red; ++rj) {
+        sred.xty[rj] = suff.xty[kept[rj]];
+        for (uint32_t ri = rj; ri < p_red; ++ri) sred.xtx[ri * p_red + rj] = suff.xtx[kept[ri] * p + kept[rj]];
+      }
+      sred.yty = suff.yty; sred.sum_y = suff.sum_y; sred.n_rows = suff.n_rows;
+      mcpo_fit_suff(&sred, &fit);
+      const mcpo_red_crit* rc = mcpo_reduced_crit(&jb->cache, spec, n, p_red);
+      if (!rc) return MCP_ERR_INVALID_SPEC;
+      crow = rc->row;
+      prow = rc->post;
+    }
     size_t cell = (size_t)s * n_ns + g;
     R->converged[cell] = (uint8_t)fit.converged;
     R->boundary_hit[cell] = 0;
-    const double* crow = jb->crit + (size_t)g * cs;
     uint8_t* unc = R->uncorrected + cell * nt;
     uint8_t* cor = R->corrected + cell * nt;
     for (uint32_t t = 0; t < nt; ++t) all_t[t] = NAN;
     memset(unc, 0, nt);
-    if (fit.converged) { /* batch.rs:1060-1095 */
+    if (fit.converged) { /* batch.rs:1060-1095; a dropped target keeps NaN (never significant) */
       double c[MCPO_MAX_P];
       for (uint32_t t = 0; t < spec->n_target_indices; ++t) {
-        memset(c, 0, sizeof(double) * p);
-        c[spec->target_indices[t]] = 1.0;
+        int32_t r = remap[spec->target_indices[t]];
+        if (r < 0) continue;
+        memset(c, 0, sizeof(double) * p_red);
+        c[r] = 1.0;
         all_t[t] = mcpo_contrast_t_sq(&fit, c);
       }
       for (uint32_t q = 0; q < spec->n_contrast_pairs; ++q) {
-        memset(c, 0, sizeof(double) * p);
-        c[spec->contrast_pairs[2 * q]] += 1.0;
-        c[spec->contrast_pairs[2 * q + 1]] -= 1.0;
+        int32_t rp = remap[spec->contrast_pairs[2 * q]], rn = remap[spec->contrast_pairs[2 * q + 1]];
+        if (rp < 0 || rn < 0) continue;
+        memset(c, 0, sizeof(double) * p_red);
+        c[rp] += 1.0;
+        c[rn] -= 1.0;
         all_t[spec->n_target_indices + q] = mcpo_contrast_t_sq(&fit, c);
       }
       for (uint32_t t = 0; t < nt; ++t)
@@ -175,10 +191,10 @@ static void ols_arm(const job* jb, const mcpo_ws* ws, uint32_t s) {
       memset(cor, 0, nt);
     }
     if (g == 0 && R->stat_capture) memcpy(R->stat_capture + (size_t)s * nt, all_t, sizeof(double) * nt);
-    if (R->overall) { /* batch.rs:1118-1142 */
+    if (R->overall) { /* batch.rs:1118-1142: numerator df follows the fitted column count */
       uint8_t sig = 0;
       if (fit.converged) {
-        double dfn = (double)((int64_t)p - 1), dfd = fit.df_resid;
+        double dfn = (double)((int64_t)p_red - 1), dfd = fit.df_resid;
         if (dfn >= 1.0 && fit.sst > 1e-10 && fit.rss > 0.0 && isfinite(fit.rss) && isfinite(fit.sst)) {
           double f = ((fit.sst - fit.rss) / dfn) / (fit.rss / dfd);
           if (isfinite(f) && f > crow[3 + nt]) sig = 1;
@@ -186,22 +202,33 @@ static void ols_arm(const job* jb, const mcpo_ws* ws, uint32_t s) {
       }
       R->overall[cell] = sig;
     }
-    if (npc) { /* posthoc.rs:41-122 */
+    if (npc) { /* posthoc.rs:41-122; batch.rs:1164-1199 zeroes a contrast that touches a dropped column */
       uint8_t* pu = R->posthoc_unc + cell * npc;
       uint8_t* pc = R->posthoc_cor + cell * npc;
       memset(pu, 0, npc);
       memset(pc, 0, npc);
       if (fit.converged) {
-        double tsq[256];
+        double tsq[256], rc[MCPO_MAX_P];
         double pcrit = crow[1 + nt];
         for (uint32_t c = 0; c < npc; ++c) {
-          tsq[c] = mcpo_contrast_t_sq(&fit, jb->post_contrasts + (size_t)c * p);
+          const double* full = jb->post_contrasts + (size_t)c * p;
+          int dropped = 0;
+          memset(rc, 0, sizeof(double) * p_red);
+          for (uint32_t col = 0; col < p; ++col)
+            if (full[col] != 0.0) {
+              if (remap[col] >= 0) rc[remap[col]] = full[col];
+              else dropped = 1;
+            }
+          if (dropped) memset(rc, 0, sizeof(double) * p_red);
+          tsq[c] = mcpo_contrast_t_sq(&fit, rc);
           if (!isnan(tsq[c]) && tsq[c] > pcrit) pu[c] = 1;
         }
-        mcpo_apply_correction(spec->correction_method, tsq, npc, pcrit, jb->post_corr + (size_t)g * npc, pc);
+        mcpo_apply_correction(spec->correction_method, tsq, npc, pcrit, prow, pc);
       }
     }
+    if (nf) memcpy(R->factor_excluded + cell * nf, flags, nf);
   }
+  return MCP_OK;
 }
 
 static void* worker(void* arg) {
@@ -216,17 +243,19 @@ static void* worker(void* arg) {
     int rc = mcpo_generate_ws(spec, jb->base_seed, jb->sim_offset + s, jb->max_n, ws);
     if (rc) { jb->rc = rc; break; }
     size_t cell0 = (size_t)s * n_ns;
+    uint8_t* fx = spec->n_factors ? R->factor_excluded + cell0 * spec->n_factors : NULL;
     if (spec->estimator == MCP_EST_OLS) {
-      ols_arm(jb, ws, s);
+      rc = ols_arm(jb, ws, s);
+      if (rc) { jb->rc = rc; break; }
     } else if (spec->estimator == MCP_EST_GLM) {
-      rc = mcpo_glm_arm(spec, ws, jb->max_n, jb->ns, n_ns, jb->crit, cs, R->uncorrected + cell0 * nt,
-                        R->corrected + cell0 * nt, R->converged + cell0, R->overall ? R->overall + cell0 : NULL,
+      rc = mcpo_glm_arm(spec, ws, jb->max_n, jb->ns, n_ns, jb->crit, cs, &jb->cache, R->uncorrected + cell0 * nt,
+                        R->corrected + cell0 * nt, R->converged + cell0, R->overall ? R->overall + cell0 : NULL, fx,
                         R->stat_capture ? R->stat_capture + (size_t)s * nt : NULL);
       if (rc) { jb->rc = rc; break; }
     } else {
       rc = mcpo_mle_arm(spec, ws, jb->max_n, jb->ns, n_ns, jb->crit, cs, R->uncorrected + cell0 * nt,
                         R->corrected + cell0 * nt, R->converged + cell0, R->boundary_hit + cell0,
-                        R->joint_unc + cell0, R->joint_cor + cell0,
+                        R->joint_unc + cell0, R->joint_cor + cell0, fx,
                         R->stat_capture ? R->stat_capture + (size_t)s * nt : NULL);
       if (rc) { jb->rc = rc; break; }
       for (uint32_t g = 0; g < n_ns; ++g) /* bit 0 = intercept variance pinned at 0 (spec.rs:566-573) */
@@ -234,6 +263,7 @@ static void* worker(void* arg) {
     }
   }
   mcpo_ws_free(ws);
+  mcpo_red_cache_free(&jb->cache);
   return NULL;
 }
 
@@ -277,6 +307,10 @@ static void fold_counters(const mcp_spec* spec, mcp_batch_result* R) {
       c[L->joint_cor] += R->joint_cor[cell];
       c[L->boundary_1] += R->boundary_hit[cell] == 1;
       c[L->boundary_2] += R->boundary_hit[cell] == 2;
+      for (uint32_t f = 0; f < R->n_factors; ++f) {
+        c[L->excl_sparse + f] += R->factor_excluded[cell * R->n_factors + f] == 1;
+        c[L->excl_sep + f] += R->factor_excluded[cell * R->n_factors + f] == 2;
+      }
       c[L->n_sims] += 1;
     }
   (void)spec;
@@ -314,20 +348,13 @@ int mcpo_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
           if (a > 0) c[d[a - 1]] -= 1.0;
           ++ci;
         }
-      /* block correction rows: a CritValueTable with n_targets = blk at alpha = posthoc_alpha */
-      mcp_spec tmp = *spec;
-      double pa = isnan(spec->posthoc_alpha) ? spec->alpha : spec->posthoc_alpha;
-      tmp.alpha = pa;
-      tmp.posthoc_alpha = pa;
-      tmp.n_contrast_pairs = 0;
-      tmp.n_target_indices = blk;
-      double* trow = (double*)malloc(sizeof(double) * n_ns * (blk + 4));
-      rc = mcpo_build_crit_table(&tmp, ns, n_ns, trow);
-      if (rc) { free(trow); free(crit); free(post_contrasts); free(post_corr); return rc; }
-      for (uint32_t g = 0; g < n_ns; ++g)
-        for (uint32_t q = 0; q < blk; ++q) post_corr[(size_t)g * npc + c0 + q] = trow[(size_t)g * (blk + 4) + 1 + q];
-      free(trow);
+      (void)blk; (void)c0;
     }
+  }
+
+  if (npc) {
+    rc = mcpo_build_posthoc_corr(spec, ns, n_ns, p, post_corr);
+    if (rc) { free(crit); free(post_contrasts); free(post_corr); mcpo_set_error("invalid spec: posthoc thresholds"); return rc; }
   }
 
   size_t cells = (size_t)n_sims * n_ns;
@@ -367,6 +394,7 @@ int mcpo_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     jb->sim_begin = (uint32_t)((uint64_t)n_sims * t / n_threads);
     jb->sim_end = (uint32_t)((uint64_t)n_sims * (t + 1) / n_threads);
     jb->crit = crit; jb->post_corr = post_corr; jb->post_contrasts = post_contrasts; jb->out = out; jb->flags = flags; jb->rc = 0;
+    memset(&jb->cache, 0, sizeof jb->cache);
   }
   if (n_threads == 1) worker(&jobs[0]);
   else {

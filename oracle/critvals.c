@@ -221,9 +221,114 @@ double mcpo_f_ppf(double p, double dfn, double dfd) {
   return x;
 }
 
+/* ---- studentized range (Tukey HSD), critvals.rs:486-760 -------------------------------------------
+ * 32-node Gauss-Legendre rule on [-1,1] (positive half; nodes/weights of the standard rule). */
+static const double GL32_X[16] = {
+    0.04830766568773831, 0.1444719615827965, 0.23928736225213706, 0.33186860228212767,
+    0.42135127613063533, 0.5068999089322294, 0.5877157572407623, 0.6630442669302152,
+    0.7321821187402897, 0.7944837959679424, 0.84936761373257, 0.8963211557660522,
+    0.9349060759377397, 0.9647622555875064, 0.9856115115452684, 0.9972638618494816};
+static const double GL32_W[16] = {
+    0.09654008851472781, 0.09563872007927483, 0.09384439908080457, 0.09117387869576386,
+    0.08765209300440391, 0.08331192422694685, 0.07819389578707031, 0.07234579410884845,
+    0.06582222277636175, 0.058684093478535704, 0.050998059262376244, 0.042835898022226426,
+    0.034273862913021626, 0.025392065309262427, 0.016274394730905965, 0.007018610009469298};
+
+static double norm_pdf_(double z) { return exp(-0.5 * z * z) / sqrt(2.0 * M_PI); }
+
+/* P(range <= w | k iid standard normals) = k * int phi(z) [Phi(z) - Phi(z - w)]^(k-1) dz over [-8, 8],
+ * composite GL32 with 4 + (k - 1) panels (critvals.rs:593-612); Phi is the engine's A&S erfc form */
+static double range_cdf_(double w, double k) {
+  if (w <= 0.0) return 0.0;
+  const double lo = -8.0, hi = 8.0;
+  uint64_t ki = (uint64_t)k;
+  uint64_t panels = 4 + (ki > 0 ? ki - 1 : 0);
+  double step = (hi - lo) / (double)panels, half = 0.5 * step, acc = 0.0;
+  for (uint64_t pnl = 0; pnl < panels; ++pnl) {
+    double mid = lo + ((double)pnl + 0.5) * step;
+    for (int i = 0; i < 16; ++i) {
+      double dx = half * GL32_X[i], fa, fb, z, inner;
+      z = mid + dx; inner = mcpo_phi(z) - mcpo_phi(z - w);
+      fa = inner > 0.0 ? norm_pdf_(z) * pow(inner, k - 1.0) : 0.0;
+      z = mid - dx; inner = mcpo_phi(z) - mcpo_phi(z - w);
+      fb = inner > 0.0 ? norm_pdf_(z) * pow(inner, k - 1.0) : 0.0;
+      acc += GL32_W[i] * (fa + fb);
+    }
+  }
+  double v = k * (half * acc);
+  return v < 1.0 ? v : 1.0;
+}
+
+/* P(W <= q) for k groups and df error df: chi mixing in u = chi2_df/df on a graded mesh (critvals.rs:640-673) */
+static double studentized_range_cdf_(double q, double k, double df) {
+  if (q <= 0.0) return 0.0;
+  if (!isfinite(df) || df > 2.0e4) return range_cdf_(q, k);
+  double half_df = 0.5 * df;
+  double ln_c = half_df * log(half_df) - ln_gamma_(half_df);
+  double u_max = 1.0 + 12.0 * sqrt(2.0 / df);
+  int panels = df < 6.0 ? 96 : 24;
+  double grade = df < 6.0 ? 3.0 : 2.0;
+  double acc = 0.0, a = 0.0;
+  for (int pnl = 1; pnl <= panels; ++pnl) {
+    double b = u_max * pow((double)pnl / (double)panels, grade);
+    double half = 0.5 * (b - a), mid = 0.5 * (b + a);
+    for (int i = 0; i < 16; ++i) {
+      double dx = half * GL32_X[i], u, ga, gb;
+      u = mid + dx;
+      ga = u <= 0.0 ? 0.0 : exp(ln_c + (half_df - 1.0) * log(u) - half_df * u) * range_cdf_(q * sqrt(u), k);
+      u = mid - dx;
+      gb = u <= 0.0 ? 0.0 : exp(ln_c + (half_df - 1.0) * log(u) - half_df * u) * range_cdf_(q * sqrt(u), k);
+      acc += half * GL32_W[i] * (ga + gb);
+    }
+    a = b;
+  }
+  return acc < 1.0 ? acc : 1.0;
+}
+
+/* critvals.rs:687-760: Bonferroni seed, Newton with central differences, bisection fallback */
+double mcpo_q_tukey_ppf(double p, double k, double df) {
+  if (!isfinite(k) || k <= 1.0 || !isfinite(df) || df < 2.0 || !isfinite(p)) return NAN;
+  if (p <= 0.0) return 0.0;
+  if (p >= 1.0) return INFINITY;
+  double m = k * (k - 1.0);
+  double t_q = mcpo_t_ppf(1.0 - (1.0 - p) / m, df);
+  double q = (isfinite(t_q) && t_q > 0.0) ? M_SQRT2 * t_q : 3.0;
+  double lo = 0.0, hi = (q > 1.0 ? q : 1.0) * 2.0 + 4.0;
+  while (studentized_range_cdf_(hi, k, df) < p && hi < 1.0e3) hi *= 1.5;
+  const double h = 1e-4;
+  for (int it = 0; it < 60; ++it) {
+    double f = studentized_range_cdf_(q, k, df) - p;
+    if (fabs(f) < 1e-9) return q;
+    if (f < 0.0) lo = q; else hi = q;
+    double deriv = (studentized_range_cdf_(q + h, k, df) - studentized_range_cdf_(q - h, k, df)) / (2.0 * h);
+    double next = (isfinite(deriv) && deriv > 1e-12) ? q - f / deriv : NAN;
+    if (!isfinite(next) || next <= lo || next >= hi) next = 0.5 * (lo + hi);
+    if (fabs(next - q) < 1e-10) return next;
+    q = next;
+  }
+  return q;
+}
+
+/* batch.rs:2235-2253: studentized-range k of the factor owning kernel column `col`; NaN off the dummy blocks */
+static double tukey_k_for_col_(const mcp_spec* spec, uint32_t col) {
+  uint32_t base = 1 + spec->n_non_factor;
+  if (col < base) return NAN;
+  uint32_t cursor = base;
+  for (uint32_t f = 0; f < spec->n_factors; ++f) {
+    uint32_t l = spec->factor_n_levels[f] > 0 ? (uint32_t)spec->factor_n_levels[f] : 0;
+    uint32_t width = l > 0 ? l - 1 : 0;
+    if (col < cursor + width) return (double)l;
+    cursor += width;
+  }
+  return NAN;
+}
+
 /* critvals.rs:827-1012; `n_predictors` = total design columns P */
-int mcpo_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, double* out) {
-  uint32_t p_total = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
+/* `p_total` is the FITTED column count: the full P for the hot-path tables, p_red for a reduced-model round
+ * (batch.rs:2334-2407 build_crit_tables is called with either).  `tukey_k` (length m, or NULL) carries the
+ * per-target studentized-range k; NULL derives it from the spec's targets (batch.rs:2346-2374). */
+int mcpo_build_crit_table_p(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t p_total,
+                            const double* tukey_k, double* out) {
   uint32_t m = spec->n_target_indices + spec->n_contrast_pairs;
   double alpha = spec->alpha;
   if (!isfinite(alpha) || alpha <= 0.0 || alpha >= 1.0) return MCP_ERR_INVALID_SPEC;
@@ -252,7 +357,14 @@ int mcpo_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_n
           double eff = (double)(k + 1) / (double)m * alpha / 2.0;
           t = eff < 1e-12 ? INFINITY : QUANT(1.0 - eff);
         } break;
-        default: return MCP_ERR_UNSUPPORTED; /* Tukey */
+        case MCP_CORR_TUKEY_HSD: { /* critvals.rs:927-948 */
+          double kk;
+          if (tukey_k) kk = tukey_k[k];
+          else if (k < spec->n_target_indices) kk = tukey_k_for_col_(spec, spec->target_indices[k]);
+          else kk = tukey_k_for_col_(spec, spec->contrast_pairs[2 * (k - spec->n_target_indices)]);
+          t = mcpo_q_tukey_ppf(1.0 - alpha, kk, df) / M_SQRT2;
+        } break;
+        default: return MCP_ERR_UNSUPPORTED;
       }
       row[1 + k] = t * t;
     }
@@ -265,6 +377,45 @@ int mcpo_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_n
     else if (spec->estimator == MCP_EST_GLM) row[3 + m] = mcpo_chi2_ppf(1.0 - alpha, npni);
     else row[3 + m] = INFINITY;
 #undef QUANT
+  }
+  return MCP_OK;
+}
+
+int mcpo_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, double* out) {
+  return mcpo_build_crit_table_p(spec, ns, n_ns, 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions,
+                                 NULL, out);
+}
+
+/* batch.rs:2262-2313 + :2383-2405: per-N correction thresholds of the post-hoc family, one block per
+ * requested factor, concatenated; a block is a CritValueTable with n_targets = C(k,2) at alpha = posthoc_alpha
+ * (Tukey: every contrast of the block carries that factor's k).  out: n_ns x npc. */
+int mcpo_build_posthoc_corr(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t p_total, double* out) {
+  uint32_t npc = 0;
+  for (uint32_t b = 0; b < spec->n_posthoc; ++b) {
+    uint32_t k = spec->posthoc_target_offsets[b + 1] - spec->posthoc_target_offsets[b] + 1;
+    npc += k * (k - 1) / 2;
+  }
+  uint32_t c0 = 0;
+  for (uint32_t b = 0; b < spec->n_posthoc; ++b) {
+    uint32_t k = spec->posthoc_target_offsets[b + 1] - spec->posthoc_target_offsets[b] + 1;
+    uint32_t blk = k * (k - 1) / 2;
+    mcp_spec tmp = *spec;
+    double pa = isnan(spec->posthoc_alpha) ? spec->alpha : spec->posthoc_alpha;
+    tmp.alpha = pa;
+    tmp.posthoc_alpha = pa;
+    tmp.n_contrast_pairs = 0;
+    tmp.n_target_indices = blk;
+    double* trow = (double*)malloc(sizeof(double) * n_ns * (blk + 4));
+    double* kk = (double*)malloc(sizeof(double) * (blk ? blk : 1));
+    for (uint32_t q = 0; q < blk; ++q) kk[q] = (double)k;
+    int rc = mcpo_build_crit_table_p(&tmp, ns, n_ns, p_total, kk, trow);
+    if (rc == MCP_OK)
+      for (uint32_t g = 0; g < n_ns; ++g)
+        for (uint32_t q = 0; q < blk; ++q) out[(size_t)g * npc + c0 + q] = trow[(size_t)g * (blk + 4) + 1 + q];
+    free(trow);
+    free(kk);
+    if (rc) return rc;
+    c0 += blk;
   }
   return MCP_OK;
 }

@@ -22,6 +22,7 @@
  * (SURVEY.md 8c, row "GLM fit").
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include "oracle_internal.h"
 
@@ -181,42 +182,90 @@ int mcpo_glm_fit(const float* x, const float* y, uint32_t n, uint32_t ld, uint32
   return MCP_OK;
 }
 
-/* GLM arm of run_one_sim (batch.rs:1562-2134), unclustered logistic, no factor exclusion */
+/* GLM arm of run_one_sim (batch.rs:1562-2134), unclustered logistic.  Sparse-factor exclusion recounts the
+ * levels of rows [0, N) at every grid point (:1836-1853); a reduced round gathers the kept design columns and the
+ * kept columns' true effects as the start (:1893-1925); when attempt 0 does not converge and the feature is on,
+ * the included factor with the smallest minimum level count is dropped (code 2) and the fit retried once from a
+ * cold start (:1976-2030). */
 int mcpo_glm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
-                 const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* overall,
-                 double* stat_row) {
+                 const double* crit, uint32_t crit_stride, mcpo_red_cache* cache, uint8_t* unc, uint8_t* cor,
+                 uint8_t* conv, uint8_t* overall, uint8_t* fx, double* stat_row) {
   if (spec->cluster.present) return MCP_ERR_UNSUPPORTED;            /* Laplace GLMM */
   if (spec->outcome_kind != MCP_OUTCOME_BINARY || spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
   if (spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;           /* GLM has no contrasts (batch.rs:2069) */
   const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
-  const uint32_t nt = spec->n_target_indices;
-  for (uint32_t g = 0; g < n_ns; ++g) {
+  const uint32_t nt = spec->n_target_indices, nf = spec->n_factors;
+  const int test_reduces = spec->n_fit_columns && spec->n_fit_columns < p;
+  uint32_t prefix_counts[MCPO_MAX_LEVELS], kept[MCPO_MAX_P];
+  int32_t remap[MCPO_MAX_P];
+  uint8_t flags[16] = {0};
+  float* xr = NULL; /* gathered kept columns, column-major with ld = max_n */
+  int rc = MCP_OK;
+  for (uint32_t g = 0; g < n_ns && rc == MCP_OK; ++g) {
+    const uint32_t n = ns[g];
+    if (nf && spec->factor_min_level_count > 0) {
+      memset(prefix_counts, 0, sizeof prefix_counts);
+      mcpo_update_factor_exclusions(ws->x, max_n, spec, 0, n, prefix_counts, flags);
+    }
     glm_fit f;
-    glm_irls(ws->x, ws->y, ns[g], max_n, p, spec->effect_sizes, &f); /* truth start, batch.rs:1945-1951 */
+    uint32_t p_red = p;
+    int reduced = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      int any_excl = 0;
+      for (uint32_t q = 0; q < nf; ++q) any_excl |= flags[q] != 0;
+      reduced = any_excl || test_reduces;
+      if (!reduced) {
+        p_red = p;
+        for (uint32_t c = 0; c < p; ++c) remap[c] = (int32_t)c;
+        glm_irls(ws->x, ws->y, n, max_n, p, attempt > 0 ? NULL : spec->effect_sizes, &f); /* truth start :1945-1951 */
+      } else {
+        double start[MCPO_MAX_P];
+        p_red = mcpo_build_exclusion_remap(spec, flags, kept, remap);
+        if (!xr) xr = (float*)malloc(sizeof(float) * (size_t)max_n * p);
+        for (uint32_t rj = 0; rj < p_red; ++rj) {
+          memcpy(xr + (size_t)rj * max_n, ws->x + (size_t)kept[rj] * max_n, sizeof(float) * n);
+          start[rj] = spec->effect_sizes[kept[rj]];
+        }
+        glm_irls(xr, ws->y, n, max_n, p_red, attempt > 0 ? NULL : start, &f);
+      }
+      if (f.converged || attempt == 1 || spec->factor_min_level_count == 0) break;
+      int drop = mcpo_smallest_min_count_factor(spec, prefix_counts, flags);
+      if (drop < 0) break;
+      flags[drop] = 2;
+    }
     const double* crow = crit + (size_t)g * crit_stride;
     double tsq[MCPO_MAX_P * 2];
     conv[g] = (uint8_t)f.converged;
     memset(unc + (size_t)g * nt, 0, nt);
     for (uint32_t t = 0; t < nt; ++t) {
       tsq[t] = NAN;
-      if (f.converged) {
+      int32_t r = remap[spec->target_indices[t]];
+      if (f.converged && r >= 0) {
         double c[MCPO_MAX_P] = {0};
-        c[spec->target_indices[t]] = 1.0;
-        tsq[t] = glm_wald_sq(&f, p, c);
+        c[r] = 1.0;
+        tsq[t] = glm_wald_sq(&f, p_red, c);
         if (!isnan(tsq[t]) && tsq[t] > crow[0]) unc[(size_t)g * nt + t] = 1;
       }
     }
     if (g == 0 && stat_row) memcpy(stat_row, tsq, sizeof(double) * nt);
     if (f.converged) mcpo_apply_correction(spec->correction_method, tsq, nt, crow[0], crow + 1, cor + (size_t)g * nt);
     else memset(cor + (size_t)g * nt, 0, nt);
-    if (overall) {
+    if (overall) { /* LRT df follows the fitted column count (batch.rs:2096-2113) */
+      double crit_overall = crow[3 + nt];
+      if (reduced) {
+        const mcpo_red_crit* e = mcpo_reduced_crit(cache, spec, n, p_red);
+        if (!e) { rc = MCP_ERR_INVALID_SPEC; break; }
+        crit_overall = e->row[3 + nt];
+      }
       uint8_t sig = 0;
       if (f.converged && isfinite(f.deviance) && isfinite(f.deviance_null)) {
         double lrt = f.deviance_null - f.deviance;
-        if (isfinite(lrt) && lrt > crow[3 + nt]) sig = 1;
+        if (isfinite(lrt) && lrt > crit_overall) sig = 1;
       }
       overall[g] = sig;
     }
+    if (nf && fx) memcpy(fx + (size_t)g * nf, flags, nf);
   }
-  return MCP_OK;
+  free(xr);
+  return rc;
 }

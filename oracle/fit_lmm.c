@@ -295,47 +295,77 @@ int mcpo_lmm_fit(const float* x, const float* y, const uint32_t* cluster_ids, ui
   return MCP_OK;
 }
 
-/* Mle arm of run_one_sim (batch.rs:1214-1560), random intercept only */
+/* Mle arm of run_one_sim (batch.rs:1214-1560), random intercept only.  Exclusion flags are recounted from rows
+ * [0, N) before every fit (:1236-1250); a reduced round fits the gathered kept columns, never updates the
+ * grid-sequential theta carry (:1414-1428), and runs the joint Wald over the kept targets against chi2(k_red)
+ * (:1456-1468); marginal / correction thresholds are Wald-z, df-free, and stay on the full table. */
 int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
-                 uint8_t* joint_unc, uint8_t* joint_cor, double* stat_row) {
+                 uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row) {
   if (!spec->cluster.present || spec->cluster.n_slopes || spec->cluster.n_extra_groupings) return MCP_ERR_UNSUPPORTED;
   if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS || spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;
   const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
-  const uint32_t nt = spec->n_target_indices;
+  const uint32_t nt = spec->n_target_indices, nf = spec->n_factors;
   const uint32_t cv = spec->cluster.sizing_value ? spec->cluster.sizing_value : 1;
   const int fixed_clusters = spec->cluster.sizing == MCP_CLUSTER_FIXED_CLUSTERS;
+  const int test_reduces = spec->n_fit_columns && spec->n_fit_columns < p;
   uint32_t ncl_max = fixed_clusters ? cv : (max_n + cv - 1) / cv;
   double* csum = (double*)malloc(sizeof(double) * (size_t)(ncl_max ? ncl_max : 1) * (p + 1));
   uint32_t* ids = (uint32_t*)malloc(sizeof(uint32_t) * max_n);
+  float* xr = NULL;
   for (uint32_t i = 0; i < max_n; ++i) ids[i] = mcpo_cluster_of_row(&spec->cluster, i);
   int has_prev = 0;
   double theta_carry = 0.0;
+  uint32_t prefix_counts[MCPO_MAX_LEVELS], kept[MCPO_MAX_P];
+  int32_t remap[MCPO_MAX_P];
+  uint8_t flags[16] = {0};
   int rc = MCP_OK;
   for (uint32_t g = 0; g < n_ns && rc == MCP_OK; ++g) {
     uint32_t n = ns[g];
+    if (nf && spec->factor_min_level_count > 0) {
+      memset(prefix_counts, 0, sizeof prefix_counts);
+      mcpo_update_factor_exclusions(ws->x, max_n, spec, 0, n, prefix_counts, flags);
+    }
+    int any_excl = 0;
+    for (uint32_t q = 0; q < nf; ++q) any_excl |= flags[q] != 0;
+    const int reduced = any_excl || test_reduces;
+    uint32_t p_red = p;
+    const float* xfit = ws->x;
+    if (!reduced) {
+      for (uint32_t c = 0; c < p; ++c) remap[c] = (int32_t)c;
+    } else {
+      p_red = mcpo_build_exclusion_remap(spec, flags, kept, remap);
+      if (p_red == 0 || kept[0] != 0) { rc = MCP_ERR_UNSUPPORTED; break; } /* intercept-free mixed fit */
+      if (!xr) xr = (float*)malloc(sizeof(float) * (size_t)max_n * p);
+      for (uint32_t rj = 0; rj < p_red; ++rj)
+        memcpy(xr + (size_t)rj * max_n, ws->x + (size_t)kept[rj] * max_n, sizeof(float) * n);
+      xfit = xr;
+    }
     /* clusters that own at least one of the first n rows (generation.rs:152-157); empty ones are skipped */
     uint32_t ncl = fixed_clusters ? cv : (n + cv - 1) / cv;
     lmm_data d;
-    rc = build_lmm_data(ws->x, ws->y, ids, n, max_n, p, ncl, &d, csum);
+    rc = build_lmm_data(xfit, ws->y, ids, n, max_n, p_red, ncl, &d, csum);
     if (rc) break;
     double start = has_prev ? theta_carry
                             : (spec->scenario.truth_start ? sqrt(fmax(spec->cluster.tau_squared, 0.0)) : THETA_BLIND);
     if (start < 0.01) start = 0.01; /* THETA_TRUTH_FLOOR, batch.rs:1316-1321 */
     lmm_fit f;
     lmm_fit_data(&d, start, &f);
-    if (f.converged) { theta_carry = f.theta; has_prev = 1; }
+    if (!reduced && f.converged) { theta_carry = f.theta; has_prev = 1; }
     const double* crow = crit + (size_t)g * crit_stride;
     conv[g] = (uint8_t)f.converged;
     bh[g] = f.boundary_hit;
     double tsq[MCPO_MAX_P * 2];
+    uint32_t kept_targets[MCPO_MAX_P * 2], k_red = 0;
     memset(unc + (size_t)g * nt, 0, nt);
     for (uint32_t t = 0; t < nt; ++t) {
       tsq[t] = NAN;
-      if (f.converged) {
+      int32_t r = remap[spec->target_indices[t]];
+      if (r >= 0) kept_targets[k_red++] = (uint32_t)r;
+      if (f.converged && r >= 0) {
         double c[MCPO_MAX_P] = {0};
-        c[spec->target_indices[t]] = 1.0;
-        double var = lmm_var(&f, p, c), b = f.ev.beta[spec->target_indices[t]];
+        c[r] = 1.0;
+        double var = lmm_var(&f, p_red, c), b = f.ev.beta[r];
         if (var > LMM_NEAR_ZERO && isfinite(var)) tsq[t] = b * b / var;
         if (!isnan(tsq[t]) && tsq[t] > crow[0]) unc[(size_t)g * nt + t] = 1;
       }
@@ -343,12 +373,15 @@ int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
     if (g == 0 && stat_row) memcpy(stat_row, tsq, sizeof(double) * nt);
     if (f.converged) mcpo_apply_correction(spec->correction_method, tsq, nt, crow[0], crow + 1, cor + (size_t)g * nt);
     else memset(cor + (size_t)g * nt, 0, nt);
-    double jq = f.converged ? lmm_joint(&f, p, spec->target_indices, nt) : NAN;
-    uint8_t js = (f.converged && isfinite(jq) && jq > crow[2 + nt]) ? 1 : 0;
+    double joint_crit = !reduced ? crow[2 + nt] : (k_red == 0 ? INFINITY : mcpo_chi2_ppf(1.0 - spec->alpha, (double)k_red));
+    double jq = (f.converged && k_red) ? lmm_joint(&f, p_red, kept_targets, k_red) : NAN;
+    uint8_t js = (f.converged && isfinite(jq) && jq > joint_crit) ? 1 : 0;
     joint_unc[g] = js;
     joint_cor[g] = js;
+    if (nf && fx) memcpy(fx + (size_t)g * nf, flags, nf);
   }
   free(csum);
   free(ids);
+  free(xr);
   return rc;
 }

@@ -72,6 +72,10 @@ double mcpo_chi2_ppf(double p, double k);
 double mcpo_f_ppf(double p, double dfn, double dfd);
 /* per sample size: [t_crit_sq_unc, correction[0..n_targets), posthoc, joint, overall] */
 int mcpo_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, double* out);
+int mcpo_build_crit_table_p(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t p_total,
+                            const double* tukey_k, double* out);
+int mcpo_build_posthoc_corr(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t p_total, double* out);
+double mcpo_q_tukey_ppf(double p, double k, double df);
 
 /* correction.rs:16-92 */
 void mcpo_apply_correction(int method, const double* t_sq, uint32_t t, double crit_unc,

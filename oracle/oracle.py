@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
             getattr(L, name).argtypes = [C.c_double, C.c_double]
         L.mcpo_f_ppf.restype = C.c_double
         L.mcpo_f_ppf.argtypes = [C.c_double] * 3
+        L.mcpo_q_tukey_ppf.restype = C.c_double
+        L.mcpo_q_tukey_ppf.argtypes = [C.c_double] * 3
         L.mcpo_phi.restype = C.c_double
         L.mcpo_phi.argtypes = [C.c_double]
         L.mcpo_marginal_uniform.restype = C.c_double
@@ -137,6 +139,10 @@ def chi2_ppf(p, k):
 
 def f_ppf(p, dfn, dfd):
     return lib().mcpo_f_ppf(p, dfn, dfd)
+
+
+def q_tukey_ppf(p, k, df):
+    return lib().mcpo_q_tukey_ppf(p, k, df)
 
 
 def phi(z):

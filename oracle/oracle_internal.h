@@ -54,5 +54,23 @@ void mcpo_fit_suff(const mcpo_suff* s, mcpo_olsfit_t* fit);
 double mcpo_contrast_t_sq(const mcpo_olsfit_t* fit, const double* c);
 
 uint32_t mcpo_fixed_level_next(const double* probs, uint32_t* counts, uint32_t n_levels);
+
+/* sparse-factor exclusion / reduced designs (exclusion.c) */
+typedef struct mcpo_red_crit {
+  uint32_t n, p_red;
+  double* row;  /* nt + 4: [t_unc^2, corr[0..nt), posthoc, joint, overall] at p_red fitted columns */
+  double* post; /* npc post-hoc correction thresholds */
+} mcpo_red_crit;
+typedef struct mcpo_red_cache {
+  mcpo_red_crit* e;
+  uint32_t count, cap;
+} mcpo_red_cache;
+void mcpo_update_factor_exclusions(const float* x, uint32_t ld, const mcp_spec* spec, uint32_t from, uint32_t to,
+                                   uint32_t* prefix_counts, uint8_t* flags);
+uint32_t mcpo_build_exclusion_remap(const mcp_spec* spec, const uint8_t* flags, uint32_t* kept_cols,
+                                    int32_t* col_remap);
+int mcpo_smallest_min_count_factor(const mcp_spec* spec, const uint32_t* prefix_counts, const uint8_t* flags);
+const mcpo_red_crit* mcpo_reduced_crit(mcpo_red_cache* cache, const mcp_spec* spec, uint32_t n, uint32_t p_red);
+void mcpo_red_cache_free(mcpo_red_cache* cache);
 void mcpo_set_error(const char* fmt, ...);
 #endif
