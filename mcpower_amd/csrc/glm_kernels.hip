@@ -264,13 +264,34 @@ __global__ __launch_bounds__(256) void fold_flags_kernel(const SimParams* __rest
         if (mc) atomicAdd(ctr + prm.ctr_k_cor + t, (unsigned long long)__popcll(mc));
       }
     }
-    for (uint32_t k = 0; k <= nt; ++k) {
+    // post-hoc contrasts count into their own slots and into the joint histogram (aggregation.rs:134-222)
+    const uint32_t npc = prm.posthoc_unc ? prm.n_posthoc : 0u;
+    for (uint32_t q = 0; q < npc; ++q) {
+      const uint32_t u = active ? prm.posthoc_unc[cell * npc + q] : 0u, c = active ? prm.posthoc_cor[cell * npc + q] : 0u;
+      ku += u != 0u;
+      kc += c != 0u;
+      const unsigned long long mu = __ballot(u != 0u), mc = __ballot(c != 0u);
+      if (lane0) {
+        if (mu) atomicAdd(ctr + prm.ctr_posthoc_unc + q, (unsigned long long)__popcll(mu));
+        if (mc) atomicAdd(ctr + prm.ctr_posthoc_cor + q, (unsigned long long)__popcll(mc));
+      }
+    }
+    for (uint32_t k = 0; k <= nt + npc; ++k) {
       const unsigned long long hu = __ballot(active && ku == k), hc = __ballot(active && kc == k);
       if (lane0) {
         if (hu) atomicAdd(ctr + prm.ctr_hist_unc + k, (unsigned long long)__popcll(hu));
         if (hc) atomicAdd(ctr + prm.ctr_hist_cor + k, (unsigned long long)__popcll(hc));
       }
     }
+    if (prm.factor_excluded)  // codes: 1 = sparse level, 2 = dropped by the GLM separation fallback (aggregation.rs:244-262)
+      for (uint32_t f = 0; f < prm.n_factors; ++f) {
+        const uint32_t code = active ? prm.factor_excluded[cell * prm.n_factors + f] : 0u;
+        const unsigned long long m1 = __ballot(code == 1u), m2 = __ballot(code == 2u);
+        if (lane0) {
+          if (m1) atomicAdd(ctr + prm.ctr_excl_sparse + f, (unsigned long long)__popcll(m1));
+          if (m2) atomicAdd(ctr + prm.ctr_excl_sep + f, (unsigned long long)__popcll(m2));
+        }
+      }
     const unsigned long long mcv = __ballot(active && prm.conv[cell] != 0);
     const unsigned long long mov = __ballot(active && prm.overall && prm.overall[cell] != 0);
     const unsigned long long mac = __ballot(active);

@@ -22,6 +22,7 @@
 
 namespace mcp {
 hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, hipStream_t st);
+hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
 hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
 hipError_t launch_scenario_design(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
 hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, hipStream_t st);
@@ -62,7 +63,7 @@ struct Arena {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Buf slots[20];
+  Buf slots[24];
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
   int device = -1;
@@ -94,7 +95,7 @@ struct Arena {
 };
 thread_local Arena g_arena;
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3 };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
   int n = 0;
@@ -152,9 +153,11 @@ int mcp_build_crit_table(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns
   if (rc) return fail(rc, err);
   const uint32_t P = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
   const uint32_t nt = spec->n_target_indices + spec->n_contrast_pairs;
-  std::vector<double> rows;
+  std::vector<double> rows, kk;
+  if (spec->correction_method == MCP_CORR_TUKEY_HSD) mcp::tukey_k_per_target(spec, kk);
+  mcp::TukeyMemo memo;
   rc = mcp::build_crit_rows(spec->estimator, spec->correction_method, spec->alpha, spec->posthoc_alpha, P, nt, ns, n_ns,
-                            rows, err);
+                            kk.empty() ? nullptr : kk.data(), &memo, rows, err);
   if (rc) return fail(rc, err);
   std::memcpy(crit_out, rows.data(), rows.size() * sizeof(double));
   return MCP_OK;
@@ -186,7 +189,11 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   const bool want_stat = flags & MCP_WANT_STAT_CAPTURE;
   const bool mle = spec->estimator == MCP_EST_MLE;
   const bool glm = spec->estimator == MCP_EST_GLM || mle;  // wave-per-replicate kernels + flag fold
+  const bool reduced = prm.red_active && !glm;             // reduced-design OLS kernel, flags folded afterwards
+  if (reduced && (flags & MCP_PIPELINE_STAGED))
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds");
   const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
+  const uint32_t npc = prm.n_posthoc;
   const uint64_t sim_offset = opts ? opts->sim_offset : 0;
   const uint32_t nt = low.n_tests, P = low.P;
   const size_t cells = (size_t)n_sims * n_ns;
@@ -195,7 +202,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   mcp::counter_layout(spec, &layout);
   out->layout = layout;
   out->n_sims = n_sims; out->n_sample_sizes = n_ns; out->n_targets = nt; out->n_factors = spec->n_factors;
-  out->n_posthoc_contrasts = 0; out->n_variance_components = spec->estimator == MCP_EST_MLE ? 1u : 0u;
+  out->n_posthoc_contrasts = npc; out->n_variance_components = spec->estimator == MCP_EST_MLE ? 1u : 0u;
   out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
@@ -249,7 +256,19 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   const uint32_t copy_stride = (n_ctr + 15u) & ~15u;  // whole 128-byte lines per copy
   const size_t ctr_words = (size_t)copy_stride * (mcp::CTR_COPIES + 1);  // copies, then the reduced vector
   DEV_TRY(ar.get(S_COUNTERS, ctr_words * sizeof(uint64_t), (void**)&d_ctr));
-  if (per_sim || glm) {  // the wave-per-replicate kernels always write flags; a fold kernel counts them
+  uint8_t *d_ph_unc = nullptr, *d_ph_cor = nullptr, *d_fx = nullptr;
+  double* d_crit_red = nullptr;
+  uint16_t* d_red_row = nullptr;
+  if (reduced) {
+    if (npc) {
+      DEV_TRY(ar.get(S_PH_UNC, cells * npc + 1, (void**)&d_ph_unc));
+      DEV_TRY(ar.get(S_PH_COR, cells * npc + 1, (void**)&d_ph_cor));
+    }
+    DEV_TRY(ar.get(S_FX, cells * (spec->n_factors ? spec->n_factors : 1) + 1, (void**)&d_fx));
+    DEV_TRY(ar.get(S_CRIT_RED, (low.crit_red.size() + 1) * sizeof(double), (void**)&d_crit_red));
+    DEV_TRY(ar.get(S_RED_ROW, low.red_row.size() * sizeof(uint16_t), (void**)&d_red_row));
+  }
+  if (per_sim || glm || reduced) {  // these kernels always write flags; a fold kernel counts them
     DEV_TRY(ar.get(S_UNC, cells * nt + 1, (void**)&d_unc));
     DEV_TRY(ar.get(S_COR, cells * nt + 1, (void**)&d_cor));
     DEV_TRY(ar.get(S_CONV, cells + 1, (void**)&d_conv));
@@ -287,6 +306,10 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(hipMemcpyAsync(d_crit, low.crit.data(), low.crit.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DEV_TRY(hipMemcpyAsync(d_levels, low.fixed_levels.data(), low.fixed_levels.size(), hipMemcpyHostToDevice, st));
   DEV_TRY(hipMemsetAsync(d_ctr, 0, ctr_words * sizeof(uint64_t), st));
+  if (reduced) {
+    DEV_TRY(hipMemcpyAsync(d_crit_red, low.crit_red.data(), low.crit_red.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    DEV_TRY(hipMemcpyAsync(d_red_row, low.red_row.data(), low.red_row.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+  }
 
   prm.base_seed = base_seed;
   prm.fixed_levels = d_levels;
@@ -301,6 +324,10 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   prm.ctr_stride = layout.stride; prm.ctr_k_unc = layout.k_unc; prm.ctr_k_cor = layout.k_cor;
   prm.ctr_conv = layout.converged; prm.ctr_overall = layout.overall; prm.ctr_hist_unc = layout.hist_unc;
   prm.ctr_hist_cor = layout.hist_cor; prm.ctr_n_sims = layout.n_sims;
+  prm.posthoc_unc = d_ph_unc; prm.posthoc_cor = d_ph_cor; prm.factor_excluded = d_fx;
+  prm.crit_red = d_crit_red; prm.red_row = d_red_row;
+  prm.ctr_posthoc_unc = layout.posthoc_unc; prm.ctr_posthoc_cor = layout.posthoc_cor;
+  prm.ctr_excl_sparse = layout.excl_sparse; prm.ctr_excl_sep = layout.excl_sep;
   prm.tile = d_tile;
   prm.tile_sims = chunk;
   prm.scen_L = d_scen_L;
@@ -318,19 +345,24 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(hipMemcpyAsync(d_prm, h_prm.data(), sizeof(mcp::SimParams) * n_chunks, hipMemcpyHostToDevice, st));
 
   // launches, each bracketed by events on the launch stream
-  const size_t ev_per_chunk = (staged || glm) ? 3 : 2;
+  const size_t ev_per_chunk = (staged || glm || reduced) ? 3 : 2;
   bool cancelled = false;
   uint32_t launched = 0;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     hipEvent_t e0, e1, e2 = nullptr;
     DEV_TRY(ar.event(2 + c * ev_per_chunk, &e0));
     DEV_TRY(ar.event(3 + c * ev_per_chunk, &e1));
-    if (staged || glm) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
+    if (staged || glm || reduced) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
       if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, st));
       else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, st));
+      DEV_TRY(hipEventRecord(e1, st));
+      DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
+      DEV_TRY(hipEventRecord(e2, st));
+    } else if (reduced) {
+      DEV_TRY(mcp::launch_ols_reduced((int)P, d_prm + c, h_prm[c].n_sims, flavor, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
@@ -374,6 +406,17 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     out->tau_squared_hat = host_alloc<double>(cells);
     for (size_t i = 0; i < cells; ++i) out->tau_squared_hat[i] = NAN;
     if (spec->n_factors) out->factor_excluded = (uint8_t*)std::calloc(cells * spec->n_factors + 1, 1);
+    if (npc) {
+      out->posthoc_unc = (uint8_t*)std::calloc(cells * npc + 1, 1);
+      out->posthoc_cor = (uint8_t*)std::calloc(cells * npc + 1, 1);
+    }
+    if (reduced) {
+      if (spec->n_factors) DEV_TRY(hipMemcpyAsync(out->factor_excluded, d_fx, cells * spec->n_factors, hipMemcpyDeviceToHost, st));
+      if (npc) {
+        DEV_TRY(hipMemcpyAsync(out->posthoc_unc, d_ph_unc, cells * npc, hipMemcpyDeviceToHost, st));
+        DEV_TRY(hipMemcpyAsync(out->posthoc_cor, d_ph_cor, cells * npc, hipMemcpyDeviceToHost, st));
+      }
+    }
     DEV_TRY(hipMemcpyAsync(out->uncorrected, d_unc, cells * nt, hipMemcpyDeviceToHost, st));
     DEV_TRY(hipMemcpyAsync(out->corrected, d_cor, cells * nt, hipMemcpyDeviceToHost, st));
     DEV_TRY(hipMemcpyAsync(out->converged, d_conv, cells, hipMemcpyDeviceToHost, st));
@@ -401,7 +444,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   for (uint32_t c = 0; c < launched; ++c) {
     hipEvent_t e0 = ar.events[2 + c * ev_per_chunk], e1 = ar.events[3 + c * ev_per_chunk];
     DEV_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (glm) {
+    if (glm || reduced) {
       kernel_ms += ms;  // simulate kernel
       DEV_TRY(hipEventElapsedTime(&ms, e1, ar.events[4 + c * ev_per_chunk]));
       aux_ms += ms;  // counter fold

@@ -229,10 +229,122 @@ std::vector<double> build_t3_table() {
   return v;
 }
 
+// ---- studentized range (Tukey HSD thresholds), critvals.rs:486-760 ---------------------------------
+// The normal CDF inside the range integral is the engine's own Abramowitz-Stegun erfc form
+// (distributions.rs:32-56), so thresholds carry the same ~1e-7 bias as the reference's.
+namespace {
+const double GL32_X[16] = {0.04830766568773831, 0.1444719615827965, 0.23928736225213706, 0.33186860228212767,
+                           0.42135127613063533, 0.5068999089322294, 0.5877157572407623,  0.6630442669302152,
+                           0.7321821187402897,  0.7944837959679424, 0.84936761373257,    0.8963211557660522,
+                           0.9349060759377397,  0.9647622555875064, 0.9856115115452684,  0.9972638618494816};
+const double GL32_W[16] = {0.09654008851472781,  0.09563872007927483,  0.09384439908080457,  0.09117387869576386,
+                           0.08765209300440391,  0.08331192422694685,  0.07819389578707031,  0.07234579410884845,
+                           0.06582222277636175,  0.058684093478535704, 0.050998059262376244, 0.042835898022226426,
+                           0.034273862913021626, 0.025392065309262427, 0.016274394730905965, 0.007018610009469298};
+
+double phi_as(double z) {
+  const double x = -z * 0.70710678118654752440;
+  const double sign = x < 0.0 ? -1.0 : 1.0;
+  const double ax = std::fabs(x);
+  const double t = 1.0 / (1.0 + 0.3275911 * ax);
+  const double y =
+      1.0 - (((((1.061405429 * t + -1.453152027) * t) + 1.421413741) * t + -0.284496736) * t + 0.254829592) * t * std::exp(-ax * ax);
+  return 0.5 * (1.0 - sign * y);
+}
+
+double norm_pdf(double z) { return std::exp(-0.5 * z * z) / std::sqrt(2.0 * kPi); }
+
+// P(range of k iid N(0,1) <= w): k * int_{-8}^{8} phi(z) [Phi(z) - Phi(z - w)]^(k-1) dz, 4 + (k-1) GL32 panels
+double range_cdf(double w, double k) {
+  if (w <= 0.0) return 0.0;
+  const uint64_t ki = (uint64_t)k;
+  const uint64_t panels = 4 + (ki > 0 ? ki - 1 : 0);
+  const double step = 16.0 / (double)panels, half = 0.5 * step;
+  double acc = 0.0;
+  auto f = [&](double z) {
+    const double inner = phi_as(z) - phi_as(z - w);
+    return inner > 0.0 ? norm_pdf(z) * std::pow(inner, k - 1.0) : 0.0;
+  };
+  for (uint64_t pn = 0; pn < panels; ++pn) {
+    const double mid = -8.0 + ((double)pn + 0.5) * step;
+    for (int i = 0; i < 16; ++i) {
+      const double dx = half * GL32_X[i];
+      acc += GL32_W[i] * (f(mid + dx) + f(mid - dx));
+    }
+  }
+  const double v = k * (half * acc);
+  return v < 1.0 ? v : 1.0;
+}
+
+// P(W <= q | k, df): gamma mixing in u = chi2_df / df on a mesh graded toward 0 (critvals.rs:640-673)
+double studentized_range_cdf(double q, double k, double df) {
+  if (q <= 0.0) return 0.0;
+  if (!std::isfinite(df) || df > 2.0e4) return range_cdf(q, k);
+  const double half_df = 0.5 * df;
+  const double ln_c = half_df * std::log(half_df) - ln_gamma(half_df);
+  const double u_max = 1.0 + 12.0 * std::sqrt(2.0 / df);
+  const int panels = df < 6.0 ? 96 : 24;
+  const double grade = df < 6.0 ? 3.0 : 2.0;
+  auto g = [&](double u) {
+    if (u <= 0.0) return 0.0;
+    return std::exp(ln_c + (half_df - 1.0) * std::log(u) - half_df * u) * range_cdf(q * std::sqrt(u), k);
+  };
+  double acc = 0.0, a = 0.0;
+  for (int pn = 1; pn <= panels; ++pn) {
+    const double b = u_max * std::pow((double)pn / (double)panels, grade);
+    const double half = 0.5 * (b - a), mid = 0.5 * (b + a);
+    for (int i = 0; i < 16; ++i) {
+      const double dx = half * GL32_X[i];
+      acc += half * GL32_W[i] * (g(mid + dx) + g(mid - dx));
+    }
+    a = b;
+  }
+  return acc < 1.0 ? acc : 1.0;
+}
+}  // namespace
+
+// critvals.rs:687-760: Bonferroni seed, Newton with a central-difference slope, bisection fallback
+double q_tukey_ppf(double p, double k, double df) {
+  if (!std::isfinite(k) || k <= 1.0 || !std::isfinite(df) || df < 2.0 || !std::isfinite(p)) return kNaN;
+  if (p <= 0.0) return 0.0;
+  if (p >= 1.0) return kInf;
+  const double m = k * (k - 1.0);
+  const double t_q = t_ppf(1.0 - (1.0 - p) / m, df);
+  double q = (std::isfinite(t_q) && t_q > 0.0) ? std::sqrt(2.0) * t_q : 3.0;
+  double lo = 0.0, hi = (q > 1.0 ? q : 1.0) * 2.0 + 4.0;
+  while (studentized_range_cdf(hi, k, df) < p && hi < 1.0e3) hi *= 1.5;
+  const double h = 1e-4;
+  for (int it = 0; it < 60; ++it) {
+    const double f = studentized_range_cdf(q, k, df) - p;
+    if (std::fabs(f) < 1e-9) return q;
+    if (f < 0.0) lo = q; else hi = q;
+    const double deriv = (studentized_range_cdf(q + h, k, df) - studentized_range_cdf(q - h, k, df)) / (2.0 * h);
+    double next = (std::isfinite(deriv) && deriv > 1e-12) ? q - f / deriv : kNaN;
+    if (!std::isfinite(next) || next <= lo || next >= hi) next = 0.5 * (lo + hi);
+    if (std::fabs(next - q) < 1e-10) return next;
+    q = next;
+  }
+  return q;
+}
+
+// memo of (alpha, k, df) -> (q / sqrt 2)^2: a grid revisits the same df for many rows, and one quantile costs
+// ~10^5 range-integral evaluations
+double TukeyMemo::threshold(double alpha, double k, double df) {
+  for (const auto& e : entries)
+    if (e.alpha == alpha && e.df == df && (e.k == k || (std::isnan(e.k) && std::isnan(k)))) return e.value;
+  const double q = q_tukey_ppf(1.0 - alpha, k, df);
+  const double t = q / std::sqrt(2.0);
+  entries.push_back({alpha, k, df, t * t});
+  return t * t;
+}
+
 // CritValueTable::build_with_tukey_k (critvals.rs:827-1012).  Row layout per sample size:
 // [t_crit_sq_uncorrected, correction_t_crit_sq[0..m), posthoc_t_crit_sq, joint_t_crit_sq, overall_crit]
+// `n_predictors` is the FITTED column count (the full P, or p_red for a reduced-model round, batch.rs:2334);
+// `tukey_k` (length m, may be null unless correction == TukeyHsd) is the per-target studentized-range k.
 int build_crit_rows(int estimator, int correction, double alpha, double posthoc_alpha, uint32_t n_predictors,
-                    uint32_t m, const uint32_t* ns, uint32_t n_ns, std::vector<double>& out, std::string& err) {
+                    uint32_t m, const uint32_t* ns, uint32_t n_ns, const double* tukey_k, TukeyMemo* memo,
+                    std::vector<double>& out, std::string& err) {
   if (!std::isfinite(alpha) || alpha <= 0.0 || alpha >= 1.0) {
     err = "invalid spec: alpha must lie in (0, 1); got " + std::to_string(alpha);
     return MCP_ERR_INVALID_SPEC;
@@ -266,9 +378,11 @@ int build_crit_rows(int estimator, int correction, double alpha, double posthoc_
       } else if (correction == MCP_CORR_BH) {
         const double eff = double(k + 1) / double(m) * alpha / 2.0;
         t = eff < 1e-12 ? kInf : quant(1.0 - eff);
-      } else if (correction == MCP_CORR_TUKEY_HSD) {
-        err = "unsupported: Tukey-HSD thresholds (critvals.rs:927-948) are not built on this path yet";
-        return MCP_ERR_UNSUPPORTED;
+      } else if (correction == MCP_CORR_TUKEY_HSD) {  // critvals.rs:927-948
+        const double kk = tukey_k ? tukey_k[k] : kNaN;
+        TukeyMemo local;
+        row[1 + k] = (memo ? memo : &local)->threshold(alpha, kk, df);
+        continue;
       }
       row[1 + k] = t * t;
     }

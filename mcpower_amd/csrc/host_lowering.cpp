@@ -142,6 +142,66 @@ static uint32_t fixed_level_next(const double* probs, uint32_t* counts, uint32_t
   return best;
 }
 
+
+uint32_t total_posthoc_contrasts(const mcp_spec* spec) {
+  uint32_t npc = 0;
+  for (uint32_t b = 0; b < spec->n_posthoc; ++b) {
+    const uint32_t k = spec->posthoc_target_offsets[b + 1] - spec->posthoc_target_offsets[b] + 1;
+    npc += k * (k - 1) / 2;
+  }
+  return npc;
+}
+
+// batch.rs:2235-2253 tukey_k_for_kernel_col: level count of the factor owning a dummy column, NaN elsewhere
+static double tukey_k_for_col(const mcp_spec* spec, uint32_t col) {
+  const uint32_t base = 1 + spec->n_non_factor;
+  if (col < base) return std::nan("");
+  uint32_t cursor = base;
+  for (uint32_t f = 0; f < spec->n_factors; ++f) {
+    const uint32_t l = spec->factor_n_levels[f] > 0 ? (uint32_t)spec->factor_n_levels[f] : 0u;
+    const uint32_t width = l ? l - 1 : 0;
+    if (col < cursor + width) return (double)l;
+    cursor += width;
+  }
+  return std::nan("");
+}
+
+// batch.rs:2346-2374: marginal targets first, then contrasts (the positive side names the factor)
+void tukey_k_per_target(const mcp_spec* spec, std::vector<double>& k) {
+  k.clear();
+  for (uint32_t t = 0; t < spec->n_target_indices; ++t) k.push_back(tukey_k_for_col(spec, spec->target_indices[t]));
+  for (uint32_t q = 0; q < spec->n_contrast_pairs; ++q) k.push_back(tukey_k_for_col(spec, spec->contrast_pairs[2 * q]));
+}
+
+// build_crit_tables (batch.rs:2334-2407) at `n_fit` fitted columns: the main table, then per post-hoc block a
+// table with n_targets = C(k,2) at alpha = posthoc_alpha whose correction row is appended (:2262-2313, :2383-2405)
+int build_crit_rows_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t n_fit, TukeyMemo* memo,
+                         std::vector<double>& out, std::string& err) {
+  const uint32_t nt = spec->n_target_indices + spec->n_contrast_pairs;
+  const uint32_t npc = total_posthoc_contrasts(spec), stride = nt + 4 + npc;
+  std::vector<double> kk, main_rows;
+  if (spec->correction_method == MCP_CORR_TUKEY_HSD) tukey_k_per_target(spec, kk);
+  int rc = build_crit_rows(spec->estimator, spec->correction_method, spec->alpha, spec->posthoc_alpha, n_fit, nt, ns, n_ns,
+                           kk.empty() ? nullptr : kk.data(), memo, main_rows, err);
+  if (rc) return rc;
+  out.assign((size_t)n_ns * stride, 0.0);
+  for (uint32_t g = 0; g < n_ns; ++g)
+    std::memcpy(out.data() + (size_t)g * stride, main_rows.data() + (size_t)g * (nt + 4), sizeof(double) * (nt + 4));
+  const double pa = std::isnan(spec->posthoc_alpha) ? spec->alpha : spec->posthoc_alpha;
+  uint32_t c0 = 0;
+  for (uint32_t b = 0; b < spec->n_posthoc; ++b) {
+    const uint32_t k = spec->posthoc_target_offsets[b + 1] - spec->posthoc_target_offsets[b] + 1;
+    const uint32_t blk = k * (k - 1) / 2;
+    std::vector<double> bk(blk, (double)k), rows;
+    rc = build_crit_rows(spec->estimator, spec->correction_method, pa, pa, n_fit, blk, ns, n_ns, bk.data(), memo, rows, err);
+    if (rc) return rc;
+    for (uint32_t g = 0; g < n_ns; ++g)
+      for (uint32_t q = 0; q < blk; ++q) out[(size_t)g * stride + nt + 4 + c0 + q] = rows[(size_t)g * (blk + 4) + 1 + q];
+    c0 += blk;
+  }
+  return MCP_OK;
+}
+
 int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParams& prm, Lowered& low, std::string& err) {
   auto unsupported = [&](const std::string& m) {
     err = "unsupported on the device path: " + m;
@@ -189,32 +249,16 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (spec->scenario.has_lme) return unsupported("LME scenario knobs (random-effect distribution, ICC jitter)");
   if (spec->n_bootstrap_frame_map || spec->upload_normal_rows || spec->upload_data_rows) return unsupported("uploaded data");
   if (spec->n_between_var_indices) return unsupported("cluster-level (between) predictors");
-  if (spec->n_posthoc) return unsupported("post-hoc contrasts");
-  if (spec->n_fit_columns && spec->n_fit_columns < P) return unsupported("reduced test design (fit_columns)");
-  // sparse-factor exclusion (batch.rs:903-915, 2451-2496) is decided per (replicate, N) from level counts.  With
-  // the deterministic allocation walk the counts are the same for every replicate, so the host can prove that
-  // no factor is ever excluded on this grid -- then the run is identical to factor_min_level_count = 0.
-  if (spec->n_factors && spec->factor_min_level_count > 0) {
-    std::vector<uint32_t> counts(spec->n_factor_proportions, 0u);
-    std::vector<uint32_t> off(spec->n_factors, 0u);
-    for (uint32_t f = 0, o = 0; f < spec->n_factors; ++f) { off[f] = o; o += (uint32_t)spec->factor_n_levels[f]; }
-    for (uint32_t f = 0; f < spec->n_factors; ++f) {
-      int sampled = spec->scenario.sampled_factor_proportions;
-      if (f < spec->n_factor_sampled && spec->factor_sampled[f] >= 0) sampled = spec->factor_sampled[f];
-      if (sampled) return unsupported("sparse-factor exclusion with sampled factor proportions (per-replicate reduced fits)");
+  const uint32_t npc = total_posthoc_contrasts(spec);
+  if (npc > (uint32_t)MAX_PC) return unsupported("more than " + std::to_string(MAX_PC) + " post-hoc contrasts");
+  for (uint32_t i = 0; i < (spec->n_posthoc ? spec->posthoc_target_offsets[spec->n_posthoc] : 0u); ++i)
+    if (spec->posthoc_target_indices[i] >= P) {
+      err = "invalid spec: posthoc target index " + std::to_string(spec->posthoc_target_indices[i]) +
+            " out of range (n_predictors = " + std::to_string(P) + ")";
+      return MCP_ERR_INVALID_SPEC;
     }
-    uint32_t g = 0;
-    for (uint32_t i = 0; i < max_n && g < n_ns; ++i) {
-      for (uint32_t f = 0; f < spec->n_factors; ++f)
-        fixed_level_next(spec->factor_proportions + off[f], counts.data() + off[f], (uint32_t)spec->factor_n_levels[f]);
-      while (g < n_ns && i + 1 == ns[g]) {
-        for (uint32_t c = 0; c < spec->n_factor_proportions; ++c)
-          if (counts[c] < spec->factor_min_level_count)
-            return unsupported("sparse-factor exclusion fires on this grid (a level has fewer than factor_min_level_count rows at N = " + std::to_string(ns[g]) + ")");
-        ++g;
-      }
-    }
-  }
+  if (spec->factor_min_level_count > 15 && spec->n_factors)
+    return unsupported("factor_min_level_count above 15 (per-level row counts are kept in saturating 4-bit lanes)");
   if (spec->heteroskedasticity_driver >= (int32_t)(1 + K + spec->n_factor_dummies)) {
     err = "invalid spec: heteroskedasticity_driver out of range";
     return MCP_ERR_INVALID_SPEC;
@@ -309,7 +353,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   }
   prm.correction = spec->correction_method;
   prm.report_overall = spec->report_overall ? 1u : 0u;
-  prm.crit_stride = nt + 4;
   prm.outcome_kind = (uint32_t)spec->outcome_kind;
   prm.estimator = (uint32_t)spec->estimator;
 
@@ -411,9 +454,105 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     prm.hsk_inv_norm = std::exp(-gamma * gamma / 2.0);
   }
 
-  const int rc = build_crit_rows(spec->estimator, spec->correction_method, spec->alpha, spec->posthoc_alpha, P, nt, ns,
-                                 n_ns, low.crit, err);
+  // ---- reduced-design path: sparse-factor exclusion, test_formula subsets, post-hoc contrasts ----
+  TukeyMemo memo;
+  int rc = build_crit_rows_spec(spec, ns, n_ns, P, &memo, low.crit, err);
   if (rc) return rc;
+  prm.crit_stride = nt + 4 + npc;
+  prm.n_posthoc = npc;
+  prm.min_level_count = spec->n_factors ? spec->factor_min_level_count : 0u;
+  for (uint32_t t = 0; t < (uint32_t)MAX_T; ++t) prm.test_pos[t] = prm.test_neg[t] = 0xff;
+  for (uint32_t t = 0; t < spec->n_target_indices; ++t) prm.test_pos[t] = (uint8_t)spec->target_indices[t];
+  for (uint32_t q = 0; q < spec->n_contrast_pairs; ++q) {
+    prm.test_pos[spec->n_target_indices + q] = (uint8_t)spec->contrast_pairs[2 * q];
+    prm.test_neg[spec->n_target_indices + q] = (uint8_t)spec->contrast_pairs[2 * q + 1];
+  }
+  {  // build_posthoc_contrasts (batch.rs:2189-2223): per block, for a < b over levels, L[b] - L[a] with L[0] = reference
+    uint32_t ci = 0;
+    for (uint32_t b = 0; b < spec->n_posthoc; ++b) {
+      const uint32_t* d = spec->posthoc_target_indices + spec->posthoc_target_offsets[b];
+      const uint32_t k = spec->posthoc_target_offsets[b + 1] - spec->posthoc_target_offsets[b] + 1;
+      for (uint32_t a = 0; a < k; ++a)
+        for (uint32_t bb = a + 1; bb < k; ++bb) {
+          prm.ph_pos[ci] = (uint8_t)d[bb - 1];
+          prm.ph_neg[ci] = a > 0 ? (uint8_t)d[a - 1] : (uint8_t)0xff;
+          ++ci;
+        }
+    }
+  }
+  const bool test_reduces = spec->n_fit_columns && spec->n_fit_columns < P;  // batch.rs:869
+  // kept-column mask of every combination of per-factor exclusion flags (build_exclusion_remap, batch.rs:2506-2562)
+  auto in_test = [&](uint32_t c) {
+    if (spec->n_fit_columns == 0) return true;
+    for (uint32_t i = 0; i < spec->n_fit_columns; ++i)
+      if (spec->fit_columns[i] == c) return true;
+    return false;
+  };
+  const uint32_t dummy_base = 1 + K, inter_base = dummy_base + spec->n_factor_dummies;
+  for (uint32_t fb = 0; fb < 16u; ++fb) {
+    uint32_t dropped_dummies = 0, keep = 0;
+    for (uint32_t c = dummy_base; c < inter_base; ++c)
+      if ((fb >> prm.col_factor[c]) & 1u) dropped_dummies |= 1u << c;
+    for (uint32_t c = 0; c < P; ++c) {
+      bool kept = in_test(c) && !((dropped_dummies >> c) & 1u);
+      if (c >= inter_base && (prm.inter_mask[c] & dropped_dummies)) kept = false;
+      if (kept) keep |= 1u << c;
+    }
+    prm.keep_mask[fb] = keep;
+  }
+  // which flag combinations can occur at each grid N: a fixed-allocation factor's level counts are the same in
+  // every replicate (the host walks them); a sampled factor's are per replicate, so both values stay open
+  low.red_row.assign((size_t)n_ns * 16u, 0xffffu);
+  low.crit_red.clear();
+  bool any_excl_possible = false;
+  {
+    std::vector<uint32_t> counts(spec->n_factor_proportions ? spec->n_factor_proportions : 1, 0u);
+    std::vector<uint32_t> fixed_flag((size_t)n_ns * (spec->n_factors ? spec->n_factors : 1), 0u);
+    uint32_t g = 0;
+    for (uint32_t i = 0; i < max_n && g < n_ns && prm.min_level_count > 0; ++i) {
+      for (uint32_t f = 0; f < spec->n_factors; ++f)
+        if (!prm.f_sampled[f])
+          counts[prm.f_prop_off[f] + low.fixed_levels[(size_t)i * spec->n_factors + f]] += 1;
+      while (g < n_ns && i + 1 == ns[g]) {
+        for (uint32_t f = 0; f < spec->n_factors; ++f)
+          if (!prm.f_sampled[f])
+            for (uint32_t l = 0; l < prm.f_levels[f]; ++l)
+              if (counts[prm.f_prop_off[f] + l] < prm.min_level_count) fixed_flag[(size_t)g * spec->n_factors + f] = 1;
+        ++g;
+      }
+    }
+    struct Key { uint32_t n, p_red, row; };
+    std::vector<Key> keys;
+    for (g = 0; g < n_ns; ++g)
+      for (uint32_t fb = 0; fb < (1u << spec->n_factors); ++fb) {
+        bool reachable = true;
+        for (uint32_t f = 0; f < spec->n_factors; ++f) {
+          const uint32_t bit = (fb >> f) & 1u;
+          if (prm.min_level_count == 0) reachable = reachable && bit == 0;
+          else if (spec->estimator == MCP_EST_GLM) continue;  // the separation fallback may drop any included factor
+          else if (!prm.f_sampled[f]) reachable = reachable && bit == fixed_flag[(size_t)g * spec->n_factors + f];
+        }
+        if (!reachable) continue;
+        if (fb) any_excl_possible = true;
+        const uint32_t p_red = (uint32_t)__builtin_popcount(prm.keep_mask[fb]);
+        if (p_red == 0 || (int64_t)ns[g] - (int64_t)p_red < 1) continue;
+        uint32_t row = 0xffffu;
+        for (const Key& kx : keys)
+          if (kx.n == ns[g] && kx.p_red == p_red) row = kx.row;
+        if (row == 0xffffu) {
+          std::vector<double> one;
+          rc = build_crit_rows_spec(spec, &ns[g], 1, p_red, &memo, one, err);
+          if (rc) return rc;
+          row = (uint32_t)(low.crit_red.size() / prm.crit_stride);
+          low.crit_red.insert(low.crit_red.end(), one.begin(), one.end());
+          keys.push_back({ns[g], p_red, row});
+        }
+        low.red_row[(size_t)g * 16u + fb] = (uint16_t)row;
+      }
+  }
+  prm.red_active = (npc > 0 || test_reduces || any_excl_possible) ? 1u : 0u;
+  if (prm.red_active && spec->estimator != MCP_EST_OLS)
+    return unsupported("sparse-factor exclusion / test_formula reduced fits under Glm / Mle (OLS only so far)");
   low.P = P;
   low.n_tests = nt;
   return MCP_OK;

@@ -16,6 +16,7 @@ constexpr int MAX_GRID = 64;     // sample-size grid points per call
 constexpr int MAX_T = 8;         // tests per fit (marginal targets + contrast pairs)
 constexpr int MAX_FACTORS = 4;
 constexpr int MAX_LEVELS = 16;   // sum of levels over all factors
+constexpr int MAX_PC = 28;       // post-hoc pairwise contrasts per fit (<= 7 dummies: one 8-level factor = C(8,2))
 // Same-address atomics serialise in L2 at ~90 per microsecond (MI355X_MICROARCH.md, "dequeue"); with one
 // atomic per wave per counter a 10^6-replicate launch would spend ~1.8 ms there.  Spreading the adds over
 // 256 copies, each on its own cache lines, takes that off the critical path; a tiny kernel sums the copies.
@@ -113,6 +114,24 @@ struct SimParams {
   uint32_t scen_stride;
   uint32_t _pad_scen;
   const double* t3_table;          // 2048-knot standardized t(3) PPF table (marginals/t3.rs) or null
+
+  // ---- reduced-design path (batch.rs:925-1213, 2418-2562): per-(replicate, N) sparse-factor exclusion, a
+  //      test_formula subset of the columns, post-hoc pairwise contrasts.  A kept-column bitmask selects the
+  //      fitted model; every df-dependent threshold of the round comes from the row built at p_red columns ----
+  uint32_t red_active;             // 1: the OLS launch takes the reduced-design kernel
+  uint32_t min_level_count;        // factor_min_level_count (0 = exclusion off)
+  uint32_t keep_mask[16];          // kept columns for each combination of per-factor exclusion flags (bit f = factor f)
+  uint32_t n_posthoc;              // post-hoc contrasts in total (all blocks, batch.rs:2189-2223 order)
+  uint8_t ph_pos[MAX_PC];          // column carrying +1
+  uint8_t ph_neg[MAX_PC];          // column carrying -1, 0xff when the pair is against the reference level
+  uint8_t test_pos[MAX_T];         // main tests in the same (+column, -column | 0xff) form
+  uint8_t test_neg[MAX_T];
+  const uint16_t* red_row;         // [n_grid][16]: threshold row of (N, flag combination); 0xffff = cannot occur
+  const double* crit_red;          // rows of crit_stride doubles: [t_unc^2, corr[nt], posthoc, joint, overall, posthoc corr[npc]]
+  uint8_t* posthoc_unc;            // [n_sims_total][n_grid][n_posthoc] or null
+  uint8_t* posthoc_cor;
+  uint8_t* factor_excluded;        // [n_sims_total][n_grid][n_factors] or null
+  uint32_t ctr_posthoc_unc, ctr_posthoc_cor, ctr_excl_sparse, ctr_excl_sep;
 
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;

@@ -95,10 +95,6 @@ static int validate(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns) {
     if (mcpo_chol_colmajor(tmp, k)) { mcpo_set_error("correlation matrix is not positive semi-definite"); return MCP_ERR_CORRELATION_NOT_PSD; }
   }
   if (!mcpo_spec_supported(spec) || p > MCPO_MAX_P) { mcpo_set_error("unsupported: uploads / bootstrap / slopes / extra groupings"); return MCP_ERR_UNSUPPORTED; }
-  for (uint32_t i = 0; i < spec->n_fit_columns; ++i) {
-    if (spec->fit_columns[i] >= p) { mcpo_set_error("invalid spec: fit_columns entry out of range"); return MCP_ERR_INVALID_SPEC; }
-    if (i && spec->fit_columns[i] <= spec->fit_columns[i - 1]) { mcpo_set_error("invalid spec: fit_columns must be strictly increasing"); return MCP_ERR_INVALID_SPEC; }
-  }
   if (spec->n_factor_proportions > MCPO_MAX_LEVELS || spec->n_factors > 16) { mcpo_set_error("unsupported: too many factor levels"); return MCP_ERR_UNSUPPORTED; }
   return MCP_OK;
 }

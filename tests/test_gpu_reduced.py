@@ -1,0 +1,168 @@
+"""GPU parity for the reduced-design rounds: sparse-factor exclusion (fixed and sampled allocation),
+test_formula column subsets, post-hoc pairwise contrasts, Tukey HSD thresholds.  The device solves the
+masked p x p system (identity rows at dropped columns); the oracle gathers the p_red x p_red system the way
+the reference does (batch.rs:970-1013) -- the two must agree on every flag and on t^2 to 1e-10."""
+import math
+
+import numpy as np
+import pytest
+
+from helpers import BASE_SEED
+from mcpower_amd import spec as S
+from test_gpu_parity import _assert_batch_equal
+from test_oracle_exclusion import factor_spec, three_level_posthoc_spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(engine, oracle, spec, ns, n_sims, seed=BASE_SEED, **kw):
+    g = engine.run_batch(spec, ns, n_sims, seed, stat_capture=True, **kw)
+    o = oracle.run_batch(spec, ns, n_sims, seed, stat_capture=True, n_threads=8, sim_offset=kw.get("sim_offset", 0))
+    return g, o
+
+
+def _assert_reduced_equal(g, o):
+    _assert_batch_equal(g, o)
+    for f in ("factor_excluded", "posthoc_unc", "posthoc_cor"):
+        ga, oa = getattr(g, f), getattr(o, f)
+        assert (ga is None) == (oa is None), f
+        if ga is not None:
+            assert np.array_equal(ga, oa), f"{f}: {int((ga != oa).sum())} of {ga.size} differ"
+    assert g.shape.n_posthoc_contrasts == o.shape.n_posthoc_contrasts
+
+
+def test_fixed_allocation_exclusion_on_a_grid(engine, oracle):
+    """batch.rs `exclusion_is_per_n_on_a_grid`: [0.9, 0.1] excluded at N = 20, included at N = 100."""
+    g, o = _both(engine, oracle, factor_spec(0.3, 0.8, [0.9, 0.1], 5), [20, 100], 3000, 42)
+    _assert_reduced_equal(g, o)
+    assert (g.factor_excluded[:, 0, 0] == 1).all() and not g.factor_excluded[:, 1, 0].any()
+    assert not g.uncorrected[:, 0, 1].any() and g.uncorrected[:, 1, 1].sum() > 0
+    assert np.isnan(g.stat_capture[:, 1]).all()
+    assert g.counter("excl_sparse", 1)[:, 0].tolist() == [3000, 0]
+
+
+def test_healthy_factor_takes_the_hot_kernel_and_matches_min_count_zero(engine, oracle):
+    a = engine.run_batch(factor_spec(0.5, 0.8, [0.5, 0.5], 5), [40], 2000, 99)
+    b = engine.run_batch(factor_spec(0.5, 0.8, [0.5, 0.5], 0), [40], 2000, 99)
+    for f in ("uncorrected", "corrected", "converged", "overall", "counters"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert not a.factor_excluded.any()
+
+
+def test_sampled_allocation_excludes_per_replicate(engine, oracle):
+    spec = factor_spec(0.4, 0.6, [0.85, 0.15], 5, factor_sampled=[True])
+    g, o = _both(engine, oracle, spec, [30, 60, 61, 200], 4000, 11)
+    _assert_reduced_equal(g, o)
+    fx = g.factor_excluded[:, :, 0]
+    assert 0 < fx[:, 0].sum() < 4000 and fx[:, 3].sum() == 0
+    assert not g.uncorrected[fx == 1][:, 1].any()
+    # shard union == single run on this path too
+    lo = engine.run_batch(spec, [30, 60, 61, 200], 1500, 11)
+    hi = engine.run_batch(spec, [30, 60, 61, 200], 2500, 11, sim_offset=1500)
+    assert np.array_equal(np.concatenate([lo.uncorrected, hi.uncorrected]), g.uncorrected)
+    assert np.array_equal(lo.counters + hi.counters, g.counters)
+    c = engine.run_batch(spec, [30, 60, 61, 200], 4000, 11, per_sim=False, chunk_sims=1024)
+    assert np.array_equal(c.counters, g.counters) and c.uncorrected is None
+
+
+def test_two_factors_interaction_and_contrast_under_exclusion(engine, oracle):
+    spec = S.SimulationSpec(n_non_factor=1, n_factor_dummies=3, correlation=[1.0], var_types=[S.Distribution.Normal],
+                            var_params=[0.0], factor_n_levels=[2, 3], factor_proportions=[0.9, 0.1, 0.55, 0.3, 0.15],
+                            factor_sampled=[True, None], interactions=[[1, 2]],
+                            effect_sizes=[0.0, 0.4, 0.5, 0.3, -0.3, 0.2], target_indices=[1, 2, 3, 5],
+                            contrast_pairs=[(3, 4), (2, 3)], correction_method=S.CorrectionMethod.Holm,
+                            factor_min_level_count=5, report_overall=True)
+    g, o = _both(engine, oracle, spec, [24, 48, 150], 3000, 5)
+    _assert_reduced_equal(g, o)
+    fx = g.factor_excluded
+    assert 0 < fx[:, 1, 0].sum() < 3000          # factor 1 sampled: mixed
+    assert (fx[:, 0, 1] == 1).all() and not fx[:, 1:, 1].any()   # factor 2 fixed: 0.15 * 24 < 5 rows only at N = 24
+    both = (fx[:, 0, 0] == 1)
+    assert both.sum() > 0 and not g.uncorrected[both][:, 0, 1:].any()
+
+
+@pytest.mark.parametrize("method", [S.CorrectionMethod.None_, S.CorrectionMethod.Bonferroni, S.CorrectionMethod.Holm,
+                                    S.CorrectionMethod.BenjaminiHochberg, S.CorrectionMethod.TukeyHsd])
+def test_posthoc_contrasts_match_oracle(engine, oracle, method):
+    spec = three_level_posthoc_spec((0.4, 0.3, 0.3), 5, method)
+    spec.effect_sizes = [0.0, 0.3, 0.5, -0.2]
+    spec.target_indices = [1, 2, 3] if method != S.CorrectionMethod.TukeyHsd else [2, 3]
+    spec.crit_values = S.CritValues(alpha=0.05, posthoc_alpha=0.1)
+    g, o = _both(engine, oracle, spec, [45, 90, 300], 3000, 21)
+    _assert_reduced_equal(g, o)
+    assert g.posthoc_unc.shape == (3000, 3, 3) and g.posthoc_unc[:, 2].mean() > g.posthoc_unc[:, 0].mean()
+    assert (g.posthoc_cor <= g.posthoc_unc).all()
+    nt = len(spec.target_indices)
+    assert g.counter("hist_unc", nt + 3 + 1).sum(axis=1).tolist() == [3000] * 3
+    assert np.array_equal(g.counter("posthoc_cor", 3), g.posthoc_cor.sum(axis=0))
+    crit = engine.build_crit_table(spec, [45, 90, 300])
+    assert np.allclose(crit, oracle.build_crit_table(spec, [45, 90, 300]), rtol=1e-9, equal_nan=True)
+
+
+def test_excluded_factor_posthoc_contrasts_report_zero(engine, oracle):
+    g, o = _both(engine, oracle, three_level_posthoc_spec(), [40, 400], 1500, 42)
+    _assert_reduced_equal(g, o)
+    assert (g.factor_excluded[:, 0, 0] == 1).all() and not g.posthoc_unc[:, 0].any()
+    assert g.posthoc_unc[:, 1].sum() > 0
+
+
+def test_two_posthoc_blocks_and_sampled_levels(engine, oracle):
+    spec = S.SimulationSpec(n_non_factor=1, n_factor_dummies=4, correlation=[1.0], var_types=[S.Distribution.Normal],
+                            var_params=[0.0], factor_n_levels=[3, 3], factor_proportions=[0.5, 0.3, 0.2, 0.4, 0.4, 0.2],
+                            effect_sizes=[0.0, 0.3, 0.5, -0.2, 0.4, 0.0], target_indices=[1],
+                            posthoc=[S.PosthocSpec(0, [2, 3]), S.PosthocSpec(1, [4, 5])],
+                            correction_method=S.CorrectionMethod.BenjaminiHochberg, factor_min_level_count=5,
+                            scenario=S.ScenarioPerturbations(name="custom", sampled_factor_proportions=True))
+    g, o = _both(engine, oracle, spec, [30, 80], 3000, 8)
+    _assert_reduced_equal(g, o)
+    assert g.shape.n_posthoc_contrasts == 6
+    fx = g.factor_excluded[:, 0, :]
+    assert 0 < fx[:, 0].sum() < 3000 and 0 < fx[:, 1].sum() < 3000
+    assert not g.posthoc_unc[fx[:, 0] == 1][:, 0, :3].any() and not g.posthoc_unc[fx[:, 1] == 1][:, 0, 3:].any()
+
+
+def test_fit_columns_subset_matches_oracle(engine, oracle):
+    spec = S.SimulationSpec(n_non_factor=3, correlation=[1.0, 0.3, 0.0, 0.3, 1.0, 0.2, 0.0, 0.2, 1.0],
+                            var_types=[S.Distribution.Normal] * 3, var_params=[0.0] * 3,
+                            effect_sizes=[0.0, 0.3, 0.5, 0.2], target_indices=[1, 3], contrast_pairs=[(1, 3)],
+                            fit_columns=[0, 1, 3], report_overall=True,
+                            correction_method=S.CorrectionMethod.Bonferroni)
+    g, o = _both(engine, oracle, spec, [60, 61, 200], 4000, 5)
+    _assert_reduced_equal(g, o)
+    full = engine.run_batch(S.SimulationSpec(**{**spec.__dict__, "fit_columns": []}), [60, 61, 200], 4000, 5)
+    assert not np.array_equal(full.uncorrected, g.uncorrected)
+
+
+def test_tukey_main_targets_on_the_hot_kernel(engine, oracle):
+    spec = three_level_posthoc_spec((0.4, 0.3, 0.3), 0, S.CorrectionMethod.TukeyHsd)
+    spec.posthoc = []
+    spec.target_indices = [1, 2, 3]
+    spec.contrast_pairs = [(3, 2)]
+    g, o = _both(engine, oracle, spec, [50, 200], 5000, 9)
+    _assert_batch_equal(g, o)
+    assert not g.corrected[:, :, 0].any() and g.corrected[:, 1, 1:].sum() > 0
+
+
+def test_exclusion_under_scenario_perturbations(engine, oracle):
+    """realistic-like preset: sampled factor proportions + correlation noise + swaps + heterogeneity."""
+    spec = S.SimulationSpec(n_non_factor=2, n_factor_dummies=2, correlation=[1.0, 0.3, 0.3, 1.0],
+                            var_types=[S.Distribution.Normal] * 2, var_params=[0.0, 0.0], factor_n_levels=[3],
+                            factor_proportions=[0.6, 0.25, 0.15], effect_sizes=[0.0, 0.3, 0.2, 0.5, 0.4],
+                            target_indices=[1, 2, 3, 4], factor_min_level_count=5, report_overall=True,
+                            posthoc=[S.PosthocSpec(0, [3, 4])], correction_method=S.CorrectionMethod.Holm,
+                            scenario=S.ScenarioPerturbations(
+                                name="realistic", heterogeneity=0.2, heteroskedasticity_ratio=2.0,
+                                correlation_noise_sd=0.15, distribution_change_prob=0.5,
+                                new_distributions=[S.Distribution.RightSkewed, S.Distribution.LeftSkewed,
+                                                   S.Distribution.Uniform],
+                                residual_change_prob=0.5,
+                                residual_dists=[S.ResidualDist.HighKurtosis, S.ResidualDist.RightSkewed],
+                                residual_df=8.0, sampled_factor_proportions=True))
+    g = engine.run_batch(spec, [30, 60, 120], 3000, 77, stat_capture=True)
+    o = oracle.run_batch(spec, [30, 60, 120], 3000, 77, stat_capture=True, n_threads=8)
+    # the general data path is pinned to <= 1e-5 one-ulp marginal mismatches (test_gpu_parity scenario tests);
+    # decisions can only differ where a statistic sits on a threshold
+    assert np.array_equal(g.factor_excluded, o.factor_excluded)
+    for f in ("uncorrected", "corrected", "posthoc_unc", "posthoc_cor", "overall", "converged"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 2e-4, f
+    assert 0 < g.factor_excluded[:, 0, 0].sum() < 3000
