@@ -36,9 +36,126 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
   return v;
 }
 
+// IRLS on the first n rows of the LDS-resident design, all lanes returning identical values.
+// MASKED: `keep` selects the fitted columns; dropped columns become identity rows/columns of X'WX and zeros of
+// X'Wz, so their coefficients stay exactly 0 and the kept block is solved by the same operations as the gathered
+// p_red x p_red system of the reference's reduced round (batch.rs:1893-1925).
+template <int P, bool MASKED>
+__device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, uint32_t n, uint32_t lane, uint32_t keep,
+                                         double (&beta)[P], double (&Lm)[P][P], double (&invd)[P], double& dev,
+                                         bool& conv) {
+  dev = __builtin_nan("");
+  double dev_prev = __builtin_inf();
+  conv = false;
+  for (int it = 0; it < MAX_IRLS_ITERS; ++it) {
+    double xtwx[P * (P + 1) / 2], xtwz[P], d = 0.0;
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) xtwx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) xtwz[i] = 0.0;
+    for (uint32_t i = lane; i < n; i += WAVE) {
+      double xd[P];
+      xd[0] = 1.0;
+#pragma unroll
+      for (int c = 1; c < P; ++c) xd[c] = (double)design[(size_t)(c - 1) * n_pad + i];
+      const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
+      double eta = 0.0;
+#pragma unroll
+      for (int c = 0; c < P; ++c) eta = __builtin_fma(xd[c], beta[c], eta);
+      const double ea = exp(-__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
+      const double inv = 1.0 / (1.0 + ea);
+      const double pr = eta >= 0.0 ? inv : ea * inv;  // stable sigmoid
+      double w = pr * (1.0 - pr);
+      w = w < W_FLOOR ? W_FLOOR : w;
+      const double z = eta + (yi - pr) / w;
+      // -2 log-likelihood of a Bernoulli observation: log p = -log1p(e^-eta), log(1-p) = -eta - log1p(e^-eta) (eta >= 0)
+      const double l1p = log1p(ea);
+      const double ll = yi > 0.5 ? (eta >= 0.0 ? -l1p : eta - l1p) : (eta >= 0.0 ? -eta - l1p : -l1p);
+      d += -2.0 * ll;
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        const double wxa = w * xd[a];
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          xtwx[idx] = __builtin_fma(wxa, xd[b], xtwx[idx]);
+          ++idx;
+        }
+        xtwz[a] = __builtin_fma(wxa, z, xtwz[a]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) xtwx[i] = wave_allreduce_sum(xtwx[i]);
+#pragma unroll
+    for (int i = 0; i < P; ++i) xtwz[i] = wave_allreduce_sum(xtwz[i]);
+    dev = wave_allreduce_sum(d);
+    if (!(dev < __builtin_inf())) break;  // NaN / inf deviance
+    const bool done = it > 0 && __builtin_fabs(dev - dev_prev) / (__builtin_fabs(dev) + 0.1) < IRLS_EPS;
+    // Cholesky of X'WX and the weighted least-squares update (all lanes, identical values)
+    bool ok = true;
+    {
+      int idx = 0;
+      double A[P][P];
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          const double v = xtwx[idx++];
+          A[a][b] = (!MASKED || (((keep >> a) & 1u) && ((keep >> b) & 1u))) ? v : (a == b ? 1.0 : 0.0);
+        }
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        double dd = A[j][j];
+#pragma unroll
+        for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lm[j][t], Lm[j][t], dd);
+        ok = ok && (dd > 0.0) && (dd < __builtin_inf());
+        const double ljj = __builtin_sqrt(dd);
+        Lm[j][j] = ljj;
+        invd[j] = 1.0 / ljj;
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+          double v = A[i][j];
+#pragma unroll
+          for (int t = 0; t < j; ++t) v = __builtin_fma(-Lm[i][t], Lm[j][t], v);
+          Lm[i][j] = v * invd[j];
+        }
+      }
+    }
+    if (!ok) break;
+    if (done) {
+      conv = true;
+      break;
+    }
+    double zf[P], nb[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      double v = (!MASKED || ((keep >> i) & 1u)) ? xtwz[i] : 0.0;
+#pragma unroll
+      for (int t = 0; t < i; ++t) v = __builtin_fma(-Lm[i][t], zf[t], v);
+      zf[i] = v * invd[i];
+    }
+    bool capped = false;
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) {
+      double v = zf[i];
+#pragma unroll
+      for (int t = i + 1; t < P; ++t) v = __builtin_fma(-Lm[t][i], nb[t], v);
+      nb[i] = v * invd[i];
+      capped = capped || !(__builtin_fabs(nb[i]) <= BETA_CAP);
+    }
+    if (capped) break;
+#pragma unroll
+    for (int i = 0; i < P; ++i) beta[i] = nb[i];
+    dev_prev = dev;
+  }
+}
+
 // LDS layout per block (one wave): design[c][row] for columns x1..x_{P-1} then y[row] (stride n_pad),
 // followed by the 4-row staging area [slot][lane] of stage_group.
-template <int P, bool FACTORS>
+// RED: sparse-factor exclusion recounted from rows [0, N) at every grid point (batch.rs:1836-1853), reduced
+// fits, and the separation fallback -- when attempt 0 does not converge, drop the included factor with the
+// smallest minimum level count (code 2) and refit once from a cold start (:1976-2030).
+template <int P, bool FACTORS, bool RED>
 __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ float lds[];
   const SimParams& prm = *pp;
@@ -75,10 +192,6 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
   const uint32_t nt = prm.n_tests;
   for (uint32_t g = 0; g < prm.n_grid; ++g) {
     const uint32_t n = prm.ns[g];
-    // ---- IRLS from the truth start (batch.rs:1945-1951) ----
-    double beta[P];
-#pragma unroll
-    for (int c = 0; c < P; ++c) beta[c] = prm.beta[c];
     double sum_y = 0.0;
     for (uint32_t i = lane; i < n; i += WAVE) sum_y += (double)design[(size_t)(P - 1) * n_pad + i];
     sum_y = wave_allreduce_sum(sum_y);
@@ -86,106 +199,63 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
     const double pbar = sum_y / nd;
     const double dev_null = (pbar > 0.0 && pbar < 1.0) ? -2.0 * (sum_y * log(pbar) + (nd - sum_y) * log(1.0 - pbar)) : 0.0;
 
-    double Lm[P][P], invd[P];
-    double dev = __builtin_nan(""), dev_prev = __builtin_inf();
-    bool conv = false;
-    for (int it = 0; it < MAX_IRLS_ITERS; ++it) {
-      double xtwx[P * (P + 1) / 2], xtwz[P], d = 0.0;
+    double beta[P], Lm[P][P], invd[P];
+    double dev;
+    bool conv;
+    uint32_t keep = (1u << P) - 1u, codes = 0;  // codes: 2 bits per factor (0 kept, 1 sparse, 2 separation)
+    if (RED) {
+      uint32_t fmin[MAX_FACTORS] = {0u, 0u, 0u, 0u};
+      uint32_t flag_bits = 0;
+      if (prm.min_level_count) {  // update_factor_exclusions (batch.rs:2451-2500), rows [0, n)
 #pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) xtwx[i] = 0.0;
+        for (int f = 0; f < MAX_FACTORS; ++f) {
+          if ((uint32_t)f < prm.n_factors) {
+            uint32_t mn = 0xffffffffu;
+            for (uint32_t l = 0; l < prm.f_levels[f]; ++l) {
+              uint32_t cnt = 0;
+              for (uint32_t i = lane; i < n; i += WAVE) {
+                uint32_t lv = 0;
 #pragma unroll
-      for (int i = 0; i < P; ++i) xtwz[i] = 0.0;
-      for (uint32_t i = lane; i < n; i += WAVE) {
-        double xd[P];
-        xd[0] = 1.0;
+                for (int c = 1; c < P; ++c)
+                  if (prm.col_factor[c] == (uint32_t)f && design[(size_t)(c - 1) * n_pad + i] == 1.0f) lv = prm.col_level[c];
+                cnt += lv == l ? 1u : 0u;
+              }
 #pragma unroll
-        for (int c = 1; c < P; ++c) xd[c] = (double)design[(size_t)(c - 1) * n_pad + i];
-        const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
-        double eta = 0.0;
-#pragma unroll
-        for (int c = 0; c < P; ++c) eta = __builtin_fma(xd[c], beta[c], eta);
-        const double ea = exp(-__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
-        const double inv = 1.0 / (1.0 + ea);
-        const double pr = eta >= 0.0 ? inv : ea * inv;  // stable sigmoid
-        double w = pr * (1.0 - pr);
-        w = w < W_FLOOR ? W_FLOOR : w;
-        const double z = eta + (yi - pr) / w;
-        // -2 log-likelihood of a Bernoulli observation: log p = -log1p(e^-eta), log(1-p) = -eta - log1p(e^-eta) (eta >= 0)
-        const double l1p = log1p(ea);
-        const double ll = yi > 0.5 ? (eta >= 0.0 ? -l1p : eta - l1p) : (eta >= 0.0 ? -eta - l1p : -l1p);
-        d += -2.0 * ll;
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < P; ++a) {
-          const double wxa = w * xd[a];
-#pragma unroll
-          for (int b = 0; b <= a; ++b) {
-            xtwx[idx] = __builtin_fma(wxa, xd[b], xtwx[idx]);
-            ++idx;
-          }
-          xtwz[a] = __builtin_fma(wxa, z, xtwz[a]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) xtwx[i] = wave_allreduce_sum(xtwx[i]);
-#pragma unroll
-      for (int i = 0; i < P; ++i) xtwz[i] = wave_allreduce_sum(xtwz[i]);
-      dev = wave_allreduce_sum(d);
-      if (!(dev < __builtin_inf())) break;  // NaN / inf deviance
-      const bool done = it > 0 && __builtin_fabs(dev - dev_prev) / (__builtin_fabs(dev) + 0.1) < IRLS_EPS;
-      // Cholesky of X'WX and the weighted least-squares update (all lanes, identical values)
-      bool ok = true;
-      {
-        int idx = 0;
-        double A[P][P];
-#pragma unroll
-        for (int a = 0; a < P; ++a)
-#pragma unroll
-          for (int b = 0; b <= a; ++b) A[a][b] = xtwx[idx++];
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-          double dd = A[j][j];
-#pragma unroll
-          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lm[j][t], Lm[j][t], dd);
-          ok = ok && (dd > 0.0) && (dd < __builtin_inf());
-          const double ljj = __builtin_sqrt(dd);
-          Lm[j][j] = ljj;
-          invd[j] = 1.0 / ljj;
-#pragma unroll
-          for (int i = j + 1; i < P; ++i) {
-            double v = A[i][j];
-#pragma unroll
-            for (int t = 0; t < j; ++t) v = __builtin_fma(-Lm[i][t], Lm[j][t], v);
-            Lm[i][j] = v * invd[j];
+              for (int m = 1; m < WAVE; m <<= 1) cnt += __shfl_xor(cnt, m, WAVE);
+              mn = cnt < mn ? cnt : mn;
+            }
+            fmin[f] = mn;
+            if (mn < prm.min_level_count) {
+              flag_bits |= 1u << f;
+              codes |= 1u << (2 * f);
+            }
           }
         }
       }
-      if (!ok) break;
-      if (done) {
-        conv = true;
-        break;
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        keep = prm.keep_mask[flag_bits & 15u];
+#pragma unroll
+        for (int c = 0; c < P; ++c) beta[c] = (attempt == 0 && ((keep >> c) & 1u)) ? prm.beta[c] : 0.0;
+        irls_fit<P, true>(design, n_pad, n, lane, keep, beta, Lm, invd, dev, conv);
+        if (conv || attempt == 1 || prm.min_level_count == 0u) break;
+        int drop = -1;  // included_factor_with_smallest_min_count (batch.rs:2573-2600)
+        uint32_t best = 0;
+#pragma unroll
+        for (int f = 0; f < MAX_FACTORS; ++f)
+          if ((uint32_t)f < prm.n_factors && !((flag_bits >> f) & 1u) && (drop < 0 || fmin[f] < best)) {
+            drop = f;
+            best = fmin[f];
+          }
+        if (drop < 0) break;
+        flag_bits |= 1u << drop;
+        codes |= 2u << (2 * drop);
       }
-      double zf[P], nb[P];
+      codes |= flag_bits << 16;
+    } else {
+      // ---- IRLS from the truth start (batch.rs:1945-1951) ----
 #pragma unroll
-      for (int i = 0; i < P; ++i) {
-        double v = xtwz[i];
-#pragma unroll
-        for (int t = 0; t < i; ++t) v = __builtin_fma(-Lm[i][t], zf[t], v);
-        zf[i] = v * invd[i];
-      }
-      bool capped = false;
-#pragma unroll
-      for (int i = P - 1; i >= 0; --i) {
-        double v = zf[i];
-#pragma unroll
-        for (int t = i + 1; t < P; ++t) v = __builtin_fma(-Lm[t][i], nb[t], v);
-        nb[i] = v * invd[i];
-        capped = capped || !(__builtin_fabs(nb[i]) <= BETA_CAP);
-      }
-      if (capped) break;
-#pragma unroll
-      for (int i = 0; i < P; ++i) beta[i] = nb[i];
-      dev_prev = dev;
+      for (int c = 0; c < P; ++c) beta[c] = prm.beta[c];
+      irls_fit<P, false>(design, n_pad, n, lane, keep, beta, Lm, invd, dev, conv);
     }
 
     // ---- Wald z^2 per target (cov = (X'WX)^-1), decisions, LRT overall ----
@@ -194,7 +264,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
 #pragma unroll
     for (int t = 0; t < MAX_T; ++t) {
       tsq[t] = __builtin_nan("");
-      if ((uint32_t)t < nt && conv) {
+      if ((uint32_t)t < nt && conv && (!RED || ((keep >> prm.test_pos[t]) & 1u))) {
         const double* c = prm.contrast + t * MAX_P;
         double est = 0.0, nq = 0.0, u[P];
 #pragma unroll
@@ -217,8 +287,11 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
     }
     bool ov = false;
     if (prm.report_overall && conv && dev < __builtin_inf() && dev_null < __builtin_inf()) {
+      double crit_overall = crow[3 + nt];
+      if (RED)  // LRT df follows the fitted column count (batch.rs:2096-2113)
+        crit_overall = prm.crit_red[(size_t)prm.red_row[(size_t)g * 16u + ((codes >> 16) & 15u)] * prm.crit_stride + 3 + nt];
       const double lrt = dev_null - dev;
-      ov = (lrt < __builtin_inf()) && (lrt > crow[3 + nt]);
+      ov = (lrt < __builtin_inf()) && (lrt > crit_overall);
     }
     if (lane == 0) {  // the wave's replicate: one writer
       const size_t cell = (size_t)out_row * prm.n_grid + g;
@@ -235,6 +308,9 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
         for (int t = 0; t < MAX_T; ++t)
           if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
       }
+      if (RED && prm.factor_excluded)
+        for (uint32_t f = 0; f < prm.n_factors; ++f)
+          prm.factor_excluded[cell * prm.n_factors + f] = (uint8_t)((codes >> (2 * f)) & 3u);
     }
   }
 }
@@ -333,18 +409,18 @@ size_t glm_lds_bytes(int P, uint32_t max_n) {
   return ((size_t)P * n_pad + (size_t)4 * P * WAVE) * sizeof(float);
 }
 
-template <bool FACTORS>
+template <bool FACTORS, bool RED>
 static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, hipStream_t st) {
   const size_t lds = glm_lds_bytes(P, max_n);
   const dim3 block(WAVE), grid(n_sims);
 #define LG(PP)                                                                                                        \
   case PP: {                                                                                                          \
     if (lds > 48 * 1024) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS>,                                    \
+      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS, RED>,                               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
       if (e != hipSuccess) return e;                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS>), grid, block, lds, st, d_prm);                                   \
+    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS, RED>), grid, block, lds, st, d_prm);                              \
   } break;
   switch (P) {
     LG(2) LG(3) LG(4) LG(5) LG(6) LG(7) LG(8)
@@ -354,8 +430,11 @@ static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
   return hipGetLastError();
 }
 
-hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, hipStream_t st) {
-  return factors ? launch_glm_f<true>(P, d_prm, n_sims, max_n, st) : launch_glm_f<false>(P, d_prm, n_sims, max_n, st);
+hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
+                          hipStream_t st) {
+  if (reduced) return launch_glm_f<true, true>(P, d_prm, n_sims, max_n, st);
+  return factors ? launch_glm_f<true, false>(P, d_prm, n_sims, max_n, st)
+                 : launch_glm_f<false, false>(P, d_prm, n_sims, max_n, st);
 }
 
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {

@@ -30,11 +30,12 @@ hipError_t launch_ols_fit_provided(int P, const float* design, const float* outc
                                    double* beta, double* se, double* tsq, double* rss, double* sst, uint8_t* conv,
                                    hipStream_t st);
 hipError_t launch_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out, hipStream_t st);
-hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, hipStream_t st);
+hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
+                          hipStream_t st);
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
 size_t glm_lds_bytes(int P, uint32_t max_n);
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
-                          hipStream_t st);
+                          bool reduced, hipStream_t st);
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st);
@@ -190,6 +191,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   const bool mle = spec->estimator == MCP_EST_MLE;
   const bool glm = spec->estimator == MCP_EST_GLM || mle;  // wave-per-replicate kernels + flag fold
   const bool reduced = prm.red_active && !glm;             // reduced-design OLS kernel, flags folded afterwards
+  const bool glm_reduced = prm.red_active && glm;          // RED variants of the wave-per-replicate kernels
   if (reduced && (flags & MCP_PIPELINE_STAGED))
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds");
   const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
@@ -259,7 +261,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   uint8_t *d_ph_unc = nullptr, *d_ph_cor = nullptr, *d_fx = nullptr;
   double* d_crit_red = nullptr;
   uint16_t* d_red_row = nullptr;
-  if (reduced) {
+  if (reduced || glm_reduced) {
     if (npc) {
       DEV_TRY(ar.get(S_PH_UNC, cells * npc + 1, (void**)&d_ph_unc));
       DEV_TRY(ar.get(S_PH_COR, cells * npc + 1, (void**)&d_ph_cor));
@@ -306,7 +308,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(hipMemcpyAsync(d_crit, low.crit.data(), low.crit.size() * sizeof(double), hipMemcpyHostToDevice, st));
   DEV_TRY(hipMemcpyAsync(d_levels, low.fixed_levels.data(), low.fixed_levels.size(), hipMemcpyHostToDevice, st));
   DEV_TRY(hipMemsetAsync(d_ctr, 0, ctr_words * sizeof(uint64_t), st));
-  if (reduced) {
+  if (reduced || glm_reduced) {
     DEV_TRY(hipMemcpyAsync(d_crit_red, low.crit_red.data(), low.crit_red.size() * sizeof(double), hipMemcpyHostToDevice, st));
     DEV_TRY(hipMemcpyAsync(d_red_row, low.red_row.data(), low.red_row.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
   }
@@ -356,8 +358,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, st));
-      else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, st));
+      if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, st));
+      else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
@@ -410,7 +412,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
       out->posthoc_unc = (uint8_t*)std::calloc(cells * npc + 1, 1);
       out->posthoc_cor = (uint8_t*)std::calloc(cells * npc + 1, 1);
     }
-    if (reduced) {
+    if (reduced || glm_reduced) {
       if (spec->n_factors) DEV_TRY(hipMemcpyAsync(out->factor_excluded, d_fx, cells * spec->n_factors, hipMemcpyDeviceToHost, st));
       if (npc) {
         DEV_TRY(hipMemcpyAsync(out->posthoc_unc, d_ph_unc, cells * npc, hipMemcpyDeviceToHost, st));

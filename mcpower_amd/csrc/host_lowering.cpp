@@ -9,6 +9,7 @@
 // the correlation, identical for every replicate on the optimistic path), and
 // batch.rs:2334-2407 (critical-value tables).
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <string>
 
@@ -551,8 +552,10 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       }
   }
   prm.red_active = (npc > 0 || test_reduces || any_excl_possible) ? 1u : 0u;
-  if (prm.red_active && spec->estimator != MCP_EST_OLS)
-    return unsupported("sparse-factor exclusion / test_formula reduced fits under Glm / Mle (OLS only so far)");
+  if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))
+    return unsupported("intercept-free reduced fit under Glm / Mle");
+  for (uint32_t k = 0; k <= (uint32_t)MAX_T; ++k)
+    prm.joint_crit_k[k] = k == 0 ? std::numeric_limits<double>::infinity() : chi2_ppf(1.0 - spec->alpha, (double)k);
   low.P = P;
   low.n_tests = nt;
   return MCP_OK;

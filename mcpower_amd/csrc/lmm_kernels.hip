@@ -45,10 +45,12 @@ struct LmmEval {
 };
 
 // dev(theta) and the REML solution at theta; csum = LDS [cluster][P+1] = {n_c, Sx_1..Sx_{P-1}, Sy}
-template <int P>
+// MASKED: `keep` selects the fitted columns (identity rows/columns of X'V^-1X at the dropped ones, zero
+// right-hand side), df = n - popcount(keep): the reduced-design round of batch.rs:1252-1394.
+template <int P, bool MASKED = false>
 __device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2], const double (&xty)[P], double yty,
                                              const double* csum, uint32_t ncl, uint32_t n, double theta,
-                                             LmmEval<P>& e) {
+                                             LmmEval<P>& e, uint32_t keep = 0xffffffffu) {
   const uint32_t lane = threadIdx.x;
   const double th2 = theta * theta;
   double dA[P * (P + 1) / 2], db[P], dyy = 0.0, ldv = 0.0;
@@ -88,10 +90,12 @@ __device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2
     for (int a = 0; a < P; ++a) {
 #pragma unroll
       for (int q = 0; q <= a; ++q) {
-        A[a][q] = xtx[idx] - lwave_sum(dA[idx]);
+        const double v = xtx[idx] - lwave_sum(dA[idx]);
+        A[a][q] = (!MASKED || (((keep >> a) & 1u) && ((keep >> q) & 1u))) ? v : (a == q ? 1.0 : 0.0);
         ++idx;
       }
-      b[a] = xty[a] - lwave_sum(db[a]);
+      const double bv = xty[a] - lwave_sum(db[a]);
+      b[a] = (!MASKED || ((keep >> a) & 1u)) ? bv : 0.0;
     }
   }
   const double yy = yty - lwave_sum(dyy);
@@ -137,7 +141,7 @@ __device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2
   double bxy = 0.0;
 #pragma unroll
   for (int i = 0; i < P; ++i) bxy = __builtin_fma(e.beta[i], b[i], bxy);
-  const double df = (double)n - (double)P;
+  const double df = (double)n - (MASKED ? (double)__popc(keep & ((1u << P) - 1u)) : (double)P);
   e.sigma_sq = (yy - bxy) / df;
   if (!(e.sigma_sq > 0.0) || !(e.sigma_sq < __builtin_inf())) return;
   e.dev = logdetv + logdetA + df * log(e.sigma_sq);
@@ -146,7 +150,10 @@ __device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2
 
 // LDS layout per block (one wave): design [P columns: x1..x_{P-1}, y][n_pad] f32 | cluster_u [ncl_pad] f32 |
 // csum [ncl_max][P+1] f64 | staging [4P][64] f32
-template <int P, bool FACTORS>
+// RED: exclusion flags recounted from rows [0, N) before every fit (batch.rs:1236-1250); a reduced round fits the
+// kept columns, never feeds the grid-sequential theta carry (:1414-1428) and runs the joint Wald over the kept
+// targets against chi2(k_red) (:1456-1468).
+template <int P, bool FACTORS, bool RED>
 __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
@@ -247,6 +254,34 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
     yty = lwave_sum(yty);
     __syncthreads();
 
+    uint32_t keep = (1u << P) - 1u, flag_bits = 0;
+    if (RED) {
+      if (prm.min_level_count) {  // update_factor_exclusions (batch.rs:2451-2500), rows [0, n)
+#pragma unroll
+        for (int f = 0; f < MAX_FACTORS; ++f) {
+          if ((uint32_t)f < prm.n_factors) {
+            uint32_t mn = 0xffffffffu;
+            for (uint32_t l = 0; l < prm.f_levels[f]; ++l) {
+              uint32_t cnt = 0;
+              for (uint32_t i = lane; i < n; i += LWAVE) {
+                uint32_t lv = 0;
+#pragma unroll
+                for (int c = 1; c < P; ++c)
+                  if (prm.col_factor[c] == (uint32_t)f && design[(size_t)(c - 1) * n_pad + i] == 1.0f) lv = prm.col_level[c];
+                cnt += lv == l ? 1u : 0u;
+              }
+#pragma unroll
+              for (int m = 1; m < LWAVE; m <<= 1) cnt += __shfl_xor(cnt, m, LWAVE);
+              mn = cnt < mn ? cnt : mn;
+            }
+            if (mn < prm.min_level_count) flag_bits |= 1u << f;
+          }
+        }
+      }
+      keep = prm.keep_mask[flag_bits & 15u];
+    }
+    const bool reduced_round = RED && keep != ((1u << P) - 1u);
+
     // ---- Brent's minimiser of dev(theta) on [0, THETA_MAX] (fmin), first probe at the start value ----
     double start = has_prev ? theta_carry : (prm.truth_start ? prm.tau : THETA_BLIND);
     start = start < 0.01 ? 0.01 : start;  // THETA_TRUTH_FLOOR (batch.rs:1316-1321)
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
     x = (x > a + 1e-3) ? x : a + 1e-3;
     x = (x < b - 1e-3) ? x : b - 1e-3;
     double w = x, v = x, e = 0.0, dstep = 0.0;
-    lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, x, ev);
+    lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, x, ev, keep);
     double fx = ev.dev, fw = fx, fv = fx;
     for (int it = 0; it < BRENT_MAX_ITERS; ++it) {
       const double xm = 0.5 * (a + b);
@@ -285,7 +320,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
         dstep = CGOLD * e;
       }
       const double u = __builtin_fabs(dstep) >= tol1 ? x + dstep : x + (dstep >= 0.0 ? tol1 : -tol1);
-      lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, u, ev);
+      lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, u, ev, keep);
       const double fu = ev.dev;
       if (fu <= fx) {
         if (u >= x) a = x; else b = x;
@@ -298,19 +333,19 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
     }
     // the interior search never evaluates theta = 0: compare with the boundary value
     double th = x;
-    lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, 0.0, ev);
+    lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, 0.0, ev, keep);
     const bool at0_ok = ev.ok;
     const double dev0 = ev.dev;
     const bool interior_ok = fx < __builtin_inf() && fx > -__builtin_inf();
     if (at0_ok && (!interior_ok || dev0 <= fx || th < THETA_ZERO)) {
       th = 0.0;  // ev already holds the theta = 0 solution
     } else {
-      lmm_evaluate<P>(xtx, xty, yty, csum, ncl, n, th, ev);
+      lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, th, ev, keep);
     }
     bool conv = ev.ok;
     const uint32_t bh = !ev.ok ? 0u : (th < THETA_ZERO ? 1u : (th > THETA_MAX - 1e-3 ? 2u : 0u));
     if (bh == 2u) conv = false;
-    if (conv) {
+    if (conv && !reduced_round) {
       theta_carry = th;
       has_prev = true;
     }
@@ -319,12 +354,16 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
     const double* crow = prm.crit + (size_t)g * prm.crit_stride;
     double tsq[MAX_T];
     double U[MAX_T][P];  // L^-1 c_t
+    uint32_t tkeep = 0;  // targets whose column is fitted
+#pragma unroll
+    for (int t = 0; t < MAX_T; ++t)
+      if ((uint32_t)t < nt && (!RED || ((keep >> prm.test_pos[t]) & 1u))) tkeep |= 1u << t;
 #pragma unroll
     for (int t = 0; t < MAX_T; ++t) {
       tsq[t] = __builtin_nan("");
 #pragma unroll
       for (int i = 0; i < P; ++i) U[t][i] = 0.0;
-      if ((uint32_t)t < nt && conv) {
+      if (((tkeep >> t) & 1u) && conv) {
         const double* c = prm.contrast + t * MAX_P;
         double est = 0.0, nq = 0.0;
 #pragma unroll
@@ -342,13 +381,18 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
     }
     // joint: b_T' Cov_TT^-1 b_T with Cov_ab = sigma^2 U_a.U_b (Cholesky of the nt x nt block)
     bool joint_sig = false;
-    if (conv && nt > 0) {
+    if (conv && tkeep != 0u) {
       double Lc[MAX_T][MAX_T], cj[MAX_T];
       bool jok = true;
       double qsum = 0.0;
 #pragma unroll
       for (int j = 0; j < MAX_T; ++j) {
-        if ((uint32_t)j < nt) {
+        if ((uint32_t)j < nt && !((tkeep >> j) & 1u)) {  // untestable target: identity row, no contribution
+          Lc[j][j] = 1.0;
+#pragma unroll
+          for (int i2 = j + 1; i2 < MAX_T; ++i2) Lc[i2][j] = 0.0;
+        }
+        if ((tkeep >> j) & 1u) {
           double dd = 0.0;
 #pragma unroll
           for (int i = 0; i < P; ++i) dd = __builtin_fma(U[j][i], U[j][i], dd);
@@ -360,7 +404,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
 #pragma unroll
           for (int i2 = j + 1; i2 < MAX_T; ++i2) {
             if ((uint32_t)i2 < nt) {
-              double vv = 0.0;
+              double vv = 0.0;  // U of an untestable target is all zeros
 #pragma unroll
               for (int i = 0; i < P; ++i) vv = __builtin_fma(U[i2][i], U[j][i], vv);
               vv *= ev.sigma_sq;
@@ -377,14 +421,16 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
           const double* c = prm.contrast + i * MAX_P;
           double vv = 0.0;
 #pragma unroll
-          for (int q = 0; q < P; ++q) vv = __builtin_fma(c[q], ev.beta[q], vv);
+          for (int q = 0; q < P; ++q) vv = __builtin_fma(((tkeep >> i) & 1u) ? c[q] : 0.0, ev.beta[q], vv);
 #pragma unroll
           for (int t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i][t], cj[t], vv);
           cj[i] = vv / Lc[i][i];
           qsum = __builtin_fma(cj[i], cj[i], qsum);
         }
       }
-      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > crow[2 + nt]);
+      // the full table row holds chi2(n_targets); a reduced round tests its k_red kept targets (batch.rs:1456-1468)
+      const double joint_crit = reduced_round ? prm.joint_crit_k[__popc(tkeep)] : crow[2 + nt];
+      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > joint_crit);
     }
     uint32_t unc_bits = 0, cor_bits = 0;
     decide_tests(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
@@ -403,6 +449,9 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
       prm.conv[cell] = conv ? 1 : 0;
       prm.boundary[cell] = (uint8_t)bh;
       prm.joint[cell] = joint_sig ? 1 : 0;
+      if (RED && prm.factor_excluded)
+        for (uint32_t f = 0; f < prm.n_factors; ++f)
+          prm.factor_excluded[cell * prm.n_factors + f] = (uint8_t)((flag_bits >> f) & 1u);
       if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1449-1451
       if (prm.stat && g == 0) {
 #pragma unroll
@@ -420,7 +469,7 @@ size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max) {
   return (size_t)ncl_max * (P + 1) * sizeof(double) + ((size_t)P * n_pad + ncl_pad + (size_t)4 * P * LWAVE) * sizeof(float);
 }
 
-template <bool FACTORS>
+template <bool FACTORS, bool RED>
 static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max,
                                hipStream_t st) {
   const size_t lds = lmm_lds_bytes(P, max_n, ncl_max);
@@ -428,11 +477,11 @@ static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
 #define LL(PP)                                                                                                        \
   case PP: {                                                                                                          \
     if (lds > 48 * 1024) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void*)lmm_sim_kernel<PP, FACTORS>,                                    \
+      hipError_t e = hipFuncSetAttribute((const void*)lmm_sim_kernel<PP, FACTORS, RED>,                               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
       if (e != hipSuccess) return e;                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((lmm_sim_kernel<PP, FACTORS>), grid, block, lds, st, d_prm);                                   \
+    hipLaunchKernelGGL((lmm_sim_kernel<PP, FACTORS, RED>), grid, block, lds, st, d_prm);                              \
   } break;
   switch (P) {
     LL(2) LL(3) LL(4) LL(5) LL(6)
@@ -443,9 +492,10 @@ static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
 }
 
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
-                          hipStream_t st) {
-  return factors ? launch_lmm_f<true>(P, d_prm, n_sims, max_n, ncl_max, st)
-                 : launch_lmm_f<false>(P, d_prm, n_sims, max_n, ncl_max, st);
+                          bool reduced, hipStream_t st) {
+  if (reduced) return launch_lmm_f<true, true>(P, d_prm, n_sims, max_n, ncl_max, st);
+  return factors ? launch_lmm_f<true, false>(P, d_prm, n_sims, max_n, ncl_max, st)
+                 : launch_lmm_f<false, false>(P, d_prm, n_sims, max_n, ncl_max, st);
 }
 
 }  // namespace mcp

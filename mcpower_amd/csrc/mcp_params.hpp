@@ -132,6 +132,7 @@ struct SimParams {
   uint8_t* posthoc_cor;
   uint8_t* factor_excluded;        // [n_sims_total][n_grid][n_factors] or null
   uint32_t ctr_posthoc_unc, ctr_posthoc_cor, ctr_excl_sparse, ctr_excl_sep;
+  double joint_crit_k[MAX_T + 1];  // chi2_ppf(1 - alpha, k): joint Wald threshold over k kept targets (Mle arm)
 
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;

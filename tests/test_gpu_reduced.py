@@ -21,7 +21,15 @@ def _both(engine, oracle, spec, ns, n_sims, seed=BASE_SEED, **kw):
     return g, o
 
 
-def _assert_reduced_equal(g, o):
+def _assert_reduced_equal(g, o, iterative=False):
+    """`iterative`: IRLS statistics carry the stopping rule's slack (deviance change < 1e-8): z^2 is compared at
+    1e-7 relative + 1e-9 absolute there, decisions and counters stay exact."""
+    if iterative:
+        a, b = g.stat_capture, o.stat_capture
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        m = ~np.isnan(a)
+        assert np.all(np.abs(a[m] - b[m]) <= 1e-7 * np.abs(b[m]) + 1e-9)
+        g.stat_capture = o.stat_capture = None
     _assert_batch_equal(g, o)
     for f in ("factor_excluded", "posthoc_unc", "posthoc_cor"):
         ga, oa = getattr(g, f), getattr(o, f)
@@ -166,3 +174,89 @@ def test_exclusion_under_scenario_perturbations(engine, oracle):
     for f in ("uncorrected", "corrected", "posthoc_unc", "posthoc_cor", "overall", "converged"):
         assert (getattr(g, f) != getattr(o, f)).mean() < 2e-4, f
     assert 0 < g.factor_excluded[:, 0, 0].sum() < 3000
+
+
+# ---------------------------------------------------------------------------------------------
+# GLM / MLE arms
+# ---------------------------------------------------------------------------------------------
+def _glm_factor_spec(effects, props, min_count=5, **kw):
+    s = S.SimulationSpec(n_non_factor=1, n_factor_dummies=len(props) - 1, correlation=[1.0],
+                         var_types=[S.Distribution.Normal], var_params=[0.0], factor_n_levels=[len(props)],
+                         factor_proportions=list(props), effect_sizes=list(effects),
+                         target_indices=list(range(1, len(effects))), outcome_kind=S.OutcomeKind.Binary,
+                         estimator=S.EstimatorSpec.Glm, report_overall=True, factor_min_level_count=min_count)
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def test_glm_sparse_exclusion_and_overall_df(engine, oracle):
+    spec = _glm_factor_spec([math.log(0.3 / 0.7), 0.5, 0.8], [0.9, 0.1])
+    g, o = _both(engine, oracle, spec, [30, 200], 2000, 13)
+    _assert_reduced_equal(g, o, iterative=True)
+    assert (g.factor_excluded[:, 0, 0] == 1).all() and not g.uncorrected[:, 0, 1].any()
+    assert g.overall[:, 0].sum() > 0
+    spec = _glm_factor_spec([math.log(0.3 / 0.7), 0.5, 0.8, -0.4], [0.5, 0.3, 0.2], factor_sampled=[True],
+                            correction_method=S.CorrectionMethod.Holm)
+    g, o = _both(engine, oracle, spec, [25, 50, 120], 2000, 14)
+    _assert_reduced_equal(g, o, iterative=True)
+    assert 0 < (g.factor_excluded[:, 0, 0] == 1).sum() < 2000
+
+
+def test_glm_separation_fallback_codes_match_oracle(engine, oracle):
+    spec = _glm_factor_spec([0.0, 2.0, 6.0], [0.6, 0.4])
+    g, o = _both(engine, oracle, spec, [20, 40], 3000, 13)
+    _assert_reduced_equal(g, o, iterative=True)
+    sep = g.factor_excluded[:, 0, 0] == 2
+    assert 100 < sep.sum() < 2500 and g.converged[sep, 0].mean() > 0.9
+    assert g.counter("excl_sep", 1)[0, 0] == sep.sum() and g.counter("excl_sparse", 1)[0, 0] == 0
+    off = engine.run_batch(S.SimulationSpec(**{**spec.__dict__, "factor_min_level_count": 0}), [20, 40], 3000, 13)
+    assert off.converged.sum() < g.converged.sum() and not off.factor_excluded.any()
+    assert np.array_equal(off.uncorrected[~sep, 0], g.uncorrected[~sep, 0])
+    # two factors: the fallback drops the included factor with the smallest minimum level count
+    spec = S.SimulationSpec(n_non_factor=1, n_factor_dummies=2, correlation=[1.0], var_types=[S.Distribution.Normal],
+                            var_params=[0.0], factor_n_levels=[2, 2], factor_proportions=[0.5, 0.5, 0.7, 0.3],
+                            effect_sizes=[0.0, 1.5, 1.0, 6.0], target_indices=[1, 2, 3],
+                            outcome_kind=S.OutcomeKind.Binary, estimator=S.EstimatorSpec.Glm, report_overall=True,
+                            factor_min_level_count=5)
+    g, o = _both(engine, oracle, spec, [24], 3000, 15)
+    _assert_reduced_equal(g, o, iterative=True)
+    fx = g.factor_excluded[:, 0, :]
+    assert (fx[:, 1] == 2).sum() > 0 and not (fx[:, 0] == 2).any()   # factor 2 has the smaller minimum count (7 vs 12)
+
+
+def test_glm_fit_columns_subset(engine, oracle):
+    spec = S.SimulationSpec(n_non_factor=3, correlation=np.eye(3).ravel().tolist(),
+                            var_types=[S.Distribution.Normal] * 3, var_params=[0.0] * 3,
+                            effect_sizes=[math.log(0.4 / 0.6), 0.5, 0.6, 0.3], target_indices=[1, 3],
+                            fit_columns=[0, 1, 3], outcome_kind=S.OutcomeKind.Binary,
+                            estimator=S.EstimatorSpec.Glm, report_overall=True)
+    g, o = _both(engine, oracle, spec, [80, 160], 2000, 16)
+    _assert_reduced_equal(g, o, iterative=True)
+
+
+def test_lmm_exclusion_reduces_fit_and_joint_test(engine, oracle):
+    spec = S.SimulationSpec(n_non_factor=1, n_factor_dummies=1, correlation=[1.0], var_types=[S.Distribution.Normal],
+                            var_params=[0.0], factor_n_levels=[2], factor_proportions=[0.95, 0.05],
+                            effect_sizes=[0.0, 0.4, 0.6], target_indices=[1, 2], estimator=S.EstimatorSpec.Mle,
+                            cluster=S.ClusterSpec(sizing=("FixedClusters", 8), tau_squared=0.2),
+                            factor_min_level_count=5,
+                            scenario=S.ScenarioPerturbations(name="optimistic", truth_start=True))
+    g = engine.run_batch(spec, [40, 80, 240], 1500, 17, stat_capture=True)
+    o = oracle.run_batch(spec, [40, 80, 240], 1500, 17, stat_capture=True, n_threads=8)
+    assert np.array_equal(g.factor_excluded, o.factor_excluded)
+    assert (g.factor_excluded[:, 0, 0] == 1).all() and not g.factor_excluded[:, 2, 0].any()
+    assert np.array_equal(np.isnan(g.stat_capture), np.isnan(o.stat_capture))
+    m = ~np.isnan(o.stat_capture)
+    assert np.max(np.abs(g.stat_capture[m] - o.stat_capture[m]) / np.maximum(o.stat_capture[m], 1e-12)) < 1e-4
+    for f in ("uncorrected", "corrected", "joint_unc", "converged"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 2e-3, f
+    assert not g.uncorrected[:, 0, 1].any()
+    # sampled levels: per-replicate reduced rounds must not feed the theta carry of later grid points
+    spec.factor_proportions = [0.8, 0.2]
+    spec.factor_sampled = [True]
+    g = engine.run_batch(spec, [24, 48, 96], 1500, 18)
+    o = oracle.run_batch(spec, [24, 48, 96], 1500, 18, n_threads=8)
+    assert np.array_equal(g.factor_excluded, o.factor_excluded) and 0 < g.factor_excluded[:, 0, 0].sum() < 1500
+    for f in ("uncorrected", "joint_unc", "converged", "boundary_hit"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 1e-2, f
