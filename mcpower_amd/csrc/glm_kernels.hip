@@ -36,14 +36,45 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
   return v;
 }
 
+// mean / weight / working response / deviance contribution of one observation (R glm.fit forms)
+__device__ __forceinline__ void fam_eval(uint32_t fam, double eta, double yi, double& w, double& z, double& dev_i) {
+  if (fam == 0u) {
+    const double ea = exp(-__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
+    const double inv = 1.0 / (1.0 + ea);
+    const double pr = eta >= 0.0 ? inv : ea * inv;  // stable sigmoid
+    w = pr * (1.0 - pr);
+    w = w < W_FLOOR ? W_FLOOR : w;
+    z = eta + (yi - pr) / w;
+    // -2 log-likelihood of a Bernoulli observation: log p = -log1p(e^-eta), log(1-p) = -eta - log1p(e^-eta) (eta >= 0)
+    const double l1p = log1p(ea);
+    const double ll = yi > 0.5 ? (eta >= 0.0 ? -l1p : eta - l1p) : (eta >= 0.0 ? -eta - l1p : -l1p);
+    dev_i = -2.0 * ll;
+  } else if (fam == 1u) {  // probit: eta clamped to +-qnorm(eps), mu' floored at eps (R's probit link)
+    const double thresh = 8.125890664701906;
+    const double e = eta < -thresh ? -thresh : (eta > thresh ? thresh : eta);
+    const double mu = 0.5 * erfc(-e * 0.70710678118654752440), omu = 0.5 * erfc(e * 0.70710678118654752440);
+    double dmu = exp(-0.5 * e * e) * 0.39894228040143267794;
+    dmu = dmu < 2.220446049250313e-16 ? 2.220446049250313e-16 : dmu;
+    w = dmu * dmu / (mu * omu);
+    w = w < W_FLOOR ? W_FLOOR : w;
+    z = eta + (yi - mu) / dmu;
+    dev_i = -2.0 * (yi > 0.5 ? log(mu) : log(omu));
+  } else {  // Poisson, log link
+    const double mu = exp(eta);
+    w = mu < W_FLOOR ? W_FLOOR : mu;
+    z = eta + (yi - mu) / w;
+    dev_i = 2.0 * ((yi > 0.0 ? yi * log(yi / mu) : 0.0) - (yi - mu));
+  }
+}
+
 // IRLS on the first n rows of the LDS-resident design, all lanes returning identical values.
 // MASKED: `keep` selects the fitted columns; dropped columns become identity rows/columns of X'WX and zeros of
 // X'Wz, so their coefficients stay exactly 0 and the kept block is solved by the same operations as the gathered
 // p_red x p_red system of the reference's reduced round (batch.rs:1893-1925).
 template <int P, bool MASKED>
 __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, uint32_t n, uint32_t lane, uint32_t keep,
-                                         double (&beta)[P], double (&Lm)[P][P], double (&invd)[P], double& dev,
-                                         bool& conv) {
+                                         uint32_t fam, double (&beta)[P], double (&Lm)[P][P], double (&invd)[P],
+                                         double& dev, bool& conv) {
   dev = __builtin_nan("");
   double dev_prev = __builtin_inf();
   conv = false;
@@ -62,16 +93,9 @@ __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, ui
       double eta = 0.0;
 #pragma unroll
       for (int c = 0; c < P; ++c) eta = __builtin_fma(xd[c], beta[c], eta);
-      const double ea = exp(-__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
-      const double inv = 1.0 / (1.0 + ea);
-      const double pr = eta >= 0.0 ? inv : ea * inv;  // stable sigmoid
-      double w = pr * (1.0 - pr);
-      w = w < W_FLOOR ? W_FLOOR : w;
-      const double z = eta + (yi - pr) / w;
-      // -2 log-likelihood of a Bernoulli observation: log p = -log1p(e^-eta), log(1-p) = -eta - log1p(e^-eta) (eta >= 0)
-      const double l1p = log1p(ea);
-      const double ll = yi > 0.5 ? (eta >= 0.0 ? -l1p : eta - l1p) : (eta >= 0.0 ? -eta - l1p : -l1p);
-      d += -2.0 * ll;
+      double w, z, di;
+      fam_eval(fam, eta, yi, w, z, di);
+      d += di;
       int idx = 0;
 #pragma unroll
       for (int a = 0; a < P; ++a) {
@@ -197,7 +221,15 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
     sum_y = wave_allreduce_sum(sum_y);
     const double nd = (double)n;
     const double pbar = sum_y / nd;
-    const double dev_null = (pbar > 0.0 && pbar < 1.0) ? -2.0 * (sum_y * log(pbar) + (nd - sum_y) * log(1.0 - pbar)) : 0.0;
+    double dev_null = (pbar > 0.0 && pbar < 1.0) ? -2.0 * (sum_y * log(pbar) + (nd - sum_y) * log(1.0 - pbar)) : 0.0;
+    if (prm.glm_family == 2u) {  // Poisson: the intercept-only fit has mu = mean(y)
+      double dn = 0.0;
+      for (uint32_t i = lane; i < n; i += WAVE) {
+        const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
+        dn += 2.0 * (((yi > 0.0 && pbar > 0.0) ? yi * log(yi / pbar) : 0.0) - (yi - pbar));
+      }
+      dev_null = wave_allreduce_sum(dn);
+    }
 
     double beta[P], Lm[P][P], invd[P];
     double dev;
@@ -236,7 +268,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
         keep = prm.keep_mask[flag_bits & 15u];
 #pragma unroll
         for (int c = 0; c < P; ++c) beta[c] = (attempt == 0 && ((keep >> c) & 1u)) ? prm.beta[c] : 0.0;
-        irls_fit<P, true>(design, n_pad, n, lane, keep, beta, Lm, invd, dev, conv);
+        irls_fit<P, true>(design, n_pad, n, lane, keep, prm.glm_family, beta, Lm, invd, dev, conv);
         if (conv || attempt == 1 || prm.min_level_count == 0u) break;
         int drop = -1;  // included_factor_with_smallest_min_count (batch.rs:2573-2600)
         uint32_t best = 0;
@@ -255,7 +287,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
       // ---- IRLS from the truth start (batch.rs:1945-1951) ----
 #pragma unroll
       for (int c = 0; c < P; ++c) beta[c] = prm.beta[c];
-      irls_fit<P, false>(design, n_pad, n, lane, keep, beta, Lm, invd, dev, conv);
+      irls_fit<P, false>(design, n_pad, n, lane, keep, prm.glm_family, beta, Lm, invd, dev, conv);
     }
 
     // ---- Wald z^2 per target (cov = (X'WX)^-1), decisions, LRT overall ----

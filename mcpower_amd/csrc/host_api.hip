@@ -22,6 +22,7 @@
 
 namespace mcp {
 hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, hipStream_t st);
+hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims, bool scen, hipStream_t st);
 hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
 hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
 hipError_t launch_scenario_design(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
@@ -516,7 +517,7 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   }
   HIP_TRY(hipMemcpyAsync(d_prm, &prm, sizeof prm, hipMemcpyHostToDevice, st));
   if (scen) HIP_TRY(mcp::launch_scenario_design(d_prm, n_sims, st));
-  HIP_TRY(mcp::launch_ols_generate((int)P, d_prm, n_sims, scen ? 2 : (spec->n_factors > 0 ? 1 : 0), st));
+  HIP_TRY(mcp::launch_design_capture((int)P, d_prm, n_sims, scen, st));
   std::vector<float> tile(tile_floats);
   HIP_TRY(hipMemcpyAsync(tile.data(), d_tile, tile_floats * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -232,8 +232,9 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (spec->estimator == MCP_EST_OLS && spec->outcome_kind != MCP_OUTCOME_CONTINUOUS)
     return unsupported("OLS on Binary / Count outcomes");
   if (spec->estimator == MCP_EST_GLM) {
-    if (spec->outcome_kind != MCP_OUTCOME_BINARY || spec->link != MCP_LINK_CANONICAL)
-      return unsupported("GLM families other than Binary/logit (probit, Poisson)");
+    if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS) return unsupported("Glm on a Continuous outcome");
+    if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL)
+      return unsupported("Count outcomes under a non-log link");
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
   if (spec->cluster.present && spec->estimator != MCP_EST_MLE) return unsupported("clustered data generation outside the Mle estimator");
@@ -356,6 +357,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   prm.report_overall = spec->report_overall ? 1u : 0u;
   prm.outcome_kind = (uint32_t)spec->outcome_kind;
   prm.estimator = (uint32_t)spec->estimator;
+  prm.glm_family = spec->outcome_kind == MCP_OUTCOME_COUNT ? 2u : (spec->link == MCP_LINK_PROBIT ? 1u : 0u);
 
   // ---- general path constants (data_gen.rs:709-776, 990-1093) ----
   prm.scen_active = general ? 1u : 0u;

@@ -68,6 +68,8 @@ struct SimParams {
   // outcome
   uint32_t outcome_kind;             // mcp_outcome_kind
   uint32_t estimator;                // mcp_estimator
+  uint32_t glm_family;               // 0 Binary/logit, 1 Binary/probit, 2 Count/log (mixed_workspace::glmm_family)
+  uint32_t _pad_family;
 
   // device pointers
   const uint8_t* fixed_levels;       // [max_n][n_factors] levels of the deterministic allocation walk

@@ -47,8 +47,8 @@ __device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const
 }
 
 // rows 4*ctr .. 4*ctr+3 of one replicate: standard normals of every column into LDS (data_gen.rs:316-421)
-// OUTCOME: 0 = continuous (normal residual), 1 = binary logit (the residual slot holds the Uniform(0,1) draw,
-// data_gen.rs:390-398)
+// OUTCOME: 0 = continuous (normal residual), 1 = discrete GLM outcome by prm.glm_family: logit keeps the
+// Uniform(0,1) draw in the residual slot, probit and Poisson a standard normal (data_gen.rs:390-411)
 template <int P, int STRIDE, int OUTCOME, bool SCEN = false>
 __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr, float* st,
                                             uint32_t scen_meta = 0u) {
@@ -58,7 +58,7 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
 #pragma unroll
   for (int j = 0; j < P - 1; ++j)
     if ((uint32_t)j < K) stage_column<STRIDE>(st, (uint32_t)j, planar_words(k0, k1, CLASS_XNORM, (uint32_t)j, ctr), pend);
-  if (OUTCOME == 0) {
+  if (OUTCOME == 0 || prm.glm_family != 0u) {
     const u32x4 w0 = planar_words(k0, k1, CLASS_RESID, 0u, ctr);
     stage_column<STRIDE>(st, K, w0, pend);
     if (SCEN) {
@@ -269,10 +269,34 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
   }
   if (OUTCOME == 0) {
     y = (float)((lp + (double)e) + u_re);  // u_re = 0.0 without a cluster (data_gen.rs:814-857)
-  } else {  // Bernoulli(sigmoid(eta)): 1{u < sigma(eta)} with the pre-drawn uniform (data_gen.rs:890-911)
+  } else {
     const double eta = lp + u_re;
-    const double pr = eta >= 0.0 ? 1.0 / (1.0 + exp(-eta)) : exp(eta) / (1.0 + exp(eta));
-    y = ((double)e < pr) ? 1.0f : 0.0f;
+    if (prm.glm_family == 0u) {  // Bernoulli(sigmoid(eta)): 1{u < sigma(eta)} with the pre-drawn uniform (data_gen.rs:890-911)
+      const double pr = eta >= 0.0 ? 1.0 / (1.0 + exp(-eta)) : exp(eta) / (1.0 + exp(eta));
+      y = ((double)e < pr) ? 1.0f : 0.0f;
+    } else if (prm.glm_family == 1u) {  // probit: eta is the latent threshold of the N(0,1) draw (data_gen.rs:899-907)
+      y = ((double)e < eta) ? 1.0f : 0.0f;
+    } else {  // Poisson by fixed-draw inverse CDF (rng.rs:370-419): exact walk for lambda <= 20, normal rounding above
+      const double lam = exp(eta), z = (double)e;
+      double out = 0.0;
+      if (lam > 0.0) {
+        if (lam <= 20.0) {
+          const double u = phi_as(z);
+          double pk = exp(-lam), cdf = pk;
+          uint32_t kk = 0;
+          while (cdf < u && kk < 200u) {
+            kk += 1u;
+            pk *= lam / (double)kk;
+            cdf += pk;
+          }
+          out = (double)kk;
+        } else {
+          const double v = floor(lam + z * __builtin_sqrt(lam) + 0.5);
+          out = v > 0.0 ? v : 0.0;
+        }
+      }
+      y = (float)out;
+    }
   }
 }
 

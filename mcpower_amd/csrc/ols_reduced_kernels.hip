@@ -287,6 +287,69 @@ __global__ __launch_bounds__(BLOCK) void ols_reduced_kernel(const SimParams* __r
   }
 }
 
+// ---- introspect::capture_sim0_data twin (introspect.rs:104-155) for every outcome kind: the generated design
+// and outcome of a replicate range in the staged tile layout ([block][column][row quad][256 lanes][4 rows]).
+// Discrete outcomes (logit / probit / Poisson) and the cluster random intercept (draw c of the sequential
+// stream, data_gen.rs:146-161) go through the same row builder the simulate kernels use. ----
+template <int P, bool SCEN>
+__global__ __launch_bounds__(BLOCK) void design_capture_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ float stage_lds[];
+  const SimParams& prm = *pp;
+  const uint32_t local = blockIdx.x * BLOCK + threadIdx.x;
+  const bool active = local < prm.n_sims;
+  const uint32_t lsim = active ? local : (prm.n_sims - 1u);
+  const uint64_t key = pcg_mix64(prm.base_seed, prm.sim_begin + lsim);
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  float* st = stage_lds + threadIdx.x;
+  RowCtx<P> cx;
+  row_ctx_init<P, true>(prm, cx);
+  ScenLane<P> sl;
+  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
+  const bool discrete = prm.outcome_kind != 0u;
+  const uint32_t n_quads = (prm.max_n + 3u) >> 2;
+  for (uint32_t ctr = 0; ctr < n_quads; ++ctr) {
+    if (discrete) stage_group<P, BLOCK, 1, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
+    else stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
+    float q[P][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t rr = 4u * ctr + r;
+      double u_re = 0.0;
+      if (prm.has_cluster) {
+        const uint32_t cid = prm.cluster_fixed_clusters ? rr % prm.cluster_v : rr / prm.cluster_v;
+        const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)(cid < prm.n_clusters_max ? cid : 0u))));
+        u_re = (double)(float)((double)z * prm.tau);
+      }
+      float x[P], y;
+      if (discrete) build_row<P, true, BLOCK, 1, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
+      else build_row<P, true, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
+#pragma unroll
+      for (int c = 1; c < P; ++c) q[c - 1][r] = x[c];
+      q[P - 1][r] = y;
+    }
+#pragma unroll
+    for (int c = 0; c < P; ++c)
+      *reinterpret_cast<float4*>(prm.tile + ((((size_t)blockIdx.x * P + c) * n_quads + ctr) * BLOCK) * 4u + threadIdx.x * 4u) =
+          make_float4(q[c][0], q[c][1], q[c][2], q[c][3]);
+  }
+}
+
+hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims, bool scen, hipStream_t st) {
+  const dim3 block(BLOCK), grid((n_sims + BLOCK - 1) / BLOCK);
+#define LC(PP)                                                                                                   \
+  case PP: {                                                                                                     \
+    const size_t lds = (size_t)(PP + 1) * 4u * BLOCK * sizeof(float);                                            \
+    if (scen) hipLaunchKernelGGL((design_capture_kernel<PP, true>), grid, block, lds, st, d_prm);                \
+    else hipLaunchKernelGGL((design_capture_kernel<PP, false>), grid, block, lds, st, d_prm);                    \
+  } break;
+  switch (P) {
+    LC(2) LC(3) LC(4) LC(5) LC(6) LC(7) LC(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef LC
+  return hipGetLastError();
+}
+
 template <int FLAVOR>
 static hipError_t launch_reduced_f(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
   const dim3 block(BLOCK), grid((n_sims + BLOCK - 1) / BLOCK);

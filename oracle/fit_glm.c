@@ -12,8 +12,11 @@
  *   crates/engine-core/src/glm_dgp_tests.rs:117-180 (converges within MAX_IRLS_ITERS on
  *     well-behaved data, finite beta / z^2).
  * The algorithm restated here is the published one (McCullagh & Nelder; R `glm.fit`): Fisher
- * scoring with working response z = eta + (y - p)/w, w = p(1-p); convergence on
+ * scoring with working response z = eta + (y - mu)/mu', w = mu'^2 / V(mu); convergence on
  * |dev - dev_old| / (|dev| + 0.1) < 1e-8, at most 25 passes (R's glm.control defaults).
+ * Families (mixed_workspace::glmm_family, batch.rs:1958-1962): Binary/logit, Binary/probit
+ * (mu = Phi(eta), mu' = phi(eta), eta clamped to +-qnorm(eps) like R's probit link), Count/log
+ * (Poisson: mu = mu' = V = exp(eta)).
  *
  * PARITY STATUS: beta, se, z pinned to R `glm` on the reference's own bytes
  * (validation/data/glm_*.golden.rds) at 1e-4 relative (validation/tolerances.R:29-31).  The
@@ -49,8 +52,47 @@ static double sigmoid_stable(double eta) {
   return e / (1.0 + e);
 }
 
+enum { FAM_LOGIT = 0, FAM_PROBIT = 1, FAM_POISSON = 2 };
+
+static int glm_family_of(const mcp_spec* spec) {
+  if (spec->outcome_kind == MCP_OUTCOME_COUNT) return FAM_POISSON;
+  return spec->link == MCP_LINK_PROBIT ? FAM_PROBIT : FAM_LOGIT;
+}
+
+/* mean, IRLS weight, working response and deviance contribution of one observation */
+static void fam_eval(int fam, double eta, double yi, double* w_out, double* z_out, double* dev_out) {
+  if (fam == FAM_LOGIT) {
+    double pr = sigmoid_stable(eta);
+    double w = pr * (1.0 - pr);
+    if (w < W_FLOOR) w = W_FLOOR;
+    /* binomial deviance contribution, y in {0,1}: -2 log(p) or -2 log(1-p), via log1p for stability */
+    double ll = yi > 0.5 ? (eta >= 0.0 ? -log1p(exp(-eta)) : eta - log1p(exp(eta)))
+                         : (eta >= 0.0 ? -eta - log1p(exp(-eta)) : -log1p(exp(eta)));
+    *w_out = w;
+    *z_out = eta + (yi - pr) / w;
+    *dev_out = -2.0 * ll;
+  } else if (fam == FAM_PROBIT) {
+    const double thresh = 8.125890664701906; /* -qnorm(.Machine$double.eps) */
+    double e = eta < -thresh ? -thresh : (eta > thresh ? thresh : eta);
+    double mu = 0.5 * erfc(-e * M_SQRT1_2), omu = 0.5 * erfc(e * M_SQRT1_2);
+    double dmu = exp(-0.5 * e * e) / sqrt(2.0 * M_PI);
+    if (dmu < 2.220446049250313e-16) dmu = 2.220446049250313e-16;
+    double w = dmu * dmu / (mu * omu);
+    if (w < W_FLOOR) w = W_FLOOR;
+    *w_out = w;
+    *z_out = eta + (yi - mu) / dmu;
+    *dev_out = -2.0 * (yi > 0.5 ? log(mu) : log(omu));
+  } else { /* Poisson, log link */
+    double mu = exp(eta);
+    double w = mu < W_FLOOR ? W_FLOOR : mu;
+    *w_out = w;
+    *z_out = eta + (yi - mu) / w;
+    *dev_out = 2.0 * ((yi > 0.0 ? yi * log(yi / mu) : 0.0) - (yi - mu));
+  }
+}
+
 /* one pass at `beta`: X'WX (lower, row-major), X'Wz, deviance */
-static void irls_pass(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, const double* beta,
+static void irls_pass(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, const double* beta,
                       double* xtwx, double* xtwz, double* dev) {
   memset(xtwx, 0, sizeof(double) * p * p);
   memset(xtwz, 0, sizeof(double) * p);
@@ -58,15 +100,9 @@ static void irls_pass(const float* x, const float* y, uint32_t n, uint32_t ld, u
   for (uint32_t i = 0; i < n; ++i) {
     double eta = 0.0;
     for (uint32_t c = 0; c < p; ++c) eta += (double)x[(size_t)c * ld + i] * beta[c];
-    double pr = sigmoid_stable(eta);
-    double yi = (double)y[i];
-    double w = pr * (1.0 - pr);
-    if (w < W_FLOOR) w = W_FLOOR;
-    double z = eta + (yi - pr) / w;
-    /* binomial deviance contribution, y in {0,1}: -2 log(p) or -2 log(1-p), via log1p for stability */
-    double ll = yi > 0.5 ? (eta >= 0.0 ? -log1p(exp(-eta)) : eta - log1p(exp(eta)))
-                         : (eta >= 0.0 ? -eta - log1p(exp(-eta)) : -log1p(exp(eta)));
-    d += -2.0 * ll;
+    double w, z, di;
+    fam_eval(fam, eta, (double)y[i], &w, &z, &di);
+    d += di;
     for (uint32_t a = 0; a < p; ++a) {
       double wxa = w * (double)x[(size_t)a * ld + i];
       for (uint32_t b = 0; b <= a; ++b) xtwx[a * p + b] += wxa * (double)x[(size_t)b * ld + i];
@@ -104,7 +140,7 @@ static int chol_solve(const double* a, const double* rhs, uint32_t p, double* L,
   return 0;
 }
 
-static void glm_irls(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, const double* beta0,
+static void glm_irls(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, const double* beta0,
                      glm_fit* f) {
   double xtwx[MCPO_MAX_P * MCPO_MAX_P], xtwz[MCPO_MAX_P], beta[MCPO_MAX_P], nb[MCPO_MAX_P];
   memset(f, 0, sizeof *f);
@@ -112,14 +148,23 @@ static void glm_irls(const float* x, const float* y, uint32_t n, uint32_t ld, ui
   double sum_y = 0.0;
   for (uint32_t i = 0; i < n; ++i) sum_y += (double)y[i];
   double pbar = sum_y / (double)n;
-  f->deviance_null = (pbar > 0.0 && pbar < 1.0)
-                         ? -2.0 * (sum_y * log(pbar) + ((double)n - sum_y) * log(1.0 - pbar))
-                         : 0.0;
+  if (fam == FAM_POISSON) { /* intercept-only fit: mu = mean(y) */
+    double dn = 0.0;
+    for (uint32_t i = 0; i < n; ++i) {
+      double yi = (double)y[i];
+      dn += 2.0 * ((yi > 0.0 && pbar > 0.0 ? yi * log(yi / pbar) : 0.0) - (yi - pbar));
+    }
+    f->deviance_null = dn;
+  } else {
+    f->deviance_null = (pbar > 0.0 && pbar < 1.0)
+                           ? -2.0 * (sum_y * log(pbar) + ((double)n - sum_y) * log(1.0 - pbar))
+                           : 0.0;
+  }
   double dev_prev = INFINITY, dev = NAN;
   int ok = 0;
   uint32_t it = 0;
   for (it = 0; it < MAX_IRLS_ITERS; ++it) {
-    irls_pass(x, y, n, ld, p, beta, xtwx, xtwz, &dev);
+    irls_pass(fam, x, y, n, ld, p, beta, xtwx, xtwz, &dev);
     if (!isfinite(dev)) break;
     if (it > 0 && fabs(dev - dev_prev) / (fabs(dev) + 0.1) < IRLS_EPS) {
       /* converged at `beta`; factor X'WX at the final beta for the Wald variances */
@@ -162,12 +207,12 @@ static double glm_wald_sq(const glm_fit* f, uint32_t p, const double* c) {
 }
 
 /* fit provided bytes (introspect::fit_provided_data twin for the logistic arm) */
-int mcpo_glm_fit(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, const double* beta_start,
-                 double* beta, double* se, double* z_sq, double* deviance, double* deviance_null, uint8_t* converged,
-                 uint32_t* n_iter) {
-  if (p > MCPO_MAX_P) return MCP_ERR_UNSUPPORTED;
+int mcpo_glm_fit_family(int family, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
+                        const double* beta_start, double* beta, double* se, double* z_sq, double* deviance,
+                        double* deviance_null, uint8_t* converged, uint32_t* n_iter) {
+  if (p > MCPO_MAX_P || family < FAM_LOGIT || family > FAM_POISSON) return MCP_ERR_UNSUPPORTED;
   glm_fit f;
-  glm_irls(x, y, n, ld, p, beta_start, &f);
+  glm_irls(family, x, y, n, ld, p, beta_start, &f);
   *converged = (uint8_t)f.converged;
   *deviance = f.deviance;
   *deviance_null = f.deviance_null;
@@ -182,7 +227,14 @@ int mcpo_glm_fit(const float* x, const float* y, uint32_t n, uint32_t ld, uint32
   return MCP_OK;
 }
 
-/* GLM arm of run_one_sim (batch.rs:1562-2134), unclustered logistic.  Sparse-factor exclusion recounts the
+int mcpo_glm_fit(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, const double* beta_start,
+                 double* beta, double* se, double* z_sq, double* deviance, double* deviance_null, uint8_t* converged,
+                 uint32_t* n_iter) {
+  return mcpo_glm_fit_family(FAM_LOGIT, x, y, n, ld, p, beta_start, beta, se, z_sq, deviance, deviance_null, converged,
+                             n_iter);
+}
+
+/* GLM arm of run_one_sim (batch.rs:1562-2134), unclustered logit / probit / Poisson.  Sparse-factor exclusion recounts the
  * levels of rows [0, N) at every grid point (:1836-1853); a reduced round gathers the kept design columns and the
  * kept columns' true effects as the start (:1893-1925); when attempt 0 does not converge and the feature is on,
  * the included factor with the smallest minimum level count is dropped (code 2) and the fit retried once from a
@@ -191,8 +243,10 @@ int mcpo_glm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
                  const double* crit, uint32_t crit_stride, mcpo_red_cache* cache, uint8_t* unc, uint8_t* cor,
                  uint8_t* conv, uint8_t* overall, uint8_t* fx, double* stat_row) {
   if (spec->cluster.present) return MCP_ERR_UNSUPPORTED;            /* Laplace GLMM */
-  if (spec->outcome_kind != MCP_OUTCOME_BINARY || spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
+  if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS) return MCP_ERR_UNSUPPORTED;
+  if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
   if (spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;           /* GLM has no contrasts (batch.rs:2069) */
+  const int fam = glm_family_of(spec);
   const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
   const uint32_t nt = spec->n_target_indices, nf = spec->n_factors;
   const int test_reduces = spec->n_fit_columns && spec->n_fit_columns < p;
@@ -217,7 +271,7 @@ int mcpo_glm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
       if (!reduced) {
         p_red = p;
         for (uint32_t c = 0; c < p; ++c) remap[c] = (int32_t)c;
-        glm_irls(ws->x, ws->y, n, max_n, p, attempt > 0 ? NULL : spec->effect_sizes, &f); /* truth start :1945-1951 */
+        glm_irls(fam, ws->x, ws->y, n, max_n, p, attempt > 0 ? NULL : spec->effect_sizes, &f); /* truth start :1945-1951 */
       } else {
         double start[MCPO_MAX_P];
         p_red = mcpo_build_exclusion_remap(spec, flags, kept, remap);
@@ -226,7 +280,7 @@ int mcpo_glm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
           memcpy(xr + (size_t)rj * max_n, ws->x + (size_t)kept[rj] * max_n, sizeof(float) * n);
           start[rj] = spec->effect_sizes[kept[rj]];
         }
-        glm_irls(xr, ws->y, n, max_n, p_red, attempt > 0 ? NULL : start, &f);
+        glm_irls(fam, xr, ws->y, n, max_n, p_red, attempt > 0 ? NULL : start, &f);
       }
       if (f.converged || attempt == 1 || spec->factor_min_level_count == 0) break;
       int drop = mcpo_smallest_min_count_factor(spec, prefix_counts, flags);

@@ -95,6 +95,10 @@ int mcpo_ols_fit(const float* x_colmajor, const float* y, uint32_t n_rows, uint3
 int mcpo_glm_fit(const float* x_colmajor, const float* y, uint32_t n_rows, uint32_t ld, uint32_t p,
                  const double* beta_start, double* beta, double* se, double* z_sq, double* deviance,
                  double* deviance_null, uint8_t* converged, uint32_t* n_iter);
+/* family: 0 = Binary/logit, 1 = Binary/probit, 2 = Count/log (Poisson) */
+int mcpo_glm_fit_family(int family, const float* x_colmajor, const float* y, uint32_t n_rows, uint32_t ld, uint32_t p,
+                        const double* beta_start, double* beta, double* se, double* z_sq, double* deviance,
+                        double* deviance_null, uint8_t* converged, uint32_t* n_iter);
 
 /* ---- random-intercept REML on provided bytes (glmm fit_on; closed-form profiled deviance, see fit_lmm.c) ---- */
 int mcpo_lmm_fit(const float* x_colmajor, const float* y, const uint32_t* cluster_ids, uint32_t n_rows, uint32_t ld,

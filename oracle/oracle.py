@@ -63,6 +63,7 @@ def lib() -> C.CDLL:
         L.mcpo_build_crit_table.restype = C.c_int
         L.mcpo_ols_fit.restype = C.c_int
         L.mcpo_glm_fit.restype = C.c_int
+        L.mcpo_glm_fit_family.restype = C.c_int
         L.mcpo_lmm_fit.restype = C.c_int
         _lib = L
     return _lib
@@ -188,8 +189,11 @@ def ols_fit(design: np.ndarray, outcome: np.ndarray):
     return dict(beta=beta, se=se, t_sq=tsq, rss=rss.value, sst=sst.value, converged=bool(conv.value))
 
 
-def glm_fit(design: np.ndarray, outcome: np.ndarray, beta_start=None):
-    """Logistic IRLS on provided bytes: design (n, p), outcome (n,) in {0,1}."""
+GLM_FAMILIES = {"logit": 0, "probit": 1, "poisson": 2}
+
+
+def glm_fit(design: np.ndarray, outcome: np.ndarray, beta_start=None, family: str = "logit"):
+    """IRLS on provided bytes: design (n, p), outcome (n,); family logit / probit (y in {0,1}) or poisson (counts)."""
     n, p = design.shape
     x = np.ascontiguousarray(design.T, dtype=np.float32)
     y = np.ascontiguousarray(outcome, dtype=np.float32)
@@ -197,10 +201,11 @@ def glm_fit(design: np.ndarray, outcome: np.ndarray, beta_start=None):
     dev, dev0, conv, nit = C.c_double(), C.c_double(), C.c_uint8(), C.c_uint32()
     pd = C.POINTER(C.c_double)
     b0 = None if beta_start is None else np.ascontiguousarray(beta_start, dtype=np.float64)
-    rc = lib().mcpo_glm_fit(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
-                            C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), None if b0 is None else b0.ctypes.data_as(pd),
-                            beta.ctypes.data_as(pd), se.ctypes.data_as(pd), zsq.ctypes.data_as(pd), C.byref(dev),
-                            C.byref(dev0), C.byref(conv), C.byref(nit))
+    rc = lib().mcpo_glm_fit_family(C.c_int(GLM_FAMILIES[family]), x.ctypes.data_as(C.POINTER(C.c_float)),
+                                   y.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(n), C.c_uint32(n), C.c_uint32(p),
+                                   None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
+                                   se.ctypes.data_as(pd), zsq.ctypes.data_as(pd), C.byref(dev), C.byref(dev0),
+                                   C.byref(conv), C.byref(nit))
     _check(rc)
     return dict(beta=beta, se=se, z_sq=zsq, deviance=dev.value, deviance_null=dev0.value,
                 converged=bool(conv.value), n_iter=nit.value)

@@ -188,6 +188,13 @@ def lower_case(spec: dict, columns):
         out["baseline_probability"] = bp
         if family == "logit":
             out["effect_sizes"][0] = math.log(bp / (1.0 - bp))
+        else:  # probit: the intercept is the standard normal quantile of the baseline probability
+            from scipy.stats import norm
+            out["effect_sizes"][0] = float(norm.ppf(bp))
+    if family == "poisson":
+        br = float(one(spec["baseline_rate"]))
+        out["baseline_rate"] = br
+        out["effect_sizes"][0] = math.log(br)
     if "cluster" in spec and spec["cluster"] is not None:
         cl = spec["cluster"]
         icc = float(one(cl["ICC"]))
@@ -203,6 +210,8 @@ CASES = (
                             "interaction_b")]
     + [f"lme_{n}" for n in ("simple_a", "simple_b", "two_a", "two_b", "factor_a", "factor_b", "interaction_a",
                             "interaction_b")]
+    + [f"probit_{n}" for n in ("simple_a", "simple_b", "two_a", "factor_a")]
+    + [f"poisson_{n}" for n in ("simple_a", "simple_b", "two_a", "factor_a")]
 )
 
 

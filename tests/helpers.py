@@ -59,8 +59,11 @@ def load_case(name):
         effect_sizes=low["effect_sizes"],
         target_indices=list(range(1, p)),
         interactions=low["interactions"],
-        outcome_kind=S.OutcomeKind.Binary if fam == "logit" else S.OutcomeKind.Continuous,
-        estimator={"ols": S.EstimatorSpec.Ols, "logit": S.EstimatorSpec.Glm, "lme": S.EstimatorSpec.Mle}[fam],
+        outcome_kind={"logit": S.OutcomeKind.Binary, "probit": S.OutcomeKind.Binary,
+                      "poisson": S.OutcomeKind.Count}.get(fam, S.OutcomeKind.Continuous),
+        link=S.LinkKind.Probit if fam == "probit" else None,
+        estimator={"ols": S.EstimatorSpec.Ols, "logit": S.EstimatorSpec.Glm, "probit": S.EstimatorSpec.Glm,
+                   "poisson": S.EstimatorSpec.Glm, "lme": S.EstimatorSpec.Mle}[fam],
         intercept=low["effect_sizes"][0],
     )
     if "cluster" in low:

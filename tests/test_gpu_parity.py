@@ -6,6 +6,8 @@ Bars: f32 data plane bit-exact; squared statistics within 1e-10 r
 (summation order / fma only); significance flags identical except where |t^2 - crit^2| / crit^2
 < 1e-9 (a knife-edge decision: expected count 0); counters identical whenever flags are.
 """
+import math
+
 import numpy as np
 import pytest
 
@@ -48,10 +50,11 @@ def test_icdf_exhaustive_all_reachable_uniforms(engine, oracle):
     assert np.array_equal(engine.icdf_probe(511, 512, 4096).view(np.uint32), ref[:4096].view(np.uint32))
 
 
-@pytest.mark.parametrize("name", case_names("ols"))
+@pytest.mark.parametrize("name", case_names())
 def test_generated_design_matches_reference_bytes(engine, oracle, name):
     """mcp_generate_design (introspect::capture_sim0_data twin) == the reference's captured sim-0
-    design/outcome bytes (validation/data/<case>.rds), and == the oracle for later sims."""
+    design/outcome bytes (validation/data/<case>.rds: OLS, logit, probit, Poisson and random-intercept LME
+    cases), and == the oracle for later sims."""
     spec, seed, arr, low = load_case(name)
     n = low["n"]
     d, y = engine.generate_design(spec, n, 3, seed, 0)
@@ -517,3 +520,42 @@ def test_c5_grid_sweep_optimistic_matches_oracle(engine, oracle):
     _assert_batch_equal(g, o)
     ku = g.counter("k_unc", 2)[:, 0]
     assert (np.diff(ku.astype(np.int64)) >= -25).all() and ku[-1] > 0.99 * 1000
+
+
+# ---------------------------------------------------------------------------------------------
+# probit / Poisson GLM families
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", case_names("probit") + case_names("poisson"))
+def test_probit_and_poisson_run_batch_match_oracle(engine, oracle, name):
+    spec, seed, arr, low = load_case(name)
+    spec.report_overall = True
+    spec.correction_method = S.CorrectionMethod.Holm
+    n = low["n"]
+    g = engine.run_batch(spec, [n // 4, n], 1500, seed, stat_capture=True)
+    o = oracle.run_batch(spec, [n // 4, n], 1500, seed, stat_capture=True, n_threads=8)
+    a, b = g.stat_capture, o.stat_capture
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    m = ~np.isnan(a)
+    assert np.all(np.abs(a[m] - b[m]) <= 1e-7 * np.abs(b[m]) + 1e-9)
+    for f in ("uncorrected", "corrected", "converged", "overall"):
+        assert np.array_equal(getattr(g, f), getattr(o, f)), f
+    assert np.array_equal(g.counters, o.counters)
+    assert g.converged.mean() > 0.99 and g.uncorrected[:, 1, 0].mean() > 0.9
+
+
+def test_poisson_large_rate_and_factor_exclusion(engine, oracle):
+    """lambda > 20 takes the rounded-normal arm of the Poisson quantile (rng.rs:370-419); sparse levels are
+    excluded under the Count family as under the others."""
+    spec, seed, arr, low = load_case("poisson_factor_a")
+    spec.effect_sizes = [math.log(30.0)] + list(spec.effect_sizes[1:])
+    spec.factor_proportions = [0.7, 0.2, 0.1]
+    spec.factor_min_level_count = 5
+    spec.report_overall = True
+    g = engine.run_batch(spec, [30, 200], 1500, seed, stat_capture=True)
+    o = oracle.run_batch(spec, [30, 200], 1500, seed, stat_capture=True, n_threads=8)
+    assert np.array_equal(g.factor_excluded, o.factor_excluded) and (g.factor_excluded[:, 0, 0] == 1).all()
+    for f in ("uncorrected", "corrected", "converged", "overall"):
+        assert np.array_equal(getattr(g, f), getattr(o, f)), f
+    d, y = engine.generate_design(spec, 200, 2, seed, 5)
+    xo, yo, _ = oracle.generate_sim_data(spec, seed, 6, 200)
+    assert np.array_equal(y[1], yo) and yo.mean() > 25
