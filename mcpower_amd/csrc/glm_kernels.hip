@@ -179,7 +179,9 @@ __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, ui
 // RED: sparse-factor exclusion recounted from rows [0, N) at every grid point (batch.rs:1836-1853), reduced
 // fits, and the separation fallback -- when attempt 0 does not converge, drop the included factor with the
 // smallest minimum level count (code 2) and refit once from a cold start (:1976-2030).
-template <int P, bool FACTORS, bool RED>
+// SCEN: general data path -- per-replicate correlation factor / marginals from the scenario design records and
+// per-study effects (data_gen.rs:709-751, 990-1093); the fit still starts from the spec's effects.
+template <int P, bool FACTORS, bool RED, bool SCEN>
 __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ float lds[];
   const SimParams& prm = *pp;
@@ -197,14 +199,16 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
   // ---- generate the replicate into LDS: lane takes Philox blocks lane, lane + 64, ... ----
   RowCtx<P> cx;
   row_ctx_init<P, FACTORS>(prm, cx);
+  ScenLane<P> sl;
+  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
   for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += WAVE) {
-    stage_group<P, WAVE, 1>(prm, k0, k1, ctr, st);
+    stage_group<P, WAVE, 1, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint32_t rr = 4u * ctr + r;
       if (rr < max_n) {
         float x[P], y;
-        build_row<P, FACTORS, WAVE, 1>(prm, cx, k0, k1, st, r, rr, x, y);
+        build_row<P, FACTORS, WAVE, 1, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, 0.0, &sl);
 #pragma unroll
         for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
         design[(size_t)(P - 1) * n_pad + rr] = y;
@@ -436,23 +440,23 @@ hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t cop
   return hipGetLastError();
 }
 
-size_t glm_lds_bytes(int P, uint32_t max_n) {
+size_t glm_lds_bytes(int P, uint32_t max_n) {  // staging sized for the general path's scratch column too
   const size_t n_pad = (max_n + 3u) & ~3u;
-  return ((size_t)P * n_pad + (size_t)4 * P * WAVE) * sizeof(float);
+  return ((size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE) * sizeof(float);
 }
 
-template <bool FACTORS, bool RED>
+template <bool FACTORS, bool RED, bool SCEN>
 static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, hipStream_t st) {
   const size_t lds = glm_lds_bytes(P, max_n);
   const dim3 block(WAVE), grid(n_sims);
 #define LG(PP)                                                                                                        \
   case PP: {                                                                                                          \
     if (lds > 48 * 1024) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS, RED>,                               \
+      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS, RED, SCEN>,                               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
       if (e != hipSuccess) return e;                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS, RED>), grid, block, lds, st, d_prm);                              \
+    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS, RED, SCEN>), grid, block, lds, st, d_prm);                        \
   } break;
   switch (P) {
     LG(2) LG(3) LG(4) LG(5) LG(6) LG(7) LG(8)
@@ -463,10 +467,11 @@ static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
 }
 
 hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
-                          hipStream_t st) {
-  if (reduced) return launch_glm_f<true, true>(P, d_prm, n_sims, max_n, st);
-  return factors ? launch_glm_f<true, false>(P, d_prm, n_sims, max_n, st)
-                 : launch_glm_f<false, false>(P, d_prm, n_sims, max_n, st);
+                          bool scen, hipStream_t st) {
+  if (scen) return launch_glm_f<true, true, true>(P, d_prm, n_sims, max_n, st);
+  if (reduced) return launch_glm_f<true, true, false>(P, d_prm, n_sims, max_n, st);
+  return factors ? launch_glm_f<true, false, false>(P, d_prm, n_sims, max_n, st)
+                 : launch_glm_f<false, false, false>(P, d_prm, n_sims, max_n, st);
 }
 
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {

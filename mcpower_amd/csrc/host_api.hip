@@ -32,11 +32,11 @@ hipError_t launch_ols_fit_provided(int P, const float* design, const float* outc
                                    hipStream_t st);
 hipError_t launch_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out, hipStream_t st);
 hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
-                          hipStream_t st);
+                          bool scen, hipStream_t st);
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
 size_t glm_lds_bytes(int P, uint32_t max_n);
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
-                          bool reduced, hipStream_t st);
+                          bool reduced, bool scen, hipStream_t st);
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st);
@@ -97,7 +97,7 @@ struct Arena {
 };
 thread_local Arena g_arena;
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
   int n = 0;
@@ -192,7 +192,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   const bool mle = spec->estimator == MCP_EST_MLE;
   const bool glm = spec->estimator == MCP_EST_GLM || mle;  // wave-per-replicate kernels + flag fold
   const bool reduced = prm.red_active && !glm;             // reduced-design OLS kernel, flags folded afterwards
-  const bool glm_reduced = prm.red_active && glm;          // RED variants of the wave-per-replicate kernels
+  // RED variants of the wave-per-replicate kernels; their general-path (scenario) variants build on them
+  const bool glm_reduced = (prm.red_active || prm.scen_active) && glm;
   if (reduced && (flags & MCP_PIPELINE_STAGED))
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds");
   const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
@@ -287,10 +288,11 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   // general path: per-replicate design records (lower factor, marginal / residual codes, per-study effects)
   const bool scen = prm.scen_active;
   const int flavor = scen ? 2 : (spec->n_factors > 0 ? 1 : 0);
-  double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr;
+  double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr, *d_scen_tau = nullptr;
   uint32_t* d_scen_meta = nullptr;
   if (scen) {
     const uint32_t K = spec->n_non_factor;
+    if (spec->cluster.present) DEV_TRY(ar.get(S_SCEN_TAU, (size_t)chunk * sizeof(double), (void**)&d_scen_tau));
     DEV_TRY(ar.get(S_SCEN_L, (size_t)(K * (K + 1) / 2 + 1) * chunk * sizeof(double), (void**)&d_scen_L));
     DEV_TRY(ar.get(S_SCEN_META, (size_t)chunk * sizeof(uint32_t), (void**)&d_scen_meta));
     if (low.need_beta_eff) DEV_TRY(ar.get(S_SCEN_BETA, (size_t)P * chunk * sizeof(double), (void**)&d_scen_beta));
@@ -336,6 +338,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   prm.scen_L = d_scen_L;
   prm.scen_meta = d_scen_meta;
   prm.scen_beta = d_scen_beta;
+  prm.scen_tau_sq = d_scen_tau;
   prm.scen_stride = chunk;
   prm.t3_table = d_t3;
   std::vector<mcp::SimParams> h_prm(n_chunks, prm);
@@ -359,8 +362,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, st));
-      else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, st));
+      if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));
+      else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, scen, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
@@ -503,8 +506,10 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   const bool scen = prm.scen_active;
   if (scen) {
     const uint32_t K = spec->n_non_factor;
-    double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr;
+    double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr, *d_scen_tau = nullptr;
     uint32_t* d_scen_meta = nullptr;
+    if (spec->cluster.present) HIP_TRY(ar.get(S_SCEN_TAU, (size_t)n_sims * sizeof(double), (void**)&d_scen_tau));
+    prm.scen_tau_sq = d_scen_tau;
     HIP_TRY(ar.get(S_SCEN_L, (size_t)(K * (K + 1) / 2 + 1) * n_sims * sizeof(double), (void**)&d_scen_L));
     HIP_TRY(ar.get(S_SCEN_META, (size_t)n_sims * sizeof(uint32_t), (void**)&d_scen_meta));
     if (low.need_beta_eff) HIP_TRY(ar.get(S_SCEN_BETA, (size_t)P * n_sims * sizeof(double), (void**)&d_scen_beta));

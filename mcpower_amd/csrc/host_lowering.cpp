@@ -246,9 +246,11 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       return unsupported("uploaded-data marginals");
     if (vt != MCP_DIST_NORMAL) general = true;
   }
-  if (general && spec->estimator != MCP_EST_OLS) return unsupported("scenario perturbations / non-normal shapes under Glm / Mle (OLS only so far)");
   if (general && K > 6) return unsupported("general data-generating path with more than 6 continuous predictors");
-  if (spec->scenario.has_lme) return unsupported("LME scenario knobs (random-effect distribution, ICC jitter)");
+  if (spec->scenario.has_lme && spec->estimator != MCP_EST_MLE) {
+    err = "invalid spec: scenario.lme requires estimator == Mle";
+    return MCP_ERR_INVALID_SPEC;
+  }
   if (spec->n_bootstrap_frame_map || spec->upload_normal_rows || spec->upload_data_rows) return unsupported("uploaded data");
   if (spec->n_between_var_indices) return unsupported("cluster-level (between) predictors");
   const uint32_t npc = total_posthoc_contrasts(spec);
@@ -317,7 +319,20 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     prm.cluster_v = spec->cluster.sizing_value;
     prm.n_clusters_max = prm.cluster_fixed_clusters ? prm.cluster_v : max_n / prm.cluster_v;
     prm.tau = std::sqrt(spec->cluster.tau_squared > 0.0 ? spec->cluster.tau_squared : 0.0);
-    prm.n_seq_pre = prm.n_clusters_max;
+    prm.tau_squared = spec->cluster.tau_squared;
+    // draws one cluster effect consumes on the sequential stream (draw_residual, data_gen.rs:1289-1320)
+    prm.lme_re_dist = spec->scenario.has_lme ? (uint32_t)spec->scenario.lme_random_effect_dist : 0u;
+    prm.lme_re_df = spec->scenario.has_lme ? spec->scenario.lme_random_effect_df : 0.0;
+    prm.lme_icc_noise_sd = spec->scenario.has_lme ? spec->scenario.lme_icc_noise_sd : 0.0;
+    {
+      const double df = prm.lme_re_df > 3.0 ? prm.lme_re_df : 3.0;
+      long dfi = std::lround(df);
+      if (dfi < 1) dfi = 1;
+      if (prm.lme_re_dist != 0u && prm.lme_re_dist != 4u && dfi > 64) return unsupported("random-effect df above 64");
+      prm.re_draws_per_cluster = prm.lme_re_dist == 1u ? (uint32_t)dfi + 1u
+                                 : ((prm.lme_re_dist == 2u || prm.lme_re_dist == 3u) ? (uint32_t)dfi : 1u);
+    }
+    prm.n_seq_pre = prm.n_clusters_max * prm.re_draws_per_cluster;
   }
   prm.truth_start = spec->scenario.truth_start ? 1u : 0u;
   low.fixed_levels.assign((size_t)max_n * (spec->n_factors ? spec->n_factors : 1), 0);

@@ -153,7 +153,9 @@ __device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2
 // RED: exclusion flags recounted from rows [0, N) before every fit (batch.rs:1236-1250); a reduced round fits the
 // kept columns, never feeds the grid-sequential theta carry (:1414-1428) and runs the joint Wald over the kept
 // targets against chi2(k_red) (:1456-1468).
-template <int P, bool FACTORS, bool RED>
+// SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
+// heteroskedastic residuals) plus the LME knobs: random-effect shape and per-replicate tau^2 (data_gen.rs:146-161).
+template <int P, bool FACTORS, bool RED, bool SCEN>
 __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
@@ -174,17 +176,28 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
   float* st = cluster_u + ncl_pad + lane;                                // staging, stride 64
 
   // ---- cluster random intercepts: draw c is word c of the sequential stream (data_gen.rs:146-161) ----
+  double tau_rep = prm.tau;
+  if (SCEN && prm.scen_tau_sq) {
+    const double t2 = prm.scen_tau_sq[lsim];
+    tau_rep = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
+  }
   for (uint32_t c = lane; c < ncl_max; c += LWAVE) {
-    const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
-    cluster_u[c] = (float)((double)z * prm.tau);
+    if (SCEN) {
+      cluster_u[c] = (float)(draw_cluster_effect(prm, k0, k1, c) * tau_rep);
+    } else {
+      const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
+      cluster_u[c] = (float)((double)z * prm.tau);
+    }
   }
   __syncthreads();
 
   // ---- generate the replicate into LDS ----
   RowCtx<P> cx;
   row_ctx_init<P, FACTORS>(prm, cx);
+  ScenLane<P> sl;
+  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
   for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += LWAVE) {
-    stage_group<P, LWAVE, 0>(prm, k0, k1, ctr, st);
+    stage_group<P, LWAVE, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint32_t rr = 4u * ctr + r;
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
         const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
         const double u_re = (double)cluster_u[cid < ncl_max ? cid : 0u];
         float x[P], y;
-        build_row<P, FACTORS, LWAVE, 0>(prm, cx, k0, k1, st, r, rr, x, y, u_re);
+        build_row<P, FACTORS, LWAVE, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
 #pragma unroll
         for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
         design[(size_t)(P - 1) * n_pad + rr] = y;
@@ -466,10 +479,10 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max) {
   const size_t n_pad = (max_n + 3u) & ~3u;
   const size_t ncl_pad = (ncl_max + 1u) & ~(size_t)1u;
-  return (size_t)ncl_max * (P + 1) * sizeof(double) + ((size_t)P * n_pad + ncl_pad + (size_t)4 * P * LWAVE) * sizeof(float);
+  return (size_t)ncl_max * (P + 1) * sizeof(double) + ((size_t)P * n_pad + ncl_pad + (size_t)4 * (P + 1) * LWAVE) * sizeof(float);
 }
 
-template <bool FACTORS, bool RED>
+template <bool FACTORS, bool RED, bool SCEN>
 static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max,
                                hipStream_t st) {
   const size_t lds = lmm_lds_bytes(P, max_n, ncl_max);
@@ -477,11 +490,11 @@ static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
 #define LL(PP)                                                                                                        \
   case PP: {                                                                                                          \
     if (lds > 48 * 1024) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void*)lmm_sim_kernel<PP, FACTORS, RED>,                               \
+      hipError_t e = hipFuncSetAttribute((const void*)lmm_sim_kernel<PP, FACTORS, RED, SCEN>,                               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
       if (e != hipSuccess) return e;                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((lmm_sim_kernel<PP, FACTORS, RED>), grid, block, lds, st, d_prm);                              \
+    hipLaunchKernelGGL((lmm_sim_kernel<PP, FACTORS, RED, SCEN>), grid, block, lds, st, d_prm);                        \
   } break;
   switch (P) {
     LL(2) LL(3) LL(4) LL(5) LL(6)
@@ -492,10 +505,11 @@ static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
 }
 
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
-                          bool reduced, hipStream_t st) {
-  if (reduced) return launch_lmm_f<true, true>(P, d_prm, n_sims, max_n, ncl_max, st);
-  return factors ? launch_lmm_f<true, false>(P, d_prm, n_sims, max_n, ncl_max, st)
-                 : launch_lmm_f<false, false>(P, d_prm, n_sims, max_n, ncl_max, st);
+                          bool reduced, bool scen, hipStream_t st) {
+  if (scen) return launch_lmm_f<true, true, true>(P, d_prm, n_sims, max_n, ncl_max, st);
+  if (reduced) return launch_lmm_f<true, true, false>(P, d_prm, n_sims, max_n, ncl_max, st);
+  return factors ? launch_lmm_f<true, false, false>(P, d_prm, n_sims, max_n, ncl_max, st)
+                 : launch_lmm_f<false, false, false>(P, d_prm, n_sims, max_n, ncl_max, st);
 }
 
 }  // namespace mcp

@@ -116,6 +116,13 @@ struct SimParams {
   uint32_t scen_stride;
   uint32_t _pad_scen;
   const double* t3_table;          // 2048-knot standardized t(3) PPF table (marginals/t3.rs) or null
+  // LME scenario knobs (data_gen.rs:146-161, 1069-1076): random-effect shape and per-replicate ICC jitter
+  uint32_t lme_re_dist;            // mcp_residual_dist of the cluster random intercept (Normal without scenario.lme)
+  uint32_t re_draws_per_cluster;   // sequential-stream draws one cluster effect consumes (1, df, or 1 + df)
+  double lme_re_df;
+  double lme_icc_noise_sd;
+  double tau_squared;              // spec cluster.tau_squared
+  double* scen_tau_sq;             // [scen_stride] realised tau^2 per replicate (general path with a cluster) or null
 
   // ---- reduced-design path (batch.rs:925-1213, 2418-2562): per-(replicate, N) sparse-factor exclusion, a
   //      test_formula subset of the columns, post-hoc pairwise contrasts.  A kept-column bitmask selects the

@@ -102,6 +102,37 @@ __device__ __forceinline__ double apply_marginal(uint32_t dist, double z, double
   }
 }
 
+// cluster random effect c of a replicate (draw_residual on the sequential stream, data_gen.rs:146-161,
+// :1289-1320): the c-th block of `re_draws_per_cluster` words; standardized to unit variance, scaled by tau outside
+__device__ __forceinline__ double draw_cluster_effect(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t c) {
+  const uint64_t base = (uint64_t)c * prm.re_draws_per_cluster;
+  auto nrm = [&](uint64_t q) { return (double)norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, q))); };
+  const uint32_t dist = prm.lme_re_dist;
+  if (dist == 0u) return nrm(base);
+  if (dist == 4u) return (2.0 * (double)u32_to_unit_f32(sequential_word(k0, k1, base)) - 1.0) * SQRT3;
+  const double df = prm.lme_re_df > 3.0 ? prm.lme_re_df : 3.0;
+  long dfi = (long)floor(df + 0.5);  // llround for df >= 3
+  dfi = dfi < 1 ? 1 : dfi;
+  if (dist == 1u) {  // HighKurtosis: t(df) = z / sqrt(chi2_df / df), standardized
+    const double z = nrm(base);
+    double chi2 = 0.0;
+    for (long i = 0; i < dfi; ++i) {
+      const double g = nrm(base + 1u + (uint64_t)i);
+      chi2 += g * g;
+    }
+    const double denom = __builtin_sqrt(chi2 / df);
+    const double t = denom <= 0.0 ? z : z / denom;
+    return t * (1.0 / __builtin_sqrt(df / (df - 2.0)));
+  }
+  double chi2 = 0.0;  // Right / LeftSkewed: centered scaled chi-square
+  for (long i = 0; i < dfi; ++i) {
+    const double g = nrm(base + (uint64_t)i);
+    chi2 += g * g;
+  }
+  const double centered = (chi2 - df) * (1.0 / __builtin_sqrt(2.0 * df));
+  return dist == 3u ? -centered : centered;
+}
+
 // lower Cholesky in place, column-major k x k (a[j*k+i] = row i, col j); false when a pivot is not positive
 __device__ inline bool chol_colmajor(double* a, uint32_t k) {
   for (uint32_t j = 0; j < k; ++j) {

@@ -317,8 +317,12 @@ __global__ __launch_bounds__(BLOCK) void design_capture_kernel(const SimParams* 
       double u_re = 0.0;
       if (prm.has_cluster) {
         const uint32_t cid = prm.cluster_fixed_clusters ? rr % prm.cluster_v : rr / prm.cluster_v;
-        const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)(cid < prm.n_clusters_max ? cid : 0u))));
-        u_re = (double)(float)((double)z * prm.tau);
+        double tau_rep = prm.tau;
+        if (SCEN && prm.scen_tau_sq) {
+          const double t2 = prm.scen_tau_sq[lsim];
+          tau_rep = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
+        }
+        u_re = (double)(float)(draw_cluster_effect(prm, k0, k1, cid < prm.n_clusters_max ? cid : 0u) * tau_rep);
       }
       float x[P], y;
       if (discrete) build_row<P, true, BLOCK, 1, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);

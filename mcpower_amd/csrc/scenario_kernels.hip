@@ -26,6 +26,7 @@ __global__ __launch_bounds__(256) void scenario_design_kernel(const SimParams* _
   double L[MAX_K * MAX_K];  // column-major
   uint32_t vt[MAX_K];
   uint32_t rd = prm.resid_spec_dist;
+  double tau_sq = prm.tau_squared;
   bool ok = true;
   for (uint32_t j = 0; j < K; ++j) vt[j] = prm.var_types[j];
   if (prm.scen_optimistic) {
@@ -67,7 +68,13 @@ __global__ __launch_bounds__(256) void scenario_design_kernel(const SimParams* _
         rd = (uint32_t)prm.resid_dists[pick];
       }
     }
+    if (prm.lme_icc_noise_sd > 0.0) {  // data_gen.rs:1069-1076: tau^2 jitter, clamped at 0
+      const double jit = (double)rng.next_normal() * prm.lme_icc_noise_sd;
+      tau_sq = tau_sq + jit;
+      tau_sq = tau_sq > 0.0 ? tau_sq : 0.0;
+    }
   }
+  if (prm.scen_tau_sq) prm.scen_tau_sq[lsim] = tau_sq;
   uint32_t meta = (rd & 7u) << 28;
   for (uint32_t j = 0; j < K; ++j) meta |= (vt[j] & 15u) << (4u * j);
   if (!ok) meta |= 0x80000000u;  // EngineError::CorrelationNotPSD for this replicate

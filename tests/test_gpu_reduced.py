@@ -260,3 +260,75 @@ def test_lmm_exclusion_reduces_fit_and_joint_test(engine, oracle):
     assert np.array_equal(g.factor_excluded, o.factor_excluded) and 0 < g.factor_excluded[:, 0, 0].sum() < 1500
     for f in ("uncorrected", "joint_unc", "converged", "boundary_hit"):
         assert (getattr(g, f) != getattr(o, f)).mean() < 1e-2, f
+
+
+# ---------------------------------------------------------------------------------------------
+# scenario perturbations under the GLM / MLE estimators (incl. the LME knobs)
+# ---------------------------------------------------------------------------------------------
+def _lme_preset(name):
+    from helpers import preset
+    sc = preset(name)
+    if name == "realistic":
+        sc.lme = S.LmeScenarioPerturbations(S.ResidualDist.HighKurtosis, 10.0, 0.15)
+    elif name == "doomer":
+        sc.lme = S.LmeScenarioPerturbations(S.ResidualDist.HighKurtosis, 5.0, 0.3)
+    return sc
+
+
+@pytest.mark.parametrize("name", ["realistic", "doomer"])
+def test_glm_under_scenario_presets(engine, oracle, name):
+    from helpers import preset
+    from test_gpu_parity import _design_mismatch
+    spec = S.SimulationSpec(n_non_factor=2, n_factor_dummies=2, correlation=[1.0, 0.4, 0.4, 1.0],
+                            var_types=[S.Distribution.Normal] * 2, var_params=[0.0, 0.0], factor_n_levels=[3],
+                            factor_proportions=[0.5, 0.3, 0.2], effect_sizes=[math.log(0.3 / 0.7), 0.5, 0.3, 0.6, -0.4],
+                            target_indices=[1, 2, 3, 4], outcome_kind=S.OutcomeKind.Binary,
+                            estimator=S.EstimatorSpec.Glm, report_overall=True, factor_min_level_count=5,
+                            correction_method=S.CorrectionMethod.BenjaminiHochberg, scenario=preset(name))
+    bx, by, worst, total = _design_mismatch(engine, oracle, spec, 150, 24)
+    assert by == 0 and bx <= max(2, total * 1e-5), (bx, by, worst)          # binary outcomes agree exactly
+    g = engine.run_batch(spec, [60, 150, 400], 2500, 31, stat_capture=True)
+    o = oracle.run_batch(spec, [60, 150, 400], 2500, 31, stat_capture=True, n_threads=8)
+    assert np.array_equal(g.factor_excluded, o.factor_excluded)
+    for f in ("uncorrected", "corrected", "overall", "converged"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 5e-4, f
+    assert g.uncorrected[:, 2, 0].mean() > 0.8
+
+
+@pytest.mark.parametrize("link", ["probit", "poisson"])
+def test_other_glm_families_under_heterogeneity(engine, oracle, link):
+    """validation scen_he_probit / scen_he_poisson shape: per-study effects on the link scale."""
+    spec = S.SimulationSpec(n_non_factor=2, correlation=[1.0, 0.0, 0.0, 1.0], var_types=[S.Distribution.Normal] * 2,
+                            var_params=[0.0, 0.0], target_indices=[1, 2], estimator=S.EstimatorSpec.Glm,
+                            scenario=S.ScenarioPerturbations(name="he", heterogeneity=0.4))
+    if link == "probit":
+        spec.outcome_kind, spec.link, spec.effect_sizes = S.OutcomeKind.Binary, S.LinkKind.Probit, [-0.5, 0.5, 0.3]
+    else:
+        spec.outcome_kind, spec.effect_sizes = S.OutcomeKind.Count, [math.log(2.0), 0.5, 0.3]
+    g = engine.run_batch(spec, [200], 3000, 41, stat_capture=True)
+    o = oracle.run_batch(spec, [200], 3000, 41, stat_capture=True, n_threads=8)
+    m = ~np.isnan(o.stat_capture)
+    assert np.array_equal(np.isnan(g.stat_capture), ~m)
+    assert np.all(np.abs(g.stat_capture[m] - o.stat_capture[m]) <= 1e-6 * np.abs(o.stat_capture[m]) + 1e-8)
+    assert np.array_equal(g.uncorrected, o.uncorrected) and np.array_equal(g.converged, o.converged)
+
+
+@pytest.mark.parametrize("name", ["realistic", "doomer"])
+def test_lmm_under_scenario_presets_with_lme_knobs(engine, oracle, name):
+    from test_gpu_parity import _design_mismatch
+    spec = S.SimulationSpec(n_non_factor=2, n_factor_dummies=1, correlation=[1.0, 0.3, 0.3, 1.0],
+                            var_types=[S.Distribution.Normal] * 2, var_params=[0.0, 0.0], factor_n_levels=[2],
+                            factor_proportions=[0.7, 0.3], effect_sizes=[0.0, 0.3, 0.2, 0.4], target_indices=[1, 2, 3],
+                            estimator=S.EstimatorSpec.Mle, factor_min_level_count=5,
+                            cluster=S.ClusterSpec(sizing=("FixedClusters", 12), tau_squared=0.25),
+                            scenario=_lme_preset(name))
+    bx, by, worst, total = _design_mismatch(engine, oracle, spec, 120, 24)
+    assert bx + by <= max(3, total * 2e-5) and worst < 2.5e-7, (bx, by, worst)
+    g = engine.run_batch(spec, [36, 120, 240], 1500, 51, stat_capture=True)
+    o = oracle.run_batch(spec, [36, 120, 240], 1500, 51, stat_capture=True, n_threads=8)
+    assert np.array_equal(g.factor_excluded, o.factor_excluded) and g.factor_excluded[:, 0, 0].sum() > 0
+    for f in ("uncorrected", "corrected", "joint_unc", "converged", "boundary_hit"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 1e-2, f
+    m = ~np.isnan(o.stat_capture) & ~np.isnan(g.stat_capture)
+    rel = np.abs(g.stat_capture[m] - o.stat_capture[m]) / np.maximum(o.stat_capture[m], 1e-9)
+    assert np.quantile(rel, 0.99) < 1e-4
