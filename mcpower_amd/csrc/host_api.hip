@@ -65,7 +65,7 @@ struct Arena {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Buf slots[24];
+  Buf slots[28];
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
   int device = -1;
@@ -97,7 +97,7 @@ struct Arena {
 };
 thread_local Arena g_arena;
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
   int n = 0;
@@ -302,6 +302,19 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
       DEV_TRY(hipMemcpy(d_t3, t3.data(), t3.size() * sizeof(double), hipMemcpyHostToDevice));
     }
   }
+  double *d_up_normal = nullptr, *d_up_data = nullptr;
+  if (spec->upload_normal_rows) {
+    const size_t nb = (size_t)spec->upload_normal_rows * spec->upload_normal_cols * sizeof(double);
+    DEV_TRY(ar.get(S_UPLOAD_NORMAL, nb, (void**)&d_up_normal));
+    DEV_TRY(hipMemcpy(d_up_normal, spec->upload_normal, nb, hipMemcpyHostToDevice));
+  }
+  if (spec->n_bootstrap_frame_map) {
+    const size_t nb = (size_t)spec->upload_data_rows * spec->upload_data_cols * sizeof(double);
+    DEV_TRY(ar.get(S_UPLOAD_DATA, nb, (void**)&d_up_data));
+    DEV_TRY(hipMemcpy(d_up_data, spec->upload_data, nb, hipMemcpyHostToDevice));
+  }
+  prm.upload_normal = d_up_normal;
+  prm.upload_data = d_up_data;
   if (staged) DEV_TRY(ar.get(S_TILE, (size_t)((chunk + 255u) / 256u) * 256u * P * prm.max_n * sizeof(float), (void**)&d_tile));
 
   hipEvent_t ev_begin, ev_end;
@@ -503,6 +516,20 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   prm.fixed_levels = d_levels;
   prm.tile = d_tile;
   prm.tile_sims = n_sims;
+  if (spec->upload_normal_rows) {
+    double* d_up = nullptr;
+    const size_t nb = (size_t)spec->upload_normal_rows * spec->upload_normal_cols * sizeof(double);
+    HIP_TRY(ar.get(S_UPLOAD_NORMAL, nb, (void**)&d_up));
+    HIP_TRY(hipMemcpy(d_up, spec->upload_normal, nb, hipMemcpyHostToDevice));
+    prm.upload_normal = d_up;
+  }
+  if (spec->n_bootstrap_frame_map) {
+    double* d_up = nullptr;
+    const size_t nb = (size_t)spec->upload_data_rows * spec->upload_data_cols * sizeof(double);
+    HIP_TRY(ar.get(S_UPLOAD_DATA, nb, (void**)&d_up));
+    HIP_TRY(hipMemcpy(d_up, spec->upload_data, nb, hipMemcpyHostToDevice));
+    prm.upload_data = d_up;
+  }
   const bool scen = prm.scen_active;
   if (scen) {
     const uint32_t K = spec->n_non_factor;

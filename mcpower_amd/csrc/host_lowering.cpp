@@ -240,18 +240,30 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (spec->cluster.present && spec->estimator != MCP_EST_MLE) return unsupported("clustered data generation outside the Mle estimator");
   // general ("scenario") data-generating path: anything beyond N(0,1) predictors + N(0,1) residual + fixed design
   bool general = !scenario_is_optimistic(spec->scenario) || spec->residual_dist != MCP_RESID_NORMAL;
-  for (uint32_t j = 0; j < K; ++j) {
-    const int vt = spec->var_types[j];
-    if (vt == MCP_DIST_UPLOADED_DATA || vt == MCP_DIST_UPLOADED_BINARY || vt == MCP_DIST_UPLOADED_FACTOR)
-      return unsupported("uploaded-data marginals");
-    if (vt != MCP_DIST_NORMAL) general = true;
+  for (uint32_t j = 0; j < K; ++j)
+    if (spec->var_types[j] != MCP_DIST_NORMAL) general = true;
+  // uploaded frames (contract_adapter.rs:356-469): NORTA quantile table and / or the strict-bootstrap frame
+  if (spec->upload_normal_rows && spec->upload_normal_cols != K) {
+    err = "invalid spec: upload_normal must have one column per non-factor predictor";
+    return MCP_ERR_INVALID_SPEC;
+  }
+  if (spec->n_bootstrap_frame_map) {
+    if (spec->n_bootstrap_frame_map != K + spec->n_factors || spec->upload_data_rows == 0) {
+      err = "invalid spec: bootstrap_frame_map length must equal n_non_factor + n_factors and the frame must be non-empty";
+      return MCP_ERR_INVALID_SPEC;
+    }
+    for (uint32_t j = 0; j < spec->n_bootstrap_frame_map; ++j)
+      if (spec->bootstrap_frame_map[j] >= (int32_t)spec->upload_data_cols) {
+        err = "invalid spec: bootstrap_frame_map entry beyond the uploaded frame's columns";
+        return MCP_ERR_INVALID_SPEC;
+      }
+    general = true;
   }
   if (general && K > 6) return unsupported("general data-generating path with more than 6 continuous predictors");
   if (spec->scenario.has_lme && spec->estimator != MCP_EST_MLE) {
     err = "invalid spec: scenario.lme requires estimator == Mle";
     return MCP_ERR_INVALID_SPEC;
   }
-  if (spec->n_bootstrap_frame_map || spec->upload_normal_rows || spec->upload_data_rows) return unsupported("uploaded data");
   if (spec->n_between_var_indices) return unsupported("cluster-level (between) predictors");
   const uint32_t npc = total_posthoc_contrasts(spec);
   if (npc > (uint32_t)MAX_PC) return unsupported("more than " + std::to_string(MAX_PC) + " post-hoc contrasts");
@@ -312,7 +324,14 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     poff += nl;
   }
   prm.n_seq_pre = 0;
-  prm.n_seq_per_row = n_sampled;
+  prm.n_sampled_factors = n_sampled;
+  prm.bootstrap = spec->n_bootstrap_frame_map ? 1u : 0u;
+  prm.n_seq_per_row = n_sampled + prm.bootstrap;  // categorical draws, then the bootstrap row pick (data_gen.rs:509-566)
+  for (uint32_t j = 0; j < (uint32_t)(MAX_K + MAX_FACTORS); ++j) prm.boot_map[j] = -1;
+  for (uint32_t j = 0; j < spec->n_bootstrap_frame_map; ++j) prm.boot_map[j < K ? j : K + (j - K)] = spec->bootstrap_frame_map[j];
+  prm.upload_rows = spec->upload_normal_rows;
+  prm.upload_data_rows = spec->upload_data_rows;
+  prm.upload_data_cols = spec->upload_data_cols;
   if (spec->cluster.present) {  // data_gen.rs:146-161: one RE draw per cluster present at max_n, before the row loop
     prm.has_cluster = 1;
     prm.cluster_fixed_clusters = spec->cluster.sizing == MCP_CLUSTER_FIXED_CLUSTERS ? 1u : 0u;
@@ -396,7 +415,10 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     bool need_t3 = false, may_chi = false, may_unif = false;
     for (uint32_t i = 0; i < sc.n_new_distributions; ++i) {
       prm.new_dist[i] = sc.new_distributions[i];
-      if (sc.new_distributions[i] >= MCP_DIST_UPLOADED_DATA) return unsupported("uploaded-data marginals in the swap menu");
+      if (sc.new_distributions[i] >= MCP_DIST_UPLOADED_DATA) {
+        err = "invalid spec: uploaded-data marginals cannot appear in the scenario swap menu";
+        return MCP_ERR_INVALID_SPEC;
+      }
       if (sc.distribution_change_prob > 0.0 && sc.new_distributions[i] == MCP_DIST_HIGH_KURTOSIS) need_t3 = true;
     }
     for (uint32_t j = 0; j < K; ++j)
@@ -548,7 +570,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
           const uint32_t bit = (fb >> f) & 1u;
           if (prm.min_level_count == 0) reachable = reachable && bit == 0;
           else if (spec->estimator == MCP_EST_GLM) continue;  // the separation fallback may drop any included factor
-          else if (!prm.f_sampled[f]) reachable = reachable && bit == fixed_flag[(size_t)g * spec->n_factors + f];
+          else if (!prm.f_sampled[f] && prm.boot_map[K + f] < 0)  // a bootstrapped factor's counts are per replicate
+            reachable = reachable && bit == fixed_flag[(size_t)g * spec->n_factors + f];
         }
         if (!reachable) continue;
         if (fb) any_excl_possible = true;

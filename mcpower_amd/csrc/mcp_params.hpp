@@ -116,6 +116,14 @@ struct SimParams {
   uint32_t scen_stride;
   uint32_t _pad_scen;
   const double* t3_table;          // 2048-knot standardized t(3) PPF table (marginals/t3.rs) or null
+  // uploaded data (data_gen.rs:552-604, :1243-1277): NORTA quantile table and the strict-bootstrap frame
+  const double* upload_normal;     // [upload_rows][K] sorted standardised values per non-factor column, or null
+  uint32_t upload_rows;
+  uint32_t bootstrap;              // 1: strict mode, one source row of `upload_data` per design row
+  const double* upload_data;       // [upload_data_rows][upload_data_cols] raw frame, or null
+  uint32_t upload_data_rows, upload_data_cols;
+  int32_t boot_map[MAX_K + MAX_FACTORS];  // frame column of non-factor j / factor K + f, -1 = synthetic
+  uint32_t n_sampled_factors;      // the bootstrap uniform follows the per-row categorical draws
   // LME scenario knobs (data_gen.rs:146-161, 1069-1076): random-effect shape and per-replicate ICC jitter
   uint32_t lme_re_dist;            // mcp_residual_dist of the cluster random intercept (Normal without scenario.lme)
   uint32_t re_draws_per_cluster;   // sequential-stream draws one cluster effect consumes (1, df, or 1 + df)

@@ -207,6 +207,23 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
       }
     }
   }
+  uint32_t boot_row = 0;
+  if (SCEN && prm.bootstrap) {  // one source-row index per design row, drawn after the categorical draws (data_gen.rs:562-566)
+    const uint64_t q = (uint64_t)prm.n_seq_pre + (uint64_t)row * prm.n_seq_per_row + prm.n_sampled_factors;
+    const double u = (double)u32_to_unit_f32(sequential_word(k0, k1, q));
+    boot_row = (uint32_t)(u * (double)prm.upload_data_rows);
+    boot_row = boot_row > prm.upload_data_rows - 1u ? prm.upload_data_rows - 1u : boot_row;
+    if (FACTORS) {  // uploaded factors re-expand the copied level code (data_gen.rs:590-603)
+#pragma unroll
+      for (int f = 0; f < MAX_FACTORS; ++f) {
+        if ((uint32_t)f < cx.n_factors && prm.boot_map[K + f] >= 0) {
+          const double lv = floor(prm.upload_data[(size_t)boot_row * prm.upload_data_cols + (uint32_t)prm.boot_map[K + f]] + 0.5);
+          const uint32_t level = lv > 0.0 ? (uint32_t)lv : 0u;
+          lvl[f] = (level > 0u && level - 1u < prm.f_levels[f] - 1u) ? level : 0u;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int c = 1; c < P; ++c) {
     float v = 0.0f;
@@ -217,7 +234,14 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
         for (int t = 0; t < c; ++t) acc = acc + sl->Lp[(c - 1) * c / 2 + t] * (double)z[t];
         v = (float)acc;
         const uint32_t vt = (sl->meta >> (4 * (c - 1))) & 15u;
-        if (vt != 0u) v = (float)apply_marginal(vt, (double)v, prm.var_params[c - 1], prm.t3_table);
+        if (vt != 0u)
+          v = (float)apply_marginal(vt, (double)v, prm.var_params[c - 1], prm.t3_table, prm.upload_normal,
+                                    prm.upload_rows, K, (uint32_t)(c - 1));
+        if (prm.bootstrap && prm.boot_map[c - 1] >= 0) {  // strict mode copies the source row's value (data_gen.rs:566-589)
+          double bv = prm.upload_data[(size_t)boot_row * prm.upload_data_cols + (uint32_t)prm.boot_map[c - 1]];
+          if (prm.var_types[c - 1] == 7u) bv = (bv + prm.var_params[c - 1] >= 0.5) ? 1.0 : 0.0;  // stored = x - p
+          v = (float)bv;
+        }
       } else if (cx.ident_L) {
         v = z[c - 1];
       } else {  // x_j = f32( sum_{t<=j} L[j][t] * f64(z_t) ), t ascending, separately rounded (data_gen.rs:334-351)

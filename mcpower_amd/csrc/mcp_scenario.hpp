@@ -72,8 +72,22 @@ __device__ __forceinline__ double t3_lookup(const double* tab, double pct) {  //
 }
 
 // apply_marginal (data_gen.rs:1106-1182) on the f32-narrowed mix value widened to f64
-__device__ __forceinline__ double apply_marginal(uint32_t dist, double z, double param, const double* t3) {
+__device__ __forceinline__ double apply_marginal(uint32_t dist, double z, double param, const double* t3,
+                                                 const double* upload_normal = nullptr, uint32_t upload_rows = 0u,
+                                                 uint32_t upload_cols = 0u, uint32_t var_idx = 0u) {
   switch (dist) {
+    case 6: {  // UploadedData: NORTA, type-7 quantile of the sorted uploaded column (data_gen.rs:1253-1277)
+      if (upload_rows == 0u) return 0.0;
+      double u = phi_as(z);
+      u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+      const double pos = u * (double)(upload_rows - 1u);
+      const uint32_t lo = (uint32_t)floor(pos);
+      const uint32_t hi = lo + 1u < upload_rows - 1u ? lo + 1u : upload_rows - 1u;
+      const double frac = pos - (double)lo;
+      const double val_lo = upload_normal[(size_t)lo * upload_cols + var_idx];
+      const double val_hi = upload_normal[(size_t)hi * upload_cols + var_idx];
+      return val_lo + frac * (val_hi - val_lo);
+    }
     case 1:    // Binary
     case 7: {  // UploadedBinary
       const double u = phi_as(z);

@@ -241,9 +241,29 @@ static double ln_owned_floor(double u) {
   return log(u > fl ? u : fl);
 }
 
+/* data_gen.rs:1253-1277: type-7 (linear interpolation) quantile of the sorted uploaded column `col` */
+static double empirical_quantile(const mcp_spec* spec, uint32_t col, double u) {
+  uint32_t u_rows = spec->upload_normal_rows, n_cols = spec->upload_normal_cols;
+  if (u_rows == 0) return 0.0;
+  double pos = u * (double)(u_rows - 1);
+  size_t lo = (size_t)floor(pos);
+  size_t hi = lo + 1 < u_rows - 1 ? lo + 1 : u_rows - 1;
+  double frac = pos - (double)lo;
+  double val_lo = spec->upload_normal[lo * n_cols + col], val_hi = spec->upload_normal[hi * n_cols + col];
+  return val_lo + frac * (val_hi - val_lo);
+}
+
 /* data_gen.rs:1190-1250 (column twin of apply_marginal :1106) */
-static int apply_marginal_column(double* col, uint32_t n, int dist, double param) {
+static int apply_marginal_column(double* col, uint32_t n, int dist, double param, const mcp_spec* spec,
+                                 uint32_t var_idx) {
   switch (dist) {
+    case MCP_DIST_UPLOADED_DATA: /* NORTA: u = Phi(z) clamped to [0,1], then the inverse empirical CDF */
+      for (uint32_t i = 0; i < n; ++i) {
+        double u = mcpo_phi(col[i]);
+        u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+        col[i] = empirical_quantile(spec, var_idx, u);
+      }
+      return 0;
     case MCP_DIST_NORMAL:
     case MCP_DIST_UPLOADED_FACTOR:
       return 0;
@@ -328,12 +348,14 @@ void mcpo_compute_het_coeffs(const mcp_spec* spec, double* lp_mean, double* lp_s
 
 int mcpo_spec_supported(const mcp_spec* spec) {
   if (spec->n_non_factor > MCPO_MAX_K) return 0;
-  if (spec->n_bootstrap_frame_map || spec->upload_normal_rows || spec->upload_data_rows) return 0;
   if (spec->cluster.present && (spec->cluster.n_slopes || spec->cluster.n_extra_groupings)) return 0;
-  for (uint32_t j = 0; j < spec->n_non_factor; ++j)
-    if (spec->var_types[j] == MCP_DIST_UPLOADED_DATA || spec->var_types[j] == MCP_DIST_UPLOADED_BINARY ||
-        spec->var_types[j] == MCP_DIST_UPLOADED_FACTOR)
-      return 0;
+  /* uploaded frames: shapes must be consistent (contract_adapter.rs:356-469 builds them) */
+  if (spec->upload_normal_rows && spec->upload_normal_cols != spec->n_non_factor) return 0;
+  if (spec->n_bootstrap_frame_map) {
+    if (spec->n_bootstrap_frame_map != spec->n_non_factor + spec->n_factors || spec->upload_data_rows == 0) return 0;
+    for (uint32_t j = 0; j < spec->n_bootstrap_frame_map; ++j)
+      if (spec->bootstrap_frame_map[j] >= (int32_t)spec->upload_data_cols) return 0;
+  }
   return 1;
 }
 
@@ -444,7 +466,7 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
     } else {
       double param = j < spec->n_var_params ? spec->var_params[j] : 0.5;
       for (uint32_t i = 0; i < max_n; ++i) acc[i] = (double)(float)acc[i];
-      int rc = apply_marginal_column(acc, max_n, var_types[j], param);
+      int rc = apply_marginal_column(acc, max_n, var_types[j], param, spec, j);
       if (rc) return rc;
       for (uint32_t i = 0; i < max_n; ++i) xc[i] = (float)acc[i];
     }
@@ -513,6 +535,34 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
       if (lvl > 0 && lvl - 1 < nl - 1) x[(size_t)(col_off + lvl - 1) * max_n + i] = 1.0f;
       prop_off += nl;
       col_off += nl - 1;
+    }
+    if (spec->n_bootstrap_frame_map) { /* strict mode: one source row per design row (data_gen.rs:552-604) */
+      uint32_t u_rows = spec->upload_data_rows, ncf = spec->upload_data_cols;
+      size_t r = (size_t)((double)mcpo_simrng_next_uniform(&rng) * (double)u_rows);
+      if (r > u_rows - 1) r = u_rows - 1;
+      for (uint32_t j = 0; j < k; ++j) {
+        int32_t fc = spec->bootstrap_frame_map[j];
+        if (fc < 0) continue;
+        double v = spec->upload_data[r * ncf + (uint32_t)fc];
+        if (spec->var_types[j] == MCP_DIST_UPLOADED_BINARY) { /* stored = x - p; recover 0/1 */
+          double pp = j < spec->n_var_params ? spec->var_params[j] : 0.0;
+          v = (v + pp >= 0.5) ? 1.0 : 0.0;
+        }
+        x[(size_t)(1 + j) * max_n + i] = (float)v;
+      }
+      uint32_t start = 1 + k;
+      for (uint32_t f = 0; f < nf; ++f) {
+        uint32_t nl = spec->factor_n_levels[f] > 0 ? (uint32_t)spec->factor_n_levels[f] : 0;
+        uint32_t nd = nl ? nl - 1 : 0;
+        int32_t fc = spec->bootstrap_frame_map[k + f];
+        if (fc >= 0) {
+          double lv = round(spec->upload_data[r * ncf + (uint32_t)fc]);
+          size_t level = lv > 0.0 ? (size_t)lv : 0;
+          for (uint32_t d = 0; d < nd; ++d) x[(size_t)(start + d) * max_n + i] = 0.0f;
+          if (level > 0 && level - 1 < nd) x[(size_t)(start + level - 1) * max_n + i] = 1.0f;
+        }
+        start += nd;
+      }
     }
     if (spec->n_between_var_indices && spec->cluster.present) { /* data_gen.rs:619-636 */
       uint32_t v = spec->cluster.sizing_value ? spec->cluster.sizing_value : 1;
