@@ -90,11 +90,17 @@ def test_unsupported_fails_loudly_never_falls_back(engine):
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(s, [100], 4, BASE_SEED)
     assert e.value.status == S.Status.InvalidSpec
-    s = spec_c2b()
-    s.var_types[0] = S.Distribution.UploadedData
+    from helpers import base_spec
+    s = base_spec(9)  # 10 design columns: beyond the register-resident kernels
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(s, [100], 4, BASE_SEED)
-    assert e.value.status == S.Status.Unsupported
+    assert e.value.status == S.Status.Unsupported and "design columns" in str(e.value)
+    s = spec_c2b()
+    s.estimator = S.EstimatorSpec.Mle
+    s.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2, slopes=[{"column": 0}])
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(s, [100], 4, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "random slopes" in str(e.value)
 
 
 def test_product_does_not_reference_the_oracle():
