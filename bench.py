@@ -169,7 +169,7 @@ def main():
         if not staged:
             fits_per_launch *= len(ns)  # a replicate on a grid is len(ns) prefix fits (throughput.rs:1111-1113)
             ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "valu", "kernel": (f"ols_sim_kernel<{spec.n_predictors},fused>" if is_ols else f"{'glm' if args.workload == 'c3' else 'lmm'}_sim_kernel<{spec.n_predictors}>"),
+            out["roofline"] = {"bound": "valu", "kernel": (f"ols_sim_kernel<{spec.n_predictors},fused>" if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>")),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
                                "traffic": (pmc_traffic(args.workload, f"ols_sim_kernel<{spec.n_predictors}, 0,")
                                            if (is_ols and not is_c5 and S == 1_000_000) else None),

@@ -38,6 +38,7 @@ size_t glm_lds_bytes(int P, uint32_t max_n);
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
                           bool reduced, bool scen, hipStream_t st);
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
+size_t lmm_rec_fields(int P, uint32_t ncl_max);
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st);
 }  // namespace mcp
@@ -97,7 +98,7 @@ struct Arena {
 };
 thread_local Arena g_arena;
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
   int n = 0;
@@ -234,6 +235,15 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
       if (step < chunk) chunk = step;
     }
   }
+  if (mle) {  // the cluster-sum records between the two LMM kernels: keep one chunk's worth under 1 GiB
+    const size_t per_rep = mcp::lmm_rec_fields((int)P, prm.n_clusters_max) * n_ns * sizeof(double);
+    const size_t cap = ((size_t)1 << 30) / (per_rep ? per_rep : 1);
+    if (cap < 64) {
+      mcp_free_result(out);
+      return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: LMM cluster-sum records of one replicate exceed 16 MiB");
+    }
+    if (chunk > cap) chunk = (uint32_t)(cap & ~(size_t)63);
+  }
   if (chunk > n_sims) chunk = n_sims;
   const uint32_t n_chunks = (n_sims + chunk - 1) / chunk;
 
@@ -279,9 +289,14 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     if (spec->report_overall) DEV_TRY(ar.get(S_OVERALL, cells + 1, (void**)&d_ov));
   }
   uint8_t *d_bh = nullptr, *d_joint = nullptr;
+  double* d_lmm_rec = nullptr;
+  uint32_t* d_lmm_flags = nullptr;
+  const uint32_t lmm_stride = (chunk + 63u) & ~63u;
   if (mle) {
     DEV_TRY(ar.get(S_BOUNDARY, cells + 1, (void**)&d_bh));
     DEV_TRY(ar.get(S_JOINT, cells + 1, (void**)&d_joint));
+    DEV_TRY(ar.get(S_LMM_REC, mcp::lmm_rec_fields((int)P, prm.n_clusters_max) * n_ns * lmm_stride * sizeof(double), (void**)&d_lmm_rec));
+    DEV_TRY(ar.get(S_LMM_FLAGS, (size_t)n_ns * lmm_stride * sizeof(uint32_t), (void**)&d_lmm_flags));
   }
   if (want_stat) DEV_TRY(ar.get(S_STAT, ((size_t)n_sims * nt + 1) * sizeof(double), (void**)&d_stat));
   // design tile: [block of 256 replicates][P columns: x1..x_{P-1}, y][max_n rows][256] f32
@@ -346,6 +361,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   prm.crit_red = d_crit_red; prm.red_row = d_red_row;
   prm.ctr_posthoc_unc = layout.posthoc_unc; prm.ctr_posthoc_cor = layout.posthoc_cor;
   prm.ctr_excl_sparse = layout.excl_sparse; prm.ctr_excl_sep = layout.excl_sep;
+  prm.lmm_rec = d_lmm_rec; prm.lmm_rec_flags = d_lmm_flags; prm.lmm_rec_stride = lmm_stride;
   prm.tile = d_tile;
   prm.tile_sims = chunk;
   prm.scen_L = d_scen_L;

@@ -1,11 +1,22 @@
 // lmm_kernels.hip -- gfx950 kernel of the random-intercept LMM (REML) simulate path.
 //
-// Mapping: ONE WAVEFRONT PER REPLICATE, design resident in LDS (as the GLM kernel).  A random
-// intercept's profiled REML deviance depends on the data only through per-cluster sums
-// (n_c, sum x_c, sum y_c) and the global X'X, X'y, y'y (scripts/lme_handcompute_theta1.py:55-93),
-// so one pass (lane = cluster, rows of a cluster walked by its lane) reduces the replicate to
-// n_clusters x (p + 1) doubles in LDS; every objective evaluation of the 1-D minimiser is then a
-// lane-strided sweep over clusters + one butterfly all-reduce + a p x p Cholesky, all wave-uniform.
+// A random intercept's profiled REML deviance depends on the data only through per-cluster sums
+// (n_c, sum x_c, sum y_c) and the global X'X, X'y, y'y (scripts/lme_handcompute_theta1.py:55-93).
+// The path is therefore split in two launches with opposite shapes:
+//   1. lmm_prepare_kernel -- ONE WAVEFRONT PER REPLICATE: the n x p design is generated into LDS (rows spread
+//      over the lanes, like the GLM kernel), then for every grid N one pass (lane = cluster) forms the cluster
+//      sums v_c = (n_c, Sx_c, Sy_c).  The deviance needs them only through sum_c s(n_c) v_c v_c', and the
+//      engine's cluster layouts produce at most TWO distinct cluster sizes (i % n_clusters, or full blocks plus
+//      one partial), so the wave reduces M_k = sum_{c in size class k} v_c v_c' for k = 0, 1 and writes
+//      2 (p+1)(p+2)/2 + 4 + p(p+1)/2 + p + 1 doubles per fit, replicate-minor, plus the sparse-factor flags:
+//      an objective evaluation no longer depends on the number of clusters at all.
+//   2. lmm_optimise_kernel -- ONE LANE PER REPLICATE: Brent's minimiser, the p x p Cholesky, Wald / joint
+//      statistics and the decisions are a few hundred dependent f64 operations per objective evaluation with
+//      no parallelism inside a replicate worth a wave; 64 replicates per wave run them without a single
+//      cross-lane reduction, reading the class matrices back coalesced ([field][grid][replicate]).
+// The first version ran the optimiser wave-per-replicate (lane = cluster + a butterfly all-reduce of
+// p(p+1)/2 + p + 2 values per evaluation): 30 of 64 lanes busy, ~70 dependent shuffles per evaluation, three
+// waves per SIMD -- latency-bound at 3 % of the vector issue rate (profiles/r01_c_*).
 //
 // Reference: crates/engine-core/src/batch.rs:1214-1560 (Mle arm), data_gen.rs:146-161 (cluster
 // random-intercept draws on the sequential stream before the row loop), :811-857 (u_re added on the
@@ -35,6 +46,211 @@ __device__ __forceinline__ double lwave_sum(double v) {
   return v;
 }
 
+// ---- record layout in HBM: rec[(field * n_grid + g) * stride + replicate] ----
+// fields: M_0, M_1 (lower triangles of sum v v', v = (n_c, Sx_1..Sx_{P-1}, Sy)), then {size_0, size_1, count_0,
+// count_1}, then X'X lower (P(P+1)/2), X'y (P), y'y (1)
+template <int P>
+__host__ __device__ constexpr uint32_t lmm_m_fields() { return (P + 1) * (P + 2) / 2; }
+template <int P>
+__host__ __device__ constexpr uint32_t lmm_total_fields() { return 2 * lmm_m_fields<P>() + 4 + P * (P + 1) / 2 + P + 1; }
+
+__device__ __forceinline__ size_t rec_at(const SimParams& prm, uint32_t field, uint32_t g, uint32_t rep) {
+  return ((size_t)field * prm.n_grid + g) * prm.lmm_rec_stride + rep;
+}
+
+// LDS layout per block (one wave): design [P columns: x1..x_{P-1}, y][n_pad] f32 | cluster_u [ncl_pad] f32 |
+// staging [4(P+1)][64] f32
+// RED: exclusion flags recounted from rows [0, N) before every fit (batch.rs:1236-1250).
+// SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
+// heteroskedastic residuals) plus the LME knobs: random-effect shape and per-replicate tau^2 (data_gen.rs:146-161).
+template <int P, bool FACTORS, bool RED, bool SCEN>
+__global__ __launch_bounds__(LWAVE) void lmm_prepare_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ float lds_f[];
+  const SimParams& prm = *pp;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lsim = blockIdx.x;
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t max_n = prm.max_n;
+  const uint32_t n_pad = (max_n + 3u) & ~3u;
+  const uint32_t ncl_max = prm.n_clusters_max;
+  const uint32_t ncl_pad = (ncl_max + 1u) & ~1u;
+  const uint32_t cv = prm.cluster_v;
+  float* design = lds_f;                          // P * n_pad
+  float* cluster_u = design + (size_t)P * n_pad;  // ncl_pad
+  float* st = cluster_u + ncl_pad + lane;         // staging, stride 64
+
+  // ---- cluster random intercepts: draw c is word c of the sequential stream (data_gen.rs:146-161) ----
+  double tau_rep = prm.tau;
+  if (SCEN && prm.scen_tau_sq) {
+    const double t2 = prm.scen_tau_sq[lsim];
+    tau_rep = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
+  }
+  for (uint32_t c = lane; c < ncl_max; c += LWAVE) {
+    if (SCEN) {
+      cluster_u[c] = (float)(draw_cluster_effect(prm, k0, k1, c) * tau_rep);
+    } else {
+      const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
+      cluster_u[c] = (float)((double)z * prm.tau);
+    }
+  }
+  __syncthreads();
+
+  // ---- generate the replicate into LDS ----
+  RowCtx<P> cx;
+  row_ctx_init<P, FACTORS>(prm, cx);
+  ScenLane<P> sl;
+  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
+  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += LWAVE) {
+    stage_group<P, LWAVE, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t rr = 4u * ctr + r;
+      if (rr < max_n) {
+        const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
+        const double u_re = (double)cluster_u[cid < ncl_max ? cid : 0u];
+        float x[P], y;
+        build_row<P, FACTORS, LWAVE, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
+#pragma unroll
+        for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
+        design[(size_t)(P - 1) * n_pad + rr] = y;
+      }
+    }
+  }
+  __syncthreads();
+
+  double* rec = prm.lmm_rec;
+  constexpr uint32_t MF = lmm_m_fields<P>();
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n = prm.ns[g];
+    const uint32_t ncl = prm.cluster_fixed_clusters ? cv : (n + cv - 1u) / cv;
+    // cluster sizes are analytic: i % ncl gives ceil / floor(n / ncl); blocks of cv give cv and one partial block
+    auto size_of = [&](uint32_t c) -> uint32_t {
+      if (prm.cluster_fixed_clusters) return n > c ? (n - 1u - c) / cv + 1u : 0u;
+      const uint32_t lo = c * cv;
+      return lo >= n ? 0u : (n - lo < cv ? n - lo : cv);
+    };
+    const uint32_t size0 = size_of(0u), size1 = size_of(ncl - 1u);  // the largest and the smallest
+    // ---- per-cluster sums (lane = cluster), class matrices, global X'X, X'y, y'y ----
+    double xtx[P * (P + 1) / 2], xty[P], yty = 0.0;
+    double M0[MF], M1[MF];
+    double cnt0 = 0.0, cnt1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) xty[i] = 0.0;
+#pragma unroll
+    for (uint32_t i = 0; i < MF; ++i) {
+      M0[i] = 0.0;
+      M1[i] = 0.0;
+    }
+    for (uint32_t c = lane; c < ncl; c += LWAVE) {
+      double v[P + 1];  // (n_c, Sx_1..Sx_{P-1}, Sy)
+#pragma unroll
+      for (int a = 0; a <= P; ++a) v[a] = 0.0;
+      const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
+      const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
+      const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
+      for (uint32_t i = first; i < last; i += step) {
+        double xd[P];
+        xd[0] = 1.0;
+#pragma unroll
+        for (int a = 1; a < P; ++a) xd[a] = (double)design[(size_t)(a - 1) * n_pad + i];
+        const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
+        v[0] += 1.0;
+        v[P] += yi;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < P; ++a) {
+          if (a > 0) v[a] += xd[a];
+#pragma unroll
+          for (int q = 0; q <= a; ++q) {
+            xtx[idx] = __builtin_fma(xd[a], xd[q], xtx[idx]);
+            ++idx;
+          }
+          xty[a] = __builtin_fma(xd[a], yi, xty[a]);
+        }
+        yty = __builtin_fma(yi, yi, yty);
+      }
+      const uint32_t sz = size_of(c);
+      if (sz != 0u) {
+        const bool k0c = sz == size0;
+        cnt0 += k0c ? 1.0 : 0.0;
+        cnt1 += k0c ? 0.0 : 1.0;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a <= P; ++a)
+#pragma unroll
+          for (int q = 0; q <= a; ++q) {
+            const double pr = v[a] * v[q];
+            M0[idx] += k0c ? pr : 0.0;
+            M1[idx] += k0c ? 0.0 : pr;
+            ++idx;
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = lwave_sum(xtx[i]);
+#pragma unroll
+    for (int i = 0; i < P; ++i) xty[i] = lwave_sum(xty[i]);
+    yty = lwave_sum(yty);
+#pragma unroll
+    for (uint32_t i = 0; i < MF; ++i) {
+      M0[i] = lwave_sum(M0[i]);
+      M1[i] = lwave_sum(M1[i]);
+    }
+    cnt0 = lwave_sum(cnt0);
+    cnt1 = lwave_sum(cnt1);
+    uint32_t flag_bits = 0;
+    if (RED && prm.min_level_count) {  // update_factor_exclusions (batch.rs:2451-2500), rows [0, n)
+#pragma unroll
+      for (int f = 0; f < MAX_FACTORS; ++f) {
+        if ((uint32_t)f < prm.n_factors) {
+          uint32_t mn = 0xffffffffu;
+          for (uint32_t l = 0; l < prm.f_levels[f]; ++l) {
+            uint32_t cnt = 0;
+            for (uint32_t i = lane; i < n; i += LWAVE) {
+              uint32_t lv = 0;
+#pragma unroll
+              for (int c = 1; c < P; ++c)
+                if (prm.col_factor[c] == (uint32_t)f && design[(size_t)(c - 1) * n_pad + i] == 1.0f) lv = prm.col_level[c];
+              cnt += lv == l ? 1u : 0u;
+            }
+#pragma unroll
+            for (int m = 1; m < LWAVE; m <<= 1) cnt += __shfl_xor(cnt, m, LWAVE);
+            mn = cnt < mn ? cnt : mn;
+          }
+          if (mn < prm.min_level_count) flag_bits |= 1u << f;
+        }
+      }
+    }
+    // lanes share the stores: lane i writes fields i, i + 64, ... (all lanes hold identical reduced values)
+    {
+      double out[lmm_total_fields<P>()];
+      uint32_t o = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < MF; ++i) out[o++] = M0[i];
+#pragma unroll
+      for (uint32_t i = 0; i < MF; ++i) out[o++] = M1[i];
+      out[o++] = (double)size0;
+      out[o++] = (double)size1;
+      out[o++] = cnt0;
+      out[o++] = cnt1;
+#pragma unroll
+      for (int i = 0; i < P * (P + 1) / 2; ++i) out[o++] = xtx[i];
+#pragma unroll
+      for (int i = 0; i < P; ++i) out[o++] = xty[i];
+      out[o++] = yty;
+      if (lane == 0) {
+#pragma unroll
+        for (uint32_t f = 0; f < lmm_total_fields<P>(); ++f) rec[rec_at(prm, f, g, lsim)] = out[f];
+        prm.lmm_rec_flags[(size_t)g * prm.lmm_rec_stride + lsim] = flag_bits;
+      }
+    }
+  }
+}
+
 template <int P>
 struct LmmEval {
   bool ok;
@@ -44,45 +260,36 @@ struct LmmEval {
   double invd[P];
 };
 
-// dev(theta) and the REML solution at theta; csum = LDS [cluster][P+1] = {n_c, Sx_1..Sx_{P-1}, Sy}
-// MASKED: `keep` selects the fitted columns (identity rows/columns of X'V^-1X at the dropped ones, zero
-// right-hand side), df = n - popcount(keep): the reduced-design round of batch.rs:1252-1394.
-template <int P, bool MASKED = false>
-__device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2], const double (&xty)[P], double yty,
-                                             const double* csum, uint32_t ncl, uint32_t n, double theta,
-                                             LmmEval<P>& e, uint32_t keep = 0xffffffffu) {
-  const uint32_t lane = threadIdx.x;
+// dev(theta) and the REML solution at theta for ONE replicate held by this lane; the cluster sums stream from
+// HBM, coalesced across the wave's 64 replicates.  `keep` selects the fitted columns (identity rows/columns of
+// X'V^-1X at the dropped ones, zero right-hand side), df = n - popcount(keep): batch.rs:1252-1394.
+// dev(theta) and the REML solution at theta for ONE replicate held by this lane.  sum_c s(n_c) v_c v_c' collapses
+// to s(size_0) M_0 + s(size_1) M_1 and sum_c log(1 + theta^2 n_c) to count_0 log(..size_0) + count_1 log(..size_1).
+// `keep` selects the fitted columns (identity rows/columns of X'V^-1X at the dropped ones, zero right-hand
+// side), df = n - popcount(keep): batch.rs:1252-1394.
+template <int P, bool MASKED>
+__device__ __forceinline__ void lmm_eval_lane(const double (&M0)[(P + 1) * (P + 2) / 2], const double (&M1)[(P + 1) * (P + 2) / 2],
+                                              double size0, double size1, double cnt0, double cnt1,
+                                              const double (&xtx)[P * (P + 1) / 2], const double (&xty)[P], double yty,
+                                              uint32_t n, double theta, uint32_t keep, LmmEval<P>& e) {
   const double th2 = theta * theta;
-  double dA[P * (P + 1) / 2], db[P], dyy = 0.0, ldv = 0.0;
+  const double s0 = cnt0 > 0.0 ? th2 / (1.0 + th2 * size0) : 0.0;
+  const double s1 = cnt1 > 0.0 ? th2 / (1.0 + th2 * size1) : 0.0;
+  double dA[P * (P + 1) / 2], db[P];
+  {
+    int idx = 0, mi = 0;
 #pragma unroll
-  for (int i = 0; i < P * (P + 1) / 2; ++i) dA[i] = 0.0;
+    for (int a = 0; a <= P; ++a)
 #pragma unroll
-  for (int i = 0; i < P; ++i) db[i] = 0.0;
-  for (uint32_t c = lane; c < ncl; c += LWAVE) {
-    const double* cs = csum + (size_t)c * (P + 1);
-    const double nc = cs[0];
-    if (nc > 0.0) {
-      const double s = th2 / (1.0 + th2 * nc);
-      double sx[P];
-      sx[0] = nc;
-#pragma unroll
-      for (int a = 1; a < P; ++a) sx[a] = cs[a];
-      const double sy = cs[P];
-      int idx = 0;
-#pragma unroll
-      for (int a = 0; a < P; ++a) {
-        const double ssa = s * sx[a];
-#pragma unroll
-        for (int q = 0; q <= a; ++q) {
-          dA[idx] = __builtin_fma(ssa, sx[q], dA[idx]);
-          ++idx;
-        }
-        db[a] = __builtin_fma(ssa, sy, db[a]);
+      for (int q = 0; q <= a; ++q) {
+        const double v = __builtin_fma(s1, M1[mi], s0 * M0[mi]);
+        if (a < P) dA[idx++] = v;
+        else if (q < P) db[q] = v;
+        ++mi;
       }
-      dyy = __builtin_fma(s * sy, sy, dyy);
-      ldv += log(1.0 + th2 * nc);
-    }
   }
+  const double dyy = __builtin_fma(s1, M1[(P + 1) * (P + 2) / 2 - 1], s0 * M0[(P + 1) * (P + 2) / 2 - 1]);
+  const double ldv = (cnt0 > 0.0 ? cnt0 * log(1.0 + th2 * size0) : 0.0) + (cnt1 > 0.0 ? cnt1 * log(1.0 + th2 * size1) : 0.0);
   double A[P][P], b[P];
   {
     int idx = 0;
@@ -90,16 +297,16 @@ __device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2
     for (int a = 0; a < P; ++a) {
 #pragma unroll
       for (int q = 0; q <= a; ++q) {
-        const double v = xtx[idx] - lwave_sum(dA[idx]);
+        const double v = xtx[idx] - dA[idx];
         A[a][q] = (!MASKED || (((keep >> a) & 1u) && ((keep >> q) & 1u))) ? v : (a == q ? 1.0 : 0.0);
         ++idx;
       }
-      const double bv = xty[a] - lwave_sum(db[a]);
+      const double bv = xty[a] - db[a];
       b[a] = (!MASKED || ((keep >> a) & 1u)) ? bv : 0.0;
     }
   }
-  const double yy = yty - lwave_sum(dyy);
-  const double logdetv = lwave_sum(ldv);
+  const double yy = yty - dyy;
+  const double logdetv = ldv;
   e.ok = false;
   e.dev = __builtin_inf();
   bool ok = true;
@@ -148,151 +355,41 @@ __device__ __forceinline__ void lmm_evaluate(const double (&xtx)[P * (P + 1) / 2
   e.ok = e.dev < __builtin_inf() && e.dev > -__builtin_inf();
 }
 
-// LDS layout per block (one wave): design [P columns: x1..x_{P-1}, y][n_pad] f32 | cluster_u [ncl_pad] f32 |
-// csum [ncl_max][P+1] f64 | staging [4P][64] f32
-// RED: exclusion flags recounted from rows [0, N) before every fit (batch.rs:1236-1250); a reduced round fits the
-// kept columns, never feeds the grid-sequential theta carry (:1414-1428) and runs the joint Wald over the kept
-// targets against chi2(k_red) (:1456-1468).
-// SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
-// heteroskedastic residuals) plus the LME knobs: random-effect shape and per-replicate tau^2 (data_gen.rs:146-161).
-template <int P, bool FACTORS, bool RED, bool SCEN>
-__global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restrict__ pp) {
-  extern __shared__ double lds_d[];
+// ONE LANE PER REPLICATE: grid-sequential REML fits (theta carried along the grid, batch.rs:1323-1332,
+// :1423-1430), Wald z^2, joint Wald chi2, decisions.  RED: a reduced round fits the kept columns, never feeds the
+// theta carry (:1414-1428) and runs the joint Wald over the kept targets against chi2(k_red) (:1456-1468).
+template <int P, bool RED>
+__global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __restrict__ pp) {
   const SimParams& prm = *pp;
-  const uint32_t lane = threadIdx.x;
-  const uint32_t lsim = blockIdx.x;
-  const uint64_t sim_id = prm.sim_begin + lsim;
-  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
-  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = local < prm.n_sims;
+  const uint32_t lsim = active ? local : (prm.n_sims - 1u);
   const uint32_t out_row = prm.out_base + lsim;
-  const uint32_t max_n = prm.max_n;
-  const uint32_t n_pad = (max_n + 3u) & ~3u;
-  const uint32_t ncl_max = prm.n_clusters_max;
-  const uint32_t ncl_pad = (ncl_max + 1u) & ~1u;
-  const uint32_t cv = prm.cluster_v;
-  double* csum = lds_d;                                                   // ncl_max * (P + 1) doubles (8-byte aligned first)
-  float* design = (float*)(lds_d + (size_t)ncl_max * (P + 1));           // P * n_pad
-  float* cluster_u = design + (size_t)P * n_pad;                         // ncl_pad
-  float* st = cluster_u + ncl_pad + lane;                                // staging, stride 64
-
-  // ---- cluster random intercepts: draw c is word c of the sequential stream (data_gen.rs:146-161) ----
-  double tau_rep = prm.tau;
-  if (SCEN && prm.scen_tau_sq) {
-    const double t2 = prm.scen_tau_sq[lsim];
-    tau_rep = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
-  }
-  for (uint32_t c = lane; c < ncl_max; c += LWAVE) {
-    if (SCEN) {
-      cluster_u[c] = (float)(draw_cluster_effect(prm, k0, k1, c) * tau_rep);
-    } else {
-      const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
-      cluster_u[c] = (float)((double)z * prm.tau);
-    }
-  }
-  __syncthreads();
-
-  // ---- generate the replicate into LDS ----
-  RowCtx<P> cx;
-  row_ctx_init<P, FACTORS>(prm, cx);
-  ScenLane<P> sl;
-  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
-  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += LWAVE) {
-    stage_group<P, LWAVE, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const uint32_t rr = 4u * ctr + r;
-      if (rr < max_n) {
-        const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
-        const double u_re = (double)cluster_u[cid < ncl_max ? cid : 0u];
-        float x[P], y;
-        build_row<P, FACTORS, LWAVE, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
-#pragma unroll
-        for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
-        design[(size_t)(P - 1) * n_pad + rr] = y;
-      }
-    }
-  }
-  __syncthreads();
-
+  constexpr uint32_t MF = lmm_m_fields<P>();
+  constexpr uint32_t f_fixed = 2 * MF + 4;
+  const double* __restrict__ rec = prm.lmm_rec;
   const uint32_t nt = prm.n_tests;
   bool has_prev = false;
   double theta_carry = 0.0;
   for (uint32_t g = 0; g < prm.n_grid; ++g) {
     const uint32_t n = prm.ns[g];
-    const uint32_t ncl = prm.cluster_fixed_clusters ? cv : (n + cv - 1u) / cv;
-    // ---- per-cluster sums (lane = cluster) and global X'X, X'y, y'y ----
-    double xtx[P * (P + 1) / 2], xty[P], yty = 0.0;
+    double M0[MF], M1[MF];
 #pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < P; ++i) xty[i] = 0.0;
-    for (uint32_t c = lane; c < ncl; c += LWAVE) {
-      double sx[P], sy = 0.0, nc = 0.0;
-#pragma unroll
-      for (int a = 0; a < P; ++a) sx[a] = 0.0;
-      const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
-      const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
-      const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
-      for (uint32_t i = first; i < last; i += step) {
-        double xd[P];
-        xd[0] = 1.0;
-#pragma unroll
-        for (int a = 1; a < P; ++a) xd[a] = (double)design[(size_t)(a - 1) * n_pad + i];
-        const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
-        nc += 1.0;
-        sy += yi;
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < P; ++a) {
-          if (a > 0) sx[a] += xd[a];
-#pragma unroll
-          for (int q = 0; q <= a; ++q) {
-            xtx[idx] = __builtin_fma(xd[a], xd[q], xtx[idx]);
-            ++idx;
-          }
-          xty[a] = __builtin_fma(xd[a], yi, xty[a]);
-        }
-        yty = __builtin_fma(yi, yi, yty);
-      }
-      double* cs = csum + (size_t)c * (P + 1);
-      cs[0] = nc;
-#pragma unroll
-      for (int a = 1; a < P; ++a) cs[a] = sx[a];
-      cs[P] = sy;
+    for (uint32_t i = 0; i < MF; ++i) {
+      M0[i] = rec[rec_at(prm, i, g, lsim)];
+      M1[i] = rec[rec_at(prm, MF + i, g, lsim)];
     }
+    const double size0 = rec[rec_at(prm, 2 * MF, g, lsim)], size1 = rec[rec_at(prm, 2 * MF + 1, g, lsim)];
+    const double cnt0 = rec[rec_at(prm, 2 * MF + 2, g, lsim)], cnt1 = rec[rec_at(prm, 2 * MF + 3, g, lsim)];
+    double xtx[P * (P + 1) / 2], xty[P];
 #pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = lwave_sum(xtx[i]);
+    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = rec[rec_at(prm, f_fixed + i, g, lsim)];
 #pragma unroll
-    for (int i = 0; i < P; ++i) xty[i] = lwave_sum(xty[i]);
-    yty = lwave_sum(yty);
-    __syncthreads();
-
-    uint32_t keep = (1u << P) - 1u, flag_bits = 0;
-    if (RED) {
-      if (prm.min_level_count) {  // update_factor_exclusions (batch.rs:2451-2500), rows [0, n)
-#pragma unroll
-        for (int f = 0; f < MAX_FACTORS; ++f) {
-          if ((uint32_t)f < prm.n_factors) {
-            uint32_t mn = 0xffffffffu;
-            for (uint32_t l = 0; l < prm.f_levels[f]; ++l) {
-              uint32_t cnt = 0;
-              for (uint32_t i = lane; i < n; i += LWAVE) {
-                uint32_t lv = 0;
-#pragma unroll
-                for (int c = 1; c < P; ++c)
-                  if (prm.col_factor[c] == (uint32_t)f && design[(size_t)(c - 1) * n_pad + i] == 1.0f) lv = prm.col_level[c];
-                cnt += lv == l ? 1u : 0u;
-              }
-#pragma unroll
-              for (int m = 1; m < LWAVE; m <<= 1) cnt += __shfl_xor(cnt, m, LWAVE);
-              mn = cnt < mn ? cnt : mn;
-            }
-            if (mn < prm.min_level_count) flag_bits |= 1u << f;
-          }
-        }
-      }
-      keep = prm.keep_mask[flag_bits & 15u];
-    }
+    for (int i = 0; i < P; ++i) xty[i] = rec[rec_at(prm, f_fixed + P * (P + 1) / 2 + i, g, lsim)];
+    const double yty = rec[rec_at(prm, f_fixed + P * (P + 1) / 2 + P, g, lsim)];
+    const uint32_t rflags = prm.lmm_rec_flags[(size_t)g * prm.lmm_rec_stride + lsim];
+    const uint32_t flag_bits = RED ? (rflags & 15u) : 0u;
+    const uint32_t keep = RED ? prm.keep_mask[flag_bits] : ((1u << P) - 1u);
     const bool reduced_round = RED && keep != ((1u << P) - 1u);
 
     // ---- Brent's minimiser of dev(theta) on [0, THETA_MAX] (fmin), first probe at the start value ----
@@ -305,7 +402,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
     x = (x > a + 1e-3) ? x : a + 1e-3;
     x = (x < b - 1e-3) ? x : b - 1e-3;
     double w = x, v = x, e = 0.0, dstep = 0.0;
-    lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, x, ev, keep);
+    lmm_eval_lane<P, RED>(M0, M1, size0, size1, cnt0, cnt1, xtx, xty, yty, n, x, keep, ev);
     double fx = ev.dev, fw = fx, fv = fx;
     for (int it = 0; it < BRENT_MAX_ITERS; ++it) {
       const double xm = 0.5 * (a + b);
@@ -333,7 +430,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
         dstep = CGOLD * e;
       }
       const double u = __builtin_fabs(dstep) >= tol1 ? x + dstep : x + (dstep >= 0.0 ? tol1 : -tol1);
-      lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, u, ev, keep);
+      lmm_eval_lane<P, RED>(M0, M1, size0, size1, cnt0, cnt1, xtx, xty, yty, n, u, keep, ev);
       const double fu = ev.dev;
       if (fu <= fx) {
         if (u >= x) a = x; else b = x;
@@ -346,14 +443,14 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
     }
     // the interior search never evaluates theta = 0: compare with the boundary value
     double th = x;
-    lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, 0.0, ev, keep);
+    lmm_eval_lane<P, RED>(M0, M1, size0, size1, cnt0, cnt1, xtx, xty, yty, n, 0.0, keep, ev);
     const bool at0_ok = ev.ok;
     const double dev0 = ev.dev;
     const bool interior_ok = fx < __builtin_inf() && fx > -__builtin_inf();
     if (at0_ok && (!interior_ok || dev0 <= fx || th < THETA_ZERO)) {
       th = 0.0;  // ev already holds the theta = 0 solution
     } else {
-      lmm_evaluate<P, RED>(xtx, xty, yty, csum, ncl, n, th, ev, keep);
+      lmm_eval_lane<P, RED>(M0, M1, size0, size1, cnt0, cnt1, xtx, xty, yty, n, th, keep, ev);
     }
     bool conv = ev.ok;
     const uint32_t bh = !ev.ok ? 0u : (th < THETA_ZERO ? 1u : (th > THETA_MAX - 1e-3 ? 2u : 0u));
@@ -362,7 +459,6 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
       theta_carry = th;
       has_prev = true;
     }
-
     // ---- Wald z^2 (cov = sigma^2 (X'V^-1X)^-1), joint Wald chi2 over the targets, decisions ----
     const double* crow = prm.crit + (size_t)g * prm.crit_stride;
     double tsq[MAX_T];
@@ -451,7 +547,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
       unc_bits = 0;
       cor_bits = 0;
     }
-    if (lane == 0) {
+    if (active) {
       const size_t cell = (size_t)out_row * prm.n_grid + g;
 #pragma unroll
       for (int t = 0; t < MAX_T; ++t)
@@ -472,29 +568,31 @@ __global__ __launch_bounds__(LWAVE) void lmm_sim_kernel(const SimParams* __restr
           if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
       }
     }
-    __syncthreads();  // csum is rebuilt for the next grid point
   }
 }
 
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max) {
   const size_t n_pad = (max_n + 3u) & ~3u;
   const size_t ncl_pad = (ncl_max + 1u) & ~(size_t)1u;
-  return (size_t)ncl_max * (P + 1) * sizeof(double) + ((size_t)P * n_pad + ncl_pad + (size_t)4 * (P + 1) * LWAVE) * sizeof(float);
+  return ((size_t)P * n_pad + ncl_pad + (size_t)4 * (P + 1) * LWAVE) * sizeof(float);
 }
 
+// doubles of record storage per (replicate, grid point)
+size_t lmm_rec_fields(int P, uint32_t) { return (size_t)(P + 1) * (P + 2) + 4 + (size_t)P * (P + 1) / 2 + P + 1; }
+
 template <bool FACTORS, bool RED, bool SCEN>
-static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max,
-                               hipStream_t st) {
+static hipError_t launch_lmm_prepare(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max,
+                                     hipStream_t st) {
   const size_t lds = lmm_lds_bytes(P, max_n, ncl_max);
   const dim3 block(LWAVE), grid(n_sims);
 #define LL(PP)                                                                                                        \
   case PP: {                                                                                                          \
     if (lds > 48 * 1024) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void*)lmm_sim_kernel<PP, FACTORS, RED, SCEN>,                               \
+      hipError_t e = hipFuncSetAttribute((const void*)lmm_prepare_kernel<PP, FACTORS, RED, SCEN>,                     \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
       if (e != hipSuccess) return e;                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((lmm_sim_kernel<PP, FACTORS, RED, SCEN>), grid, block, lds, st, d_prm);                        \
+    hipLaunchKernelGGL((lmm_prepare_kernel<PP, FACTORS, RED, SCEN>), grid, block, lds, st, d_prm);                    \
   } break;
   switch (P) {
     LL(2) LL(3) LL(4) LL(5) LL(6)
@@ -504,12 +602,29 @@ static hipError_t launch_lmm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
   return hipGetLastError();
 }
 
+template <bool RED>
+static hipError_t launch_lmm_optimise(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+  const dim3 block(64), grid((n_sims + 63u) / 64u);
+  switch (P) {
+    case 2: hipLaunchKernelGGL((lmm_optimise_kernel<2, RED>), grid, block, 0, st, d_prm); break;
+    case 3: hipLaunchKernelGGL((lmm_optimise_kernel<3, RED>), grid, block, 0, st, d_prm); break;
+    case 4: hipLaunchKernelGGL((lmm_optimise_kernel<4, RED>), grid, block, 0, st, d_prm); break;
+    case 5: hipLaunchKernelGGL((lmm_optimise_kernel<5, RED>), grid, block, 0, st, d_prm); break;
+    case 6: hipLaunchKernelGGL((lmm_optimise_kernel<6, RED>), grid, block, 0, st, d_prm); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
                           bool reduced, bool scen, hipStream_t st) {
-  if (scen) return launch_lmm_f<true, true, true>(P, d_prm, n_sims, max_n, ncl_max, st);
-  if (reduced) return launch_lmm_f<true, true, false>(P, d_prm, n_sims, max_n, ncl_max, st);
-  return factors ? launch_lmm_f<true, false, false>(P, d_prm, n_sims, max_n, ncl_max, st)
-                 : launch_lmm_f<false, false, false>(P, d_prm, n_sims, max_n, ncl_max, st);
+  hipError_t e;
+  if (scen) e = launch_lmm_prepare<true, true, true>(P, d_prm, n_sims, max_n, ncl_max, st);
+  else if (reduced) e = launch_lmm_prepare<true, true, false>(P, d_prm, n_sims, max_n, ncl_max, st);
+  else if (factors) e = launch_lmm_prepare<true, false, false>(P, d_prm, n_sims, max_n, ncl_max, st);
+  else e = launch_lmm_prepare<false, false, false>(P, d_prm, n_sims, max_n, ncl_max, st);
+  if (e != hipSuccess) return e;
+  return (scen || reduced) ? launch_lmm_optimise<true>(P, d_prm, n_sims, st) : launch_lmm_optimise<false>(P, d_prm, n_sims, st);
 }
 
 }  // namespace mcp

@@ -151,6 +151,12 @@ struct SimParams {
   uint32_t ctr_posthoc_unc, ctr_posthoc_cor, ctr_excl_sparse, ctr_excl_sep;
   double joint_crit_k[MAX_T + 1];  // chi2_ppf(1 - alpha, k): joint Wald threshold over k kept targets (Mle arm)
 
+  // LMM split path: per-(replicate, grid point) cluster sums between the prepare and optimise kernels
+  double* lmm_rec;                 // [field][n_grid][lmm_rec_stride]
+  uint32_t* lmm_rec_flags;         // [n_grid][lmm_rec_stride]: exclusion flag bits | LMM_FLAG_BALANCED
+  uint32_t lmm_rec_stride;         // replicates per chunk, padded to 64
+  uint32_t _pad_lmm;
+
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;
   uint32_t tile_sims;

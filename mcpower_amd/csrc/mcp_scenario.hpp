@@ -71,49 +71,49 @@ __device__ __forceinline__ double t3_lookup(const double* tab, double pct) {  //
   return tab[ii] * (1.0 - frac) + tab[ii + 1u] * frac;
 }
 
-// apply_marginal (data_gen.rs:1106-1182) on the f32-narrowed mix value widened to f64
+// apply_marginal (data_gen.rs:1106-1182) on the f32-narrowed mix value widened to f64.
+// Lanes of a wave carry different marginals (per-replicate swaps), so a switch with one Phi per arm makes the
+// wave pay every arm.  Phi(z) and Phi(-z) share |x|, t and the exponential of the A&S form, so both are taken
+// from ONE evaluation (bitwise what phi_as(z) / phi_as(-z) return), the two skewed shapes share ONE log, and
+// the rest are selects: one exp + at most one log per value whatever mix of shapes the wave holds.
 __device__ __forceinline__ double apply_marginal(uint32_t dist, double z, double param, const double* t3,
                                                  const double* upload_normal = nullptr, uint32_t upload_rows = 0u,
                                                  uint32_t upload_cols = 0u, uint32_t var_idx = 0u) {
-  switch (dist) {
-    case 6: {  // UploadedData: NORTA, type-7 quantile of the sorted uploaded column (data_gen.rs:1253-1277)
-      if (upload_rows == 0u) return 0.0;
-      double u = phi_as(z);
-      u = u < 0.0 ? 0.0 : (u > 1.0 ? 1.0 : u);
+  if (dist == 0u || dist > 7u) return z;
+  const double x = -z * 0.70710678118654752440;
+  const double ax = __builtin_fabs(x);
+  const double t = 1.0 / (1.0 + 0.3275911 * ax);
+  const double y =
+      1.0 - (((((1.061405429 * t + -1.453152027) * t) + 1.421413741) * t + -0.284496736) * t + 0.254829592) * t * exp(-ax * ax);
+  const double u_pos = 0.5 * (1.0 - (x < 0.0 ? -1.0 : 1.0) * y);  // phi_as(z)
+  const double u_neg = 0.5 * (1.0 - (x > 0.0 ? -1.0 : 1.0) * y);  // phi_as(-z): its x is exactly -x
+  double out = z;
+  if (dist == 2u || dist == 3u) {  // Right / LeftSkewed: censored standardized Exp(1), mirrored
+    double u = dist == 2u ? u_neg : u_pos;
+    u = u > 1.0 / 2048.0 ? u : 1.0 / 2048.0;  // ln_owned's 2^-11 input floor
+    double e = -log(u);
+    e = e < EXP_CAP ? e : EXP_CAP;
+    out = dist == 2u ? (e - EXP_CENSORED_MEAN) / EXP_CENSORED_STD : (EXP_CENSORED_MEAN - e) / EXP_CENSORED_STD;
+  } else if (dist == 5u) {  // Uniform(-sqrt3, sqrt3)
+    out = -SQRT3 + (SQRT3 - (-SQRT3)) * u_pos;
+  } else if (dist == 1u || dist == 7u) {  // Binary / UploadedBinary: 1 in the high-z tail
+    out = u_pos < 1.0 - param ? 0.0 : 1.0;
+  } else if (dist == 4u) {  // HighKurtosis: standardized t(3) via the PPF table
+    out = t3 ? t3_lookup(t3, u_pos) : z;
+  } else if (dist == 6u) {  // UploadedData: NORTA, type-7 quantile of the sorted uploaded column (data_gen.rs:1253-1277)
+    out = 0.0;
+    if (upload_rows != 0u) {
+      const double u = u_pos < 0.0 ? 0.0 : (u_pos > 1.0 ? 1.0 : u_pos);
       const double pos = u * (double)(upload_rows - 1u);
       const uint32_t lo = (uint32_t)floor(pos);
       const uint32_t hi = lo + 1u < upload_rows - 1u ? lo + 1u : upload_rows - 1u;
       const double frac = pos - (double)lo;
       const double val_lo = upload_normal[(size_t)lo * upload_cols + var_idx];
       const double val_hi = upload_normal[(size_t)hi * upload_cols + var_idx];
-      return val_lo + frac * (val_hi - val_lo);
+      out = val_lo + frac * (val_hi - val_lo);
     }
-    case 1:    // Binary
-    case 7: {  // UploadedBinary
-      const double u = phi_as(z);
-      return u < 1.0 - param ? 0.0 : 1.0;
-    }
-    case 5:  // Uniform(-sqrt3, sqrt3)
-      return -SQRT3 + (SQRT3 - (-SQRT3)) * phi_as(z);
-    case 2: {  // RightSkewed: censored standardized Exp(1)
-      double u = phi_as(-z);
-      u = u > 1.0 / 2048.0 ? u : 1.0 / 2048.0;  // ln_owned's 2^-11 input floor
-      double e = -log(u);
-      e = e < EXP_CAP ? e : EXP_CAP;
-      return (e - EXP_CENSORED_MEAN) / EXP_CENSORED_STD;
-    }
-    case 3: {  // LeftSkewed
-      double u = phi_as(z);
-      u = u > 1.0 / 2048.0 ? u : 1.0 / 2048.0;
-      double e = -log(u);
-      e = e < EXP_CAP ? e : EXP_CAP;
-      return (EXP_CENSORED_MEAN - e) / EXP_CENSORED_STD;
-    }
-    case 4:  // HighKurtosis: standardized t(3) via the PPF table
-      return t3 ? t3_lookup(t3, phi_as(z)) : z;
-    default:
-      return z;
   }
+  return out;
 }
 
 // cluster random effect c of a replicate (draw_residual on the sequential stream, data_gen.rs:146-161,
