@@ -296,9 +296,9 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
 
     // ---- Wald z^2 per target (cov = (X'WX)^-1), decisions, LRT overall ----
     const double* crow = prm.crit + (size_t)g * prm.crit_stride;
-    double tsq[MAX_T];
+    double tsq[MAX_T_WAVE];
 #pragma unroll
-    for (int t = 0; t < MAX_T; ++t) {
+    for (int t = 0; t < MAX_T_WAVE; ++t) {
       tsq[t] = __builtin_nan("");
       if ((uint32_t)t < nt && conv && (!RED || ((keep >> prm.test_pos[t]) & 1u))) {
         const double* c = prm.contrast + t * MAX_P;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
     if (lane == 0) {  // the wave's replicate: one writer
       const size_t cell = (size_t)out_row * prm.n_grid + g;
 #pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
+      for (int t = 0; t < MAX_T_WAVE; ++t)
         if ((uint32_t)t < nt) {
           prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
           prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
       if (prm.overall) prm.overall[cell] = ov ? 1 : 0;
       if (prm.stat && g == 0) {
 #pragma unroll
-        for (int t = 0; t < MAX_T; ++t)
+        for (int t = 0; t < MAX_T_WAVE; ++t)
           if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
       }
       if (RED && prm.factor_excluded)

@@ -196,7 +196,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   // RED variants of the wave-per-replicate kernels; their general-path (scenario) variants build on them
   const bool glm_reduced = (prm.red_active || prm.scen_active) && glm;
   if (reduced && (flags & MCP_PIPELINE_STAGED))
-    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds");
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds or more than 8 design columns / tests");
   const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
   const uint32_t npc = prm.n_posthoc;
   const uint64_t sim_offset = opts ? opts->sim_offset : 0;
@@ -586,7 +586,7 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
 int mcp_fit_design(const float* design, const float* outcome, uint32_t n_fits, uint32_t n, uint32_t p, double* beta_out,
                    double* se_out, double* t_sq_out, double* rss_out, double* sst_out, uint8_t* converged_out) {
   if (p < 2 || p > (uint32_t)mcp::MAX_P)
-    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: design columns outside [2, 8]");
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: design columns outside [2, 12]");
   if (n <= p) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: df = N - P < 1");
   if (n_fits == 0) return MCP_OK;
   hipStream_t st = nullptr;

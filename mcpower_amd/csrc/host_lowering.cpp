@@ -231,6 +231,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   }
   if (spec->estimator == MCP_EST_OLS && spec->outcome_kind != MCP_OUTCOME_CONTINUOUS)
     return unsupported("OLS on Binary / Count outcomes");
+  if (spec->estimator != MCP_EST_OLS && (P > (uint32_t)MAX_P_WAVE || nt > (uint32_t)MAX_T_WAVE))
+    return unsupported("Glm / Mle with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests");
   if (spec->estimator == MCP_EST_GLM) {
     if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS) return unsupported("Glm on a Continuous outcome");
     if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL)
@@ -591,7 +593,10 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
         low.red_row[(size_t)g * 16u + fb] = (uint16_t)row;
       }
   }
-  prm.red_active = (npc > 0 || test_reduces || any_excl_possible) ? 1u : 0u;
+  // designs beyond the hot kernels' register budget (more than 8 columns or 8 tests) run on the reduced-design
+  // kernel too: its solve and decisions are sized at run time
+  const bool wide = P > (uint32_t)MAX_P_WAVE || nt > (uint32_t)MAX_T_WAVE;
+  prm.red_active = (npc > 0 || test_reduces || any_excl_possible || wide) ? 1u : 0u;
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))
     return unsupported("intercept-free reduced fit under Glm / Mle");
   for (uint32_t k = 0; k <= (uint32_t)MAX_T; ++k)

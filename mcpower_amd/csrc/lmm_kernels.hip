@@ -461,14 +461,14 @@ __global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __res
     }
     // ---- Wald z^2 (cov = sigma^2 (X'V^-1X)^-1), joint Wald chi2 over the targets, decisions ----
     const double* crow = prm.crit + (size_t)g * prm.crit_stride;
-    double tsq[MAX_T];
-    double U[MAX_T][P];  // L^-1 c_t
+    double tsq[MAX_T_WAVE];
+    double U[MAX_T_WAVE][P];  // L^-1 c_t
     uint32_t tkeep = 0;  // targets whose column is fitted
 #pragma unroll
-    for (int t = 0; t < MAX_T; ++t)
+    for (int t = 0; t < MAX_T_WAVE; ++t)
       if ((uint32_t)t < nt && (!RED || ((keep >> prm.test_pos[t]) & 1u))) tkeep |= 1u << t;
 #pragma unroll
-    for (int t = 0; t < MAX_T; ++t) {
+    for (int t = 0; t < MAX_T_WAVE; ++t) {
       tsq[t] = __builtin_nan("");
 #pragma unroll
       for (int i = 0; i < P; ++i) U[t][i] = 0.0;
@@ -491,15 +491,15 @@ __global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __res
     // joint: b_T' Cov_TT^-1 b_T with Cov_ab = sigma^2 U_a.U_b (Cholesky of the nt x nt block)
     bool joint_sig = false;
     if (conv && tkeep != 0u) {
-      double Lc[MAX_T][MAX_T], cj[MAX_T];
+      double Lc[MAX_T_WAVE][MAX_T_WAVE], cj[MAX_T_WAVE];
       bool jok = true;
       double qsum = 0.0;
 #pragma unroll
-      for (int j = 0; j < MAX_T; ++j) {
+      for (int j = 0; j < MAX_T_WAVE; ++j) {
         if ((uint32_t)j < nt && !((tkeep >> j) & 1u)) {  // untestable target: identity row, no contribution
           Lc[j][j] = 1.0;
 #pragma unroll
-          for (int i2 = j + 1; i2 < MAX_T; ++i2) Lc[i2][j] = 0.0;
+          for (int i2 = j + 1; i2 < MAX_T_WAVE; ++i2) Lc[i2][j] = 0.0;
         }
         if ((tkeep >> j) & 1u) {
           double dd = 0.0;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __res
           jok = jok && (dd > 0.0);
           Lc[j][j] = __builtin_sqrt(dd);
 #pragma unroll
-          for (int i2 = j + 1; i2 < MAX_T; ++i2) {
+          for (int i2 = j + 1; i2 < MAX_T_WAVE; ++i2) {
             if ((uint32_t)i2 < nt) {
               double vv = 0.0;  // U of an untestable target is all zeros
 #pragma unroll
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __res
         }
       }
 #pragma unroll
-      for (int i = 0; i < MAX_T; ++i) {
+      for (int i = 0; i < MAX_T_WAVE; ++i) {
         if ((uint32_t)i < nt) {
           const double* c = prm.contrast + i * MAX_P;
           double vv = 0.0;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __res
     if (active) {
       const size_t cell = (size_t)out_row * prm.n_grid + g;
 #pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
+      for (int t = 0; t < MAX_T_WAVE; ++t)
         if ((uint32_t)t < nt) {
           prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
           prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __res
       if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1449-1451
       if (prm.stat && g == 0) {
 #pragma unroll
-        for (int t = 0; t < MAX_T; ++t)
+        for (int t = 0; t < MAX_T_WAVE; ++t)
           if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
       }
     }

@@ -28,40 +28,41 @@ __device__ __forceinline__ void ranks_desc(const double (&t)[T], uint32_t n, uin
 
 // uncorrected + corrected decisions for the squared statistics of one fit (NaN never passes).
 // crow = [crit_unc, per-rank / per-target corrected thresholds ...]
-__device__ __forceinline__ void decide_tests(const double (&tsq)[MAX_T], uint32_t nt, const double* crow, int method,
+template <int MT>
+__device__ __forceinline__ void decide_tests(const double (&tsq)[MT], uint32_t nt, const double* crow, int method,
                                              uint32_t& unc_bits, uint32_t& cor_bits) {
   const double crit_unc = crow[0];
   unc_bits = 0;
   cor_bits = 0;
 #pragma unroll
-  for (int t = 0; t < MAX_T; ++t)
+  for (int t = 0; t < MT; ++t)
     if ((uint32_t)t < nt && tsq[t] > crit_unc) unc_bits |= 1u << t;  // NaN compares false
   if (method == 0) {
     cor_bits = unc_bits;
   } else if (method == 1 || method == 4) {  // Bonferroni / Tukey: per-target threshold
 #pragma unroll
-    for (int t = 0; t < MAX_T; ++t)
+    for (int t = 0; t < MT; ++t)
       if ((uint32_t)t < nt && tsq[t] > crow[1 + t]) cor_bits |= 1u << t;
   } else {
-    uint32_t rank[MAX_T];
-    ranks_desc<MAX_T>(tsq, nt, rank);
+    uint32_t rank[MT];
+    ranks_desc<MT>(tsq, nt, rank);
     uint32_t okb = 0;  // test t clears the threshold of its own rank
 #pragma unroll
-    for (int t = 0; t < MAX_T; ++t) {
+    for (int t = 0; t < MT; ++t) {
       if ((uint32_t)t < nt) {
         double cr = crow[1];
 #pragma unroll
-        for (int k = 1; k < MAX_T; ++k) cr = (rank[t] == (uint32_t)k && (uint32_t)k < nt) ? crow[1 + k] : cr;
+        for (int k = 1; k < MT; ++k) cr = (rank[t] == (uint32_t)k && (uint32_t)k < nt) ? crow[1 + k] : cr;
         if (tsq[t] > cr) okb |= 1u << t;
       }
     }
     if (method == 2) {  // Holm step-down: pass while every better-ranked test passed
 #pragma unroll
-      for (int t = 0; t < MAX_T; ++t) {
+      for (int t = 0; t < MT; ++t) {
         if ((uint32_t)t < nt) {
           bool pass = true;
 #pragma unroll
-          for (int j = 0; j < MAX_T; ++j)
+          for (int j = 0; j < MT; ++j)
             if ((uint32_t)j < nt && rank[j] <= rank[t] && !((okb >> j) & 1u)) pass = false;
           if (pass) cor_bits |= 1u << t;
         }
@@ -69,10 +70,10 @@ __device__ __forceinline__ void decide_tests(const double (&tsq)[MAX_T], uint32_
     } else {  // BH step-up: everything ranked at or above the last passing rank
       int last = -1;
 #pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
+      for (int t = 0; t < MT; ++t)
         if ((uint32_t)t < nt && ((okb >> t) & 1u)) last = (int)rank[t] > last ? (int)rank[t] : last;
 #pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
+      for (int t = 0; t < MT; ++t)
         if ((uint32_t)t < nt && (int)rank[t] <= last) cor_bits |= 1u << t;
     }
   }

@@ -10,10 +10,12 @@
 
 namespace mcp {
 
-constexpr int MAX_P = 8;         // design columns incl. intercept handled by the register-resident kernels
-constexpr int MAX_K = 7;         // continuous predictors
+constexpr int MAX_P = 12;        // design columns incl. intercept handled by the register-resident OLS kernels
+constexpr int MAX_P_WAVE = 8;    // ... by the wave-per-replicate GLM kernels (Mle: 6)
+constexpr int MAX_K = 11;        // continuous predictors
 constexpr int MAX_GRID = 64;     // sample-size grid points per call
-constexpr int MAX_T = 8;         // tests per fit (marginal targets + contrast pairs)
+constexpr int MAX_T = 12;        // tests per fit (marginal targets + contrast pairs)
+constexpr int MAX_T_WAVE = 8;    // ... in the GLM / LMM kernels (no contrast pairs there, targets <= P - 1)
 constexpr int MAX_FACTORS = 4;
 constexpr int MAX_LEVELS = 16;   // sum of levels over all factors
 constexpr int MAX_PC = 28;       // post-hoc pairwise contrasts per fit (<= 7 dummies: one 8-level factor = C(8,2))

@@ -33,8 +33,18 @@ __device__ __forceinline__ uint32_t categorical(const SimParams& prm, uint32_t f
 // LDS layout: stage[slot * 256 + tid], slot = 4 * column + r, column j < K = continuous predictor j,
 // column K = the residual.  One Philox call yields rows 4*ctr..4*ctr+3 of one column (rng.rs:149-178).
 
-template <int STRIDE>
-__device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const u32x4 w, uint32_t& pend) {
+// pending-tail mask: 4 bits per staged column; more than 8 columns need 64 bits
+template <int P>
+struct PendMask { typedef uint32_t type; };
+template <> struct PendMask<9> { typedef unsigned long long type; };
+template <> struct PendMask<10> { typedef unsigned long long type; };
+template <> struct PendMask<11> { typedef unsigned long long type; };
+template <> struct PendMask<12> { typedef unsigned long long type; };
+__device__ __forceinline__ uint32_t pend_ctz(uint32_t m) { return (uint32_t)__builtin_ctz(m); }
+__device__ __forceinline__ uint32_t pend_ctz(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }
+
+template <int STRIDE, typename MaskT>
+__device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const u32x4 w, MaskT& pend) {
   const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -42,7 +52,7 @@ __device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const
     const bool tail = __builtin_fabsf(v) > NORM_INV_BP;
     const float z = icdf_central(v);           // branch-free central polynomial for every lane
     st[(col_slot * 4u + r) * STRIDE] = tail ? v : z;  // tail lanes park v for the fix-up loop
-    pend |= tail ? (1u << (col_slot * 4u + r)) : 0u;
+    pend |= tail ? ((MaskT)1 << (col_slot * 4u + r)) : (MaskT)0;
   }
 }
 
@@ -53,7 +63,8 @@ template <int P, int STRIDE, int OUTCOME, bool SCEN = false>
 __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr, float* st,
                                             uint32_t scen_meta = 0u) {
   const uint32_t K = prm.K;
-  uint32_t pend = 0;
+  typedef typename PendMask<P>::type mask_t;
+  mask_t pend = 0;
   float eu[4] = {0.f, 0.f, 0.f, 0.f};  // slot-0 uniforms (Uniform residual, data_gen.rs:485-501)
 #pragma unroll
   for (int j = 0; j < P - 1; ++j)
@@ -75,10 +86,10 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
     st[(K * 4u + 3u) * STRIDE] = u32_to_unit_f32(w.w);
   }
   // tail fix-up: each pass retires one parked draw per lane; ~3-4 passes per block instead of 4*(K+1)
-  while (__ballot(pend != 0u) != 0ull) {
-    if (pend != 0u) {
-      const uint32_t slot = (uint32_t)__builtin_ctz(pend);
-      pend &= pend - 1u;
+  while (__ballot(pend != 0) != 0ull) {
+    if (pend != 0) {
+      const uint32_t slot = pend_ctz(pend);
+      pend &= pend - 1;
       st[slot * STRIDE] = icdf_tail(st[slot * STRIDE]);
     }
   }
@@ -96,12 +107,12 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
 #pragma unroll
       for (int r = 0; r < 4; ++r) chi_sk[r] = (double)z0[r] * (double)z0[r];  // skewed forms start at slot 0
       for (uint32_t s = 1; s <= dfi; ++s) {
-        uint32_t pd = 0;
+        mask_t pd = 0;
         stage_column<STRIDE>(st, K + 1u, planar_words(k0, k1, CLASS_RESID, s, ctr), pd);
-        while (__ballot(pd != 0u) != 0ull) {
-          if (pd != 0u) {
-            const uint32_t slot = (uint32_t)__builtin_ctz(pd);
-            pd &= pd - 1u;
+        while (__ballot(pd != 0) != 0ull) {
+          if (pd != 0) {
+            const uint32_t slot = pend_ctz(pd);
+            pd &= pd - 1;
             st[slot * STRIDE] = icdf_tail(st[slot * STRIDE]);
           }
         }

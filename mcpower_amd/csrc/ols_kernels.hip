@@ -103,9 +103,9 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   // ---- squared statistic per test: (c'beta)^2 / (sigma^2 ||L^-1 c||^2)  (posthoc.rs:86-99) ----
   const double* crow = prm.crit + (size_t)g * prm.crit_stride;
   const uint32_t nt = prm.n_tests;
-  double tsq[MAX_T];
+  double tsq[MAX_T_WAVE];
 #pragma unroll
-  for (int t = 0; t < MAX_T; ++t) {
+  for (int t = 0; t < MAX_T_WAVE; ++t) {
     tsq[t] = __builtin_nan("");
     if ((uint32_t)t < nt) {
       const double* c = prm.contrast + t * MAX_P;
@@ -147,7 +147,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
     const size_t cell = (size_t)out_row * prm.n_grid + g;
     if (prm.unc) {
 #pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
+      for (int t = 0; t < MAX_T_WAVE; ++t)
         if ((uint32_t)t < nt) {
           prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
           prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
     if (prm.overall) prm.overall[cell] = ov ? 1 : 0;
     if (prm.stat && g == 0) {
 #pragma unroll
-      for (int t = 0; t < MAX_T; ++t)
+      for (int t = 0; t < MAX_T_WAVE; ++t)
         if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
     }
   }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   const bool lane0 = (threadIdx.x & 63u) == 0u;
   const uint32_t ub = active ? unc_bits : 0u, cb = active ? cor_bits : 0u;
 #pragma unroll
-  for (int t = 0; t < MAX_T; ++t) {
+  for (int t = 0; t < MAX_T_WAVE; ++t) {
     if ((uint32_t)t < nt) {
       const unsigned long long mu = __ballot((ub >> t) & 1u);
       const unsigned long long mc = __ballot((cb >> t) & 1u);
@@ -181,7 +181,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   }
   const uint32_t ku = __popc(ub), kc = __popc(cb);
 #pragma unroll
-  for (int k = 0; k <= MAX_T; ++k) {
+  for (int k = 0; k <= MAX_T_WAVE; ++k) {
     if ((uint32_t)k <= nt) {
       const unsigned long long hu = __ballot(active && ku == (uint32_t)k);
       const unsigned long long hc = __ballot(active && kc == (uint32_t)k);
@@ -473,7 +473,7 @@ hipError_t launch_ols_fit_provided(int P, const float* design, const float* outc
 #define LFP(PP) \
   case PP: hipLaunchKernelGGL((ols_fit_provided_kernel<PP>), grid, block, 0, st, design, outcome, n_fits, n, beta, se, tsq, rss, sst, conv); break;
   switch (P) {
-    LFP(2) LFP(3) LFP(4) LFP(5) LFP(6) LFP(7) LFP(8)
+    LFP(2) LFP(3) LFP(4) LFP(5) LFP(6) LFP(7) LFP(8) LFP(9) LFP(10) LFP(11) LFP(12)
     default: return hipErrorInvalidValue;
   }
 #undef LFP

@@ -332,3 +332,65 @@ def test_lmm_under_scenario_presets_with_lme_knobs(engine, oracle, name):
     m = ~np.isnan(o.stat_capture) & ~np.isnan(g.stat_capture)
     rel = np.abs(g.stat_capture[m] - o.stat_capture[m]) / np.maximum(o.stat_capture[m], 1e-9)
     assert np.quantile(rel, 0.99) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# wide OLS designs (9..12 columns, up to 12 tests): run-time sized solve on the reduced-design kernel
+# ---------------------------------------------------------------------------------------------
+def test_wide_ols_eleven_predictors(engine, oracle):
+    from helpers import base_spec
+    spec = base_spec(11)
+    c = np.eye(11)
+    c[0, 1] = c[1, 0] = 0.4
+    c[2, 5] = c[5, 2] = -0.3
+    c[9, 10] = c[10, 9] = 0.5
+    spec.correlation = c.flatten().tolist()
+    spec.effect_sizes = [0.0, 0.25, 0.2, 0.15, 0.1, 0.0, 0.3, -0.2, 0.0, 0.12, 0.18, -0.15]
+    spec.target_indices = list(range(1, 12))
+    spec.contrast_pairs = [(1, 2)]
+    spec.correction_method = S.CorrectionMethod.Holm
+    spec.report_overall = True
+    g, o = _both(engine, oracle, spec, [40, 41, 150, 400], 3000, 61)
+    _assert_reduced_equal(g, o)
+    assert g.shape.n_targets == 12 and g.uncorrected[:, 3, 0].mean() > 0.9
+    d, y = engine.generate_design(spec, 150, 3, 61, 0)
+    for s in range(3):
+        xo, yo, _ = oracle.generate_sim_data(spec, 61, s, 150)
+        assert np.array_equal(d[s].view(np.uint32), xo.view(np.uint32)) and np.array_equal(y[s], yo)
+    f = engine.fit_design(d, y)
+    for s in range(3):
+        fo = oracle.ols_fit(d[s], y[s])
+        assert np.allclose(f["beta"][s], fo["beta"], rtol=1e-10, atol=1e-13)
+        assert np.allclose(f["t_sq"][s], fo["t_sq"], rtol=1e-9)
+
+
+def test_wide_ols_factors_interactions_posthoc_and_exclusion(engine, oracle):
+    spec = S.SimulationSpec(
+        n_non_factor=3, n_factor_dummies=5, correlation=[1.0, 0.3, 0.0, 0.3, 1.0, 0.2, 0.0, 0.2, 1.0],
+        var_types=[S.Distribution.Normal] * 3, var_params=[0.0] * 3, factor_n_levels=[3, 4],
+        factor_proportions=[0.5, 0.3, 0.2, 0.4, 0.3, 0.2, 0.1], factor_sampled=[None, True],
+        interactions=[[1, 4], [1, 5], [2, 3]],
+        effect_sizes=[0.0, 0.3, 0.2, 0.1, 0.4, -0.3, 0.2, 0.3, 0.5, 0.15, -0.1, 0.2],
+        target_indices=[1, 2, 3, 4, 5, 9, 10, 11], contrast_pairs=[(6, 7), (8, 6)],
+        posthoc=[S.PosthocSpec(1, [6, 7, 8])], correction_method=S.CorrectionMethod.BenjaminiHochberg,
+        factor_min_level_count=5, report_overall=True)
+    assert spec.n_predictors == 12
+    g, o = _both(engine, oracle, spec, [40, 90, 300], 2500, 62)
+    _assert_reduced_equal(g, o)
+    assert g.shape.n_posthoc_contrasts == 6 and 0 < g.factor_excluded[:, 0, 1].sum() < 2500
+
+
+def test_wide_ols_under_a_scenario_preset(engine, oracle):
+    from helpers import preset
+    spec = S.SimulationSpec(
+        n_non_factor=5, n_factor_dummies=3, correlation=np.eye(5).ravel().tolist(),
+        var_types=[S.Distribution.Normal] * 5, var_params=[0.0] * 5, factor_n_levels=[4],
+        factor_proportions=[0.4, 0.3, 0.2, 0.1], interactions=[[1, 2]],
+        effect_sizes=[0.0, 0.3, 0.2, 0.0, 0.1, 0.25, 0.4, -0.3, 0.2, 0.15], target_indices=[1, 2, 5, 6, 9],
+        factor_min_level_count=5, scenario=preset("realistic"))
+    assert spec.n_predictors == 10
+    g = engine.run_batch(spec, [60, 200], 2500, 63, stat_capture=True)
+    o = oracle.run_batch(spec, [60, 200], 2500, 63, stat_capture=True, n_threads=8)
+    assert np.array_equal(g.factor_excluded, o.factor_excluded)
+    for f in ("uncorrected", "corrected", "converged"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 3e-4, f
