@@ -36,15 +36,17 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
   return v;
 }
 
-// mean / weight / working response / deviance contribution of one observation (R glm.fit forms)
-__device__ __forceinline__ void fam_eval(uint32_t fam, double eta, double yi, double& w, double& z, double& dev_i) {
+// IRLS weight w, the product w * z of weight and working response, and the deviance contribution of one
+// observation (R glm.fit forms).  X'Wz only ever needs w * z = w * eta + (y - mu) * (w / mu'), which for the
+// canonical links is w * eta + (y - mu): no division by the (possibly floored) weight.
+__device__ __forceinline__ void fam_eval(uint32_t fam, double eta, double yi, double& w, double& wz, double& dev_i) {
   if (fam == 0u) {
     const double ea = exp(-__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
     const double inv = 1.0 / (1.0 + ea);
     const double pr = eta >= 0.0 ? inv : ea * inv;  // stable sigmoid
     w = pr * (1.0 - pr);
     w = w < W_FLOOR ? W_FLOOR : w;
-    z = eta + (yi - pr) / w;
+    wz = __builtin_fma(w, eta, yi - pr);
     // -2 log-likelihood of a Bernoulli observation: log p = -log1p(e^-eta), log(1-p) = -eta - log1p(e^-eta) (eta >= 0)
     const double l1p = log1p(ea);
     const double ll = yi > 0.5 ? (eta >= 0.0 ? -l1p : eta - l1p) : (eta >= 0.0 ? -eta - l1p : -l1p);
@@ -57,12 +59,12 @@ __device__ __forceinline__ void fam_eval(uint32_t fam, double eta, double yi, do
     dmu = dmu < 2.220446049250313e-16 ? 2.220446049250313e-16 : dmu;
     w = dmu * dmu / (mu * omu);
     w = w < W_FLOOR ? W_FLOOR : w;
-    z = eta + (yi - mu) / dmu;
+    wz = w * (eta + (yi - mu) / dmu);
     dev_i = -2.0 * (yi > 0.5 ? log(mu) : log(omu));
   } else {  // Poisson, log link
     const double mu = exp(eta);
     w = mu < W_FLOOR ? W_FLOOR : mu;
-    z = eta + (yi - mu) / w;
+    wz = __builtin_fma(w, eta, yi - mu);
     dev_i = 2.0 * ((yi > 0.0 ? yi * log(yi / mu) : 0.0) - (yi - mu));
   }
 }
@@ -93,8 +95,8 @@ __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, ui
       double eta = 0.0;
 #pragma unroll
       for (int c = 0; c < P; ++c) eta = __builtin_fma(xd[c], beta[c], eta);
-      double w, z, di;
-      fam_eval(fam, eta, yi, w, z, di);
+      double w, wz, di;
+      fam_eval(fam, eta, yi, w, wz, di);
       d += di;
       int idx = 0;
 #pragma unroll
@@ -105,7 +107,7 @@ __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, ui
           xtwx[idx] = __builtin_fma(wxa, xd[b], xtwx[idx]);
           ++idx;
         }
-        xtwz[a] = __builtin_fma(wxa, z, xtwz[a]);
+        xtwz[a] = __builtin_fma(xd[a], wz, xtwz[a]);
       }
     }
 #pragma unroll

@@ -50,9 +50,65 @@ __device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const
   for (int r = 0; r < 4; ++r) {
     const float v = u32_to_unit_f32(ws[r]) - 0.5f;
     const bool tail = __builtin_fabsf(v) > NORM_INV_BP;
-    const float z = icdf_central(v);           // branch-free central polynomial for every lane
-    st[(col_slot * 4u + r) * STRIDE] = tail ? v : z;  // tail lanes park v for the fix-up loop
+    // branch-free central polynomial for every lane.  (Forcing v_pk_mul_f32 / v_pk_add_f32 over draw pairs was
+    // measured 8 % SLOWER on the fused kernel: packed f32 issues at ~1.6x the scalar cost here, profiles/README.)
+    const float z = icdf_central(v);
+    st[(col_slot * 4u + r) * STRIDE] = tail ? v : z;  // tail lanes park v for the fix-up
     pend |= tail ? ((MaskT)1 << (col_slot * 4u + r)) : (MaskT)0;
+  }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave: Hillis-Steele inside each row of 16 with DPP row shifts,
+// then the row totals carried across with row_bcast15 / row_bcast31 (gfx9 DPP)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast31 into rows 2, 3
+  return x;
+}
+
+constexpr uint32_t TAIL_QUEUE = 128;  // entries per wave of the dense tail queue
+
+// Tail fix-up of one staged block.  ~4.85 % of the draws need the tail branch of the inverse CDF; a per-lane loop
+// runs max_lane(count) passes of the ~75-instruction branch with most lanes idle (3-4 passes for ~0.8 parked draws
+// per lane).  The dense form compacts the wave's parked draws into an LDS queue (prefix sum over the lanes) and
+// lets all 64 lanes work them off: ~50 draws per wave and block = one full pass.
+template <int STRIDE, typename MaskT>
+__device__ __forceinline__ void fixup_tails(float* st, MaskT pend, uint32_t* queue) {
+  if (queue != nullptr) {
+    const uint32_t cnt = (uint32_t)__popcll((unsigned long long)pend);
+    const uint32_t incl = wave_inclusive_scan_u32(cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0u) return;
+    if (total <= TAIL_QUEUE) {
+      uint32_t off = incl - cnt;
+      MaskT m = pend;
+      while (m != 0) {  // each parked draw: its index in the block's staging area
+        const uint32_t slot = pend_ctz(m);
+        m &= m - 1;
+        queue[off++] = slot * STRIDE + threadIdx.x;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float* base = st - threadIdx.x;
+      for (uint32_t j = threadIdx.x & 63u; j < total; j += 64u) {
+        const uint32_t idx = queue[j];
+        base[idx] = icdf_tail(base[idx]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
+  }
+  while (__ballot(pend != 0) != 0ull) {
+    if (pend != 0) {
+      const uint32_t slot = pend_ctz(pend);
+      pend &= pend - 1;
+      st[slot * STRIDE] = icdf_tail(st[slot * STRIDE]);
+    }
   }
 }
 
@@ -61,7 +117,7 @@ __device__ __forceinline__ void stage_column(float* st, uint32_t col_slot, const
 // Uniform(0,1) draw in the residual slot, probit and Poisson a standard normal (data_gen.rs:390-411)
 template <int P, int STRIDE, int OUTCOME, bool SCEN = false>
 __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, uint32_t k1, uint32_t ctr, float* st,
-                                            uint32_t scen_meta = 0u) {
+                                            uint32_t scen_meta = 0u, uint32_t* tail_queue = nullptr) {
   const uint32_t K = prm.K;
   typedef typename PendMask<P>::type mask_t;
   mask_t pend = 0;
@@ -85,14 +141,7 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
     st[(K * 4u + 2u) * STRIDE] = u32_to_unit_f32(w.z);
     st[(K * 4u + 3u) * STRIDE] = u32_to_unit_f32(w.w);
   }
-  // tail fix-up: each pass retires one parked draw per lane; ~3-4 passes per block instead of 4*(K+1)
-  while (__ballot(pend != 0) != 0ull) {
-    if (pend != 0) {
-      const uint32_t slot = pend_ctz(pend);
-      pend &= pend - 1;
-      st[slot * STRIDE] = icdf_tail(st[slot * STRIDE]);
-    }
-  }
+  fixup_tails<STRIDE, mask_t>(st, pend, tail_queue);
   if (SCEN && OUTCOME == 0) {
     // residual shapes (data_gen.rs:412-501): slot 0 = z; t / chi-square forms add the normals of slots 1..df.
     // The realized distribution is per replicate (scenario swap), the column count is launch-uniform.
@@ -109,13 +158,7 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
       for (uint32_t s = 1; s <= dfi; ++s) {
         mask_t pd = 0;
         stage_column<STRIDE>(st, K + 1u, planar_words(k0, k1, CLASS_RESID, s, ctr), pd);
-        while (__ballot(pd != 0) != 0ull) {
-          if (pd != 0) {
-            const uint32_t slot = pend_ctz(pd);
-            pd &= pd - 1;
-            st[slot * STRIDE] = icdf_tail(st[slot * STRIDE]);
-          }
-        }
+        fixup_tails<STRIDE, mask_t>(st, pd, nullptr);  // ~12 parked draws per wave: the loop is cheaper than a scan
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double g = (double)st[((K + 1u) * 4u + r) * STRIDE];

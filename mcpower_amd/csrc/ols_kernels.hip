@@ -236,6 +236,8 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
   const uint32_t out_row = prm.out_base + lsim;
   const uint32_t max_n = prm.max_n;
   float* st = stage_lds + threadIdx.x;
+  // dense tail queue of this wave, behind the staging area
+  uint32_t* tq = reinterpret_cast<uint32_t*>(stage_lds + (size_t)4 * (P + (SCEN ? 1 : 0)) * BLOCK) + (threadIdx.x >> 6) * TAIL_QUEUE;
   RowCtx<P> cx;
   if (MODE != MODE_FIT) row_ctx_init<P, FACTORS>(prm, cx);
   ScenLane<P> sl;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
   const uint32_t n_quads = (max_n + 3u) >> 2;
   if (MODE == MODE_GENERATE) {
     for (uint32_t ctr = 0; ctr < n_quads; ++ctr) {
-      stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
+      stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u, tq);
       float q[P][4];  // [column: x1..x_{P-1}, y][row of the quad]
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(BLOCK, MCP_LB_W) void ols_sim_kernel(const SimParam
     if (MODE == MODE_FUSED) {
       while (row < n_end) {
         const uint32_t base = row & ~3u;
-        if ((row & 3u) == 0u) stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, row >> 2, st, SCEN ? sl.meta : 0u);
+        if ((row & 3u) == 0u) stage_group<P, BLOCK, 0, SCEN>(prm, k0, k1, row >> 2, st, SCEN ? sl.meta : 0u, tq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const uint32_t rr = base + (uint32_t)r;
@@ -432,7 +434,8 @@ static hipError_t launch_sim_pgf(int P, const SimParams* d_prm, uint32_t n_sims,
   const dim3 block(BLOCK), grid((n_sims + BLOCK - 1u) / BLOCK);
   // staging area: 4 rows x (K + 1 <= P) columns x 256 lanes of f32 (+1 scratch column on the general path;
   // none for the fit-only kernel)
-  const size_t lds = MODE == MODE_FIT ? 0 : (size_t)4 * (P + (FLAVOR == 2 ? 1 : 0)) * BLOCK * sizeof(float);
+  const size_t lds = MODE == MODE_FIT ? 0 : (size_t)4 * (P + (FLAVOR == 2 ? 1 : 0)) * BLOCK * sizeof(float) +
+                                                (BLOCK / 64) * TAIL_QUEUE * sizeof(uint32_t);
   switch (P) {
     case 2: hipLaunchKernelGGL((ols_sim_kernel<2, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
     case 3: hipLaunchKernelGGL((ols_sim_kernel<3, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
