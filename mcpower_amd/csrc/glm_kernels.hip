@@ -30,10 +30,82 @@ constexpr double BETA_CAP = 30.0;  // batch.rs:4550
 constexpr double W_FLOOR = 1e-10;
 constexpr double GLM_NEAR_ZERO = 1e-30;
 
+// All-reduce over the wave without LDS traffic: rotations inside each row of 16 lanes (DPP row_ror 8, 4, 2, 1 --
+// every lane ends with its row's total, bitwise the same in all 16 because each step adds a commuting pair),
+// then the four row totals read through scalar registers and summed in one order by every lane.  The previous
+// xor butterfly cost 12 ds_bpermute per value (180 per IRLS pass at p = 4) and their LDS latency with 2-3 waves
+// per SIMD.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_allreduce_sum(double v) {
-#pragma unroll
-  for (int m = 1; m < WAVE; m <<= 1) v += __shfl_xor(v, m, WAVE);
-  return v;
+  v += dpp_f64<0x128>(v);  // row_ror:8
+  v += dpp_f64<0x124>(v);  // row_ror:4
+  v += dpp_f64<0x122>(v);  // row_ror:2
+  v += dpp_f64<0x121>(v);  // row_ror:1
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// ---- short f64 kernels for the logistic row: e^{-a} (a >= 0), 1 / u and log(u) (u in (1, 2]).  ocml's exp and
+// log1p are correctly-rounded-grade double-double expansions (~150 instructions each here, ISA count) and made
+// the IRLS row 4x the cost of its algebra; IRLS needs ~1e-15, not the last bit (the stopping rule is 1e-8 on the
+// deviance).  Maximum relative error against libm: exp 2.3e-16 on [0, 700], log1p 5.6e-16 (checked in numpy
+// with the same operations; tests/test_gpu_parity.py compares the fits with the oracle's glibc path). ----
+__device__ __forceinline__ double fast_rcp(double d) {  // v_rcp_f64 + one Newton step
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+  return y;
+}
+
+__device__ __forceinline__ double exp_neg(double a) {  // e^{-a}, a >= 0
+  const double kf = __builtin_rint(a * 1.4426950408889634);
+  double r = __builtin_fma(kf, -6.93147180369123816490e-01, a);  // Cody-Waite: a - k ln2 (hi, lo)
+  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+  const double x = -r;  // |x| <= ln2 / 2
+  double p = 1.6059043836821613e-10;  // 1/13!
+  p = __builtin_fma(p, x, 2.08767569878681e-09);
+  p = __builtin_fma(p, x, 2.505210838544172e-08);
+  p = __builtin_fma(p, x, 2.755731922398589e-07);
+  p = __builtin_fma(p, x, 2.7557319223985893e-06);
+  p = __builtin_fma(p, x, 2.48015873015873e-05);
+  p = __builtin_fma(p, x, 0.0001984126984126984);
+  p = __builtin_fma(p, x, 0.001388888888888889);
+  p = __builtin_fma(p, x, 0.008333333333333333);
+  p = __builtin_fma(p, x, 0.041666666666666664);
+  p = __builtin_fma(p, x, 0.16666666666666666);
+  p = __builtin_fma(p, x, 0.5);
+  p = __builtin_fma(p, x, 1.0);
+  p = __builtin_fma(p, x, 1.0);
+  return ldexp(p, -(int)kf);
+}
+
+// log(1 + x) for x in [0, 1] given u = 1 + x and ru = 1 / u: log(u) by the atanh series on m = u or u / 2 in
+// (1/sqrt2, sqrt2], plus the rounding of 1 + x carried as (x - (u - 1)) / u
+__device__ __forceinline__ double log1p_unit(double x, double u, double ru) {
+  const double c = x - (u - 1.0);
+  const bool big = u > 1.4142135623730951;
+  const double m = big ? u * 0.5 : u;
+  const double s = (m - 1.0) * fast_rcp(m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 21.0;
+  p = __builtin_fma(p, z, 1.0 / 19.0);
+  p = __builtin_fma(p, z, 1.0 / 17.0);
+  p = __builtin_fma(p, z, 1.0 / 15.0);
+  p = __builtin_fma(p, z, 1.0 / 13.0);
+  p = __builtin_fma(p, z, 1.0 / 11.0);
+  p = __builtin_fma(p, z, 1.0 / 9.0);
+  p = __builtin_fma(p, z, 1.0 / 7.0);
+  p = __builtin_fma(p, z, 1.0 / 5.0);
+  p = __builtin_fma(p, z, 1.0 / 3.0);
+  p = __builtin_fma(p, z, 1.0);
+  return __builtin_fma(2.0 * s, p, (big ? 0.6931471805599453 : 0.0)) + c * ru;
 }
 
 // IRLS weight w, the product w * z of weight and working response, and the deviance contribution of one
@@ -41,14 +113,15 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
 // canonical links is w * eta + (y - mu): no division by the (possibly floored) weight.
 __device__ __forceinline__ void fam_eval(uint32_t fam, double eta, double yi, double& w, double& wz, double& dev_i) {
   if (fam == 0u) {
-    const double ea = exp(-__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
-    const double inv = 1.0 / (1.0 + ea);
+    const double ea = exp_neg(__builtin_fabs(eta));  // e^{-|eta|} in (0, 1]
+    const double u = 1.0 + ea;
+    const double inv = fast_rcp(u);
     const double pr = eta >= 0.0 ? inv : ea * inv;  // stable sigmoid
     w = pr * (1.0 - pr);
     w = w < W_FLOOR ? W_FLOOR : w;
     wz = __builtin_fma(w, eta, yi - pr);
     // -2 log-likelihood of a Bernoulli observation: log p = -log1p(e^-eta), log(1-p) = -eta - log1p(e^-eta) (eta >= 0)
-    const double l1p = log1p(ea);
+    const double l1p = log1p_unit(ea, u, inv);
     const double ll = yi > 0.5 ? (eta >= 0.0 ? -l1p : eta - l1p) : (eta >= 0.0 ? -eta - l1p : -l1p);
     dev_i = -2.0 * ll;
   } else if (fam == 1u) {  // probit: eta clamped to +-qnorm(eps), mu' floored at eps (R's probit link)
@@ -73,10 +146,13 @@ __device__ __forceinline__ void fam_eval(uint32_t fam, double eta, double yi, do
 // MASKED: `keep` selects the fitted columns; dropped columns become identity rows/columns of X'WX and zeros of
 // X'Wz, so their coefficients stay exactly 0 and the kept block is solved by the same operations as the gathered
 // p_red x p_red system of the reference's reduced round (batch.rs:1893-1925).
-template <int P, bool MASKED>
+// LOGIT: the family is known at compile time (the probit / Poisson arms and their ocml expansions stay out of the
+// kernel's register allocation: 180 -> fewer VGPRs, one more wave per SIMD).
+template <int P, bool MASKED, bool LOGIT>
 __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, uint32_t n, uint32_t lane, uint32_t keep,
-                                         uint32_t fam, double (&beta)[P], double (&Lm)[P][P], double (&invd)[P],
+                                         uint32_t fam_rt, double (&beta)[P], double (&Lm)[P][P], double (&invd)[P],
                                          double& dev, bool& conv) {
+  const uint32_t fam = LOGIT ? 0u : fam_rt;
   dev = __builtin_nan("");
   double dev_prev = __builtin_inf();
   conv = false;
@@ -183,7 +259,7 @@ __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, ui
 // smallest minimum level count (code 2) and refit once from a cold start (:1976-2030).
 // SCEN: general data path -- per-replicate correlation factor / marginals from the scenario design records and
 // per-study effects (data_gen.rs:709-751, 990-1093); the fit still starts from the spec's effects.
-template <int P, bool FACTORS, bool RED, bool SCEN>
+template <int P, bool FACTORS, bool RED, bool SCEN, bool LOGIT>
 __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ float lds[];
   const SimParams& prm = *pp;
@@ -228,7 +304,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
     const double nd = (double)n;
     const double pbar = sum_y / nd;
     double dev_null = (pbar > 0.0 && pbar < 1.0) ? -2.0 * (sum_y * log(pbar) + (nd - sum_y) * log(1.0 - pbar)) : 0.0;
-    if (prm.glm_family == 2u) {  // Poisson: the intercept-only fit has mu = mean(y)
+    if (!LOGIT && prm.glm_family == 2u) {  // Poisson: the intercept-only fit has mu = mean(y)
       double dn = 0.0;
       for (uint32_t i = lane; i < n; i += WAVE) {
         const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
@@ -274,7 +350,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
         keep = prm.keep_mask[flag_bits & 15u];
 #pragma unroll
         for (int c = 0; c < P; ++c) beta[c] = (attempt == 0 && ((keep >> c) & 1u)) ? prm.beta[c] : 0.0;
-        irls_fit<P, true>(design, n_pad, n, lane, keep, prm.glm_family, beta, Lm, invd, dev, conv);
+        irls_fit<P, true, LOGIT>(design, n_pad, n, lane, keep, prm.glm_family, beta, Lm, invd, dev, conv);
         if (conv || attempt == 1 || prm.min_level_count == 0u) break;
         int drop = -1;  // included_factor_with_smallest_min_count (batch.rs:2573-2600)
         uint32_t best = 0;
@@ -293,7 +369,7 @@ __global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restri
       // ---- IRLS from the truth start (batch.rs:1945-1951) ----
 #pragma unroll
       for (int c = 0; c < P; ++c) beta[c] = prm.beta[c];
-      irls_fit<P, false>(design, n_pad, n, lane, keep, prm.glm_family, beta, Lm, invd, dev, conv);
+      irls_fit<P, false, LOGIT>(design, n_pad, n, lane, keep, prm.glm_family, beta, Lm, invd, dev, conv);
     }
 
     // ---- Wald z^2 per target (cov = (X'WX)^-1), decisions, LRT overall ----
@@ -447,18 +523,18 @@ size_t glm_lds_bytes(int P, uint32_t max_n) {  // staging sized for the general 
   return ((size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE) * sizeof(float);
 }
 
-template <bool FACTORS, bool RED, bool SCEN>
+template <bool FACTORS, bool RED, bool SCEN, bool LOGIT>
 static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, hipStream_t st) {
   const size_t lds = glm_lds_bytes(P, max_n);
   const dim3 block(WAVE), grid(n_sims);
 #define LG(PP)                                                                                                        \
   case PP: {                                                                                                          \
     if (lds > 48 * 1024) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS, RED, SCEN>,                               \
+      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS, RED, SCEN, LOGIT>,                               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
       if (e != hipSuccess) return e;                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS, RED, SCEN>), grid, block, lds, st, d_prm);                        \
+    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS, RED, SCEN, LOGIT>), grid, block, lds, st, d_prm);                 \
   } break;
   switch (P) {
     LG(2) LG(3) LG(4) LG(5) LG(6) LG(7) LG(8)
@@ -469,11 +545,15 @@ static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, u
 }
 
 hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
-                          bool scen, hipStream_t st) {
-  if (scen) return launch_glm_f<true, true, true>(P, d_prm, n_sims, max_n, st);
-  if (reduced) return launch_glm_f<true, true, false>(P, d_prm, n_sims, max_n, st);
-  return factors ? launch_glm_f<true, false, false>(P, d_prm, n_sims, max_n, st)
-                 : launch_glm_f<false, false, false>(P, d_prm, n_sims, max_n, st);
+                          bool scen, bool logit, hipStream_t st) {
+  if (!logit) {  // probit / Poisson: one run-time-family variant (the superset kernel)
+    return scen ? launch_glm_f<true, true, true, false>(P, d_prm, n_sims, max_n, st)
+                : launch_glm_f<true, true, false, false>(P, d_prm, n_sims, max_n, st);
+  }
+  if (scen) return launch_glm_f<true, true, true, true>(P, d_prm, n_sims, max_n, st);
+  if (reduced) return launch_glm_f<true, true, false, true>(P, d_prm, n_sims, max_n, st);
+  return factors ? launch_glm_f<true, false, false, true>(P, d_prm, n_sims, max_n, st)
+                 : launch_glm_f<false, false, false, true>(P, d_prm, n_sims, max_n, st);
 }
 
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {

@@ -32,7 +32,7 @@ hipError_t launch_ols_fit_provided(int P, const float* design, const float* outc
                                    hipStream_t st);
 hipError_t launch_icdf_probe(uint32_t first_word, uint32_t stride, uint32_t n, float* out, hipStream_t st);
 hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
-                          bool scen, hipStream_t st);
+                          bool scen, bool logit, hipStream_t st);
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
 size_t glm_lds_bytes(int P, uint32_t max_n);
 hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool factors,
@@ -194,7 +194,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   const bool glm = spec->estimator == MCP_EST_GLM || mle;  // wave-per-replicate kernels + flag fold
   const bool reduced = prm.red_active && !glm;             // reduced-design OLS kernel, flags folded afterwards
   // RED variants of the wave-per-replicate kernels; their general-path (scenario) variants build on them
-  const bool glm_reduced = (prm.red_active || prm.scen_active) && glm;
+  // (probit / Poisson run on the superset kernel as well: only the logit kernels are family-specialised)
+  const bool glm_reduced = (prm.red_active || prm.scen_active || (!mle && prm.glm_family != 0u)) && glm;
   if (reduced && (flags & MCP_PIPELINE_STAGED))
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds or more than 8 design columns / tests");
   const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
@@ -392,7 +393,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
       if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));
-      else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, scen, st));
+      else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, scen, prm.glm_family == 0u, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
