@@ -58,34 +58,6 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
 // the IRLS row 4x the cost of its algebra; IRLS needs ~1e-15, not the last bit (the stopping rule is 1e-8 on the
 // deviance).  Maximum relative error against libm: exp 2.3e-16 on [0, 700], log1p 5.6e-16 (checked in numpy
 // with the same operations; tests/test_gpu_parity.py compares the fits with the oracle's glibc path). ----
-__device__ __forceinline__ double fast_rcp(double d) {  // v_rcp_f64 + one Newton step
-  double y = __builtin_amdgcn_rcp(d);
-  y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
-  return y;
-}
-
-__device__ __forceinline__ double exp_neg(double a) {  // e^{-a}, a >= 0
-  const double kf = __builtin_rint(a * 1.4426950408889634);
-  double r = __builtin_fma(kf, -6.93147180369123816490e-01, a);  // Cody-Waite: a - k ln2 (hi, lo)
-  r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
-  const double x = -r;  // |x| <= ln2 / 2
-  double p = 1.6059043836821613e-10;  // 1/13!
-  p = __builtin_fma(p, x, 2.08767569878681e-09);
-  p = __builtin_fma(p, x, 2.505210838544172e-08);
-  p = __builtin_fma(p, x, 2.755731922398589e-07);
-  p = __builtin_fma(p, x, 2.7557319223985893e-06);
-  p = __builtin_fma(p, x, 2.48015873015873e-05);
-  p = __builtin_fma(p, x, 0.0001984126984126984);
-  p = __builtin_fma(p, x, 0.001388888888888889);
-  p = __builtin_fma(p, x, 0.008333333333333333);
-  p = __builtin_fma(p, x, 0.041666666666666664);
-  p = __builtin_fma(p, x, 0.16666666666666666);
-  p = __builtin_fma(p, x, 0.5);
-  p = __builtin_fma(p, x, 1.0);
-  p = __builtin_fma(p, x, 1.0);
-  return ldexp(p, -(int)kf);
-}
-
 // log(1 + x) for x in [0, 1] given u = 1 + x and ru = 1 / u: log(u) by the atanh series on m = u or u / 2 in
 // (1/sqrt2, sqrt2], plus the rounding of 1 + x carried as (x - (u - 1)) / u
 __device__ __forceinline__ double log1p_unit(double x, double u, double ru) {
