@@ -239,7 +239,13 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       return unsupported("Count outcomes under a non-log link");
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
-  if (spec->cluster.present && spec->estimator != MCP_EST_MLE) return unsupported("clustered data generation outside the Mle estimator");
+  if (spec->cluster.present && spec->estimator == MCP_EST_GLM) return unsupported("clustered GLM (GLMM: Laplace / AGQ fits)");
+  if (spec->cluster.present && (spec->cluster.n_slopes || spec->cluster.n_extra_groupings))
+    return unsupported("random slopes / extra groupings (random intercept only)");
+  if (spec->cluster.present && spec->cluster.sizing_value == 0) { err = "invalid spec: cluster sizing value must be > 0"; return MCP_ERR_INVALID_SPEC; }
+  if (spec->cluster.present && spec->cluster.sizing == MCP_CLUSTER_FIXED_SIZE)
+    for (uint32_t g = 0; g < n_ns; ++g)
+      if (ns[g] % spec->cluster.sizing_value) return unsupported("FixedSize clusters with a sample size that is not a multiple of cluster_size");
   // general ("scenario") data-generating path: anything beyond N(0,1) predictors + N(0,1) residual + fixed design
   bool general = !scenario_is_optimistic(spec->scenario) || spec->residual_dist != MCP_RESID_NORMAL;
   for (uint32_t j = 0; j < K; ++j)
@@ -596,7 +602,10 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   // designs beyond the hot kernels' register budget (more than 8 columns or 8 tests) run on the reduced-design
   // kernel too: its solve and decisions are sized at run time
   const bool wide = P > (uint32_t)MAX_P_WAVE || nt > (uint32_t)MAX_T_WAVE;
-  prm.red_active = (npc > 0 || test_reduces || any_excl_possible || wide) ? 1u : 0u;
+  // clustered data fitted by OLS ignoring the clustering (orchestrator tests/clustered_ols_smoke.rs): the random
+  // intercept of a row's cluster is re-drawn per row on the reduced-design kernel
+  const bool ols_cluster = spec->cluster.present && spec->estimator == MCP_EST_OLS;
+  prm.red_active = (npc > 0 || test_reduces || any_excl_possible || wide || ols_cluster) ? 1u : 0u;
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))
     return unsupported("intercept-free reduced fit under Glm / Mle");
   for (uint32_t k = 0; k <= (uint32_t)MAX_T; ++k)

@@ -236,6 +236,11 @@ __global__ __launch_bounds__(BLOCK) void ols_reduced_kernel(const SimParams* __r
   ScenLane<P> sl;
   if (SCEN) scen_lane_load<P>(prm, lsim, sl);
 
+  double tau_rep = prm.tau;
+  if (SCEN && prm.scen_tau_sq) {
+    const double t2 = prm.scen_tau_sq[lsim];
+    tau_rep = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
+  }
   Suff<P> s;
   suff_reset(s);
   unsigned long long level_counts[MAX_FACTORS] = {0ull, 0ull, 0ull, 0ull};  // 4-bit saturating count per level
@@ -251,7 +256,12 @@ __global__ __launch_bounds__(BLOCK) void ols_reduced_kernel(const SimParams* __r
         const uint32_t rr = base + (uint32_t)r;
         if (rr >= row && rr < n_end) {
           float x[P], y;
-          build_row<P, true, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, 0.0, &sl);
+          double u_re = 0.0;
+          if (prm.has_cluster) {  // cluster random intercept: draw c of the sequential stream (data_gen.rs:146-161)
+            const uint32_t cid = prm.cluster_fixed_clusters ? rr % prm.cluster_v : rr / prm.cluster_v;
+            u_re = (double)(float)(draw_cluster_effect(prm, k0, k1, cid < prm.n_clusters_max ? cid : 0u) * tau_rep);
+          }
+          build_row<P, true, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
           suff_add_row<P>(s, x, y);
           if (min_c) {  // level of every factor read back from its dummy block (exact 0.0 / 1.0)
 #pragma unroll

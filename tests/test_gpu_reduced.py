@@ -394,3 +394,23 @@ def test_wide_ols_under_a_scenario_preset(engine, oracle):
     assert np.array_equal(g.factor_excluded, o.factor_excluded)
     for f in ("uncorrected", "corrected", "converged"):
         assert (getattr(g, f) != getattr(o, f)).mean() < 3e-4, f
+
+
+def test_ols_on_clustered_data_ignoring_the_clustering(engine, oracle):
+    """orchestrator tests/clustered_ols_smoke.rs: Continuous + cluster + Ols -- clustered generation, naive OLS fit."""
+    from helpers import base_spec
+    from test_gpu_parity import _design_mismatch
+    spec = base_spec(2)
+    spec.effect_sizes = [0.0, 0.5, 0.3]
+    spec.cluster = S.ClusterSpec(sizing=("FixedClusters", 20), tau_squared=0.3)
+    spec.report_overall = True
+    bx, by, worst, total = _design_mismatch(engine, oracle, spec, 200, 16)
+    assert bx == 0 and by == 0
+    g, o = _both(engine, oracle, spec, [100, 200], 3000, 71)
+    _assert_reduced_equal(g, o)
+    assert g.uncorrected[:, 1, 0].mean() > 0.2
+    spec.cluster = S.ClusterSpec(sizing=("FixedSize", 10), tau_squared=0.5)
+    spec.scenario = S.ScenarioPerturbations(name="hsk", heteroskedasticity_ratio=2.0)
+    g, o = _both(engine, oracle, spec, [50, 200], 2000, 72)
+    for f in ("uncorrected", "corrected", "converged", "overall"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 5e-4, f
