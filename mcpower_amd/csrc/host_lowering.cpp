@@ -272,7 +272,13 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     err = "invalid spec: scenario.lme requires estimator == Mle";
     return MCP_ERR_INVALID_SPEC;
   }
-  if (spec->n_between_var_indices) return unsupported("cluster-level (between) predictors");
+  if (spec->n_between_var_indices && spec->cluster.present && spec->estimator != MCP_EST_MLE)
+    return unsupported("cluster-level (between) predictors outside the Mle estimator");
+  for (uint32_t b = 0; b < spec->n_between_var_indices; ++b)
+    if (spec->between_var_indices[b] == 0 || spec->between_var_indices[b] >= 1 + K + spec->n_factor_dummies) {
+      err = "invalid spec: between_var_indices entry must name a continuous or dummy column";
+      return MCP_ERR_INVALID_SPEC;
+    }
   const uint32_t npc = total_posthoc_contrasts(spec);
   if (npc > (uint32_t)MAX_PC) return unsupported("more than " + std::to_string(MAX_PC) + " post-hoc contrasts");
   for (uint32_t i = 0; i < (spec->n_posthoc ? spec->posthoc_target_offsets[spec->n_posthoc] : 0u); ++i)
@@ -347,6 +353,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     prm.n_clusters_max = prm.cluster_fixed_clusters ? prm.cluster_v : max_n / prm.cluster_v;
     prm.tau = std::sqrt(spec->cluster.tau_squared > 0.0 ? spec->cluster.tau_squared : 0.0);
     prm.tau_squared = spec->cluster.tau_squared;
+    for (uint32_t b = 0; b < spec->n_between_var_indices; ++b) prm.between_mask |= 1u << spec->between_var_indices[b];
     // draws one cluster effect consumes on the sequential stream (draw_residual, data_gen.rs:1289-1320)
     prm.lme_re_dist = spec->scenario.has_lme ? (uint32_t)spec->scenario.lme_random_effect_dist : 0u;
     prm.lme_re_df = spec->scenario.has_lme ? spec->scenario.lme_random_effect_df : 0.0;

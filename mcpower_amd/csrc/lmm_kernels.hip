@@ -102,6 +102,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_prepare_kernel(const SimParams* __r
   row_ctx_init<P, FACTORS>(prm, cx);
   ScenLane<P> sl;
   if (SCEN) scen_lane_load<P>(prm, lsim, sl);
+  const uint32_t bmask = prm.between_mask;
   for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += LWAVE) {
     stage_group<P, LWAVE, 0, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
 #pragma unroll
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(LWAVE) void lmm_prepare_kernel(const SimParams* __r
         const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
         const double u_re = (double)cluster_u[cid < ncl_max ? cid : 0u];
         float x[P], y;
-        build_row<P, FACTORS, LWAVE, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
+        const float e = build_x<P, FACTORS, LWAVE, SCEN>(prm, cx, k0, k1, st, r, rr, x, &sl);
+        if (bmask == 0u) finish_row<P, 0, SCEN>(prm, cx, x, e, y, u_re, &sl);
+        else y = e;  // the residual waits in the outcome slot until the cluster-level columns are broadcast
 #pragma unroll
         for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
         design[(size_t)(P - 1) * n_pad + rr] = y;
@@ -119,6 +122,45 @@ __global__ __launch_bounds__(LWAVE) void lmm_prepare_kernel(const SimParams* __r
     }
   }
   __syncthreads();
+  if (bmask != 0u) {
+    // cluster-level predictors (data_gen.rs:606-636): every row takes the marked columns from its cluster's
+    // representative row (row i % n_clusters, or the first row of the block), then interactions and the outcome
+    // are formed from the broadcast values.  Representative rows keep their own values, so the copies below
+    // read final data whatever order the lanes run in.
+    for (uint32_t rr = lane; rr < max_n; rr += LWAVE) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cv : rr - (rr % cv);
+      float x[P];
+      x[0] = 1.0f;
+#pragma unroll
+      for (int c = 1; c < P; ++c) {
+        const uint32_t src = ((bmask >> c) & 1u) ? rep : rr;
+        x[c] = design[(size_t)(c - 1) * n_pad + src];
+      }
+      rebuild_interactions<P>(cx, x);
+      const float e = design[(size_t)(P - 1) * n_pad + rr];
+      const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
+      float y;
+      finish_row<P, 0, SCEN>(prm, cx, x, e, y, (double)cluster_u[cid < ncl_max ? cid : 0u], &sl);
+      __builtin_amdgcn_wave_barrier();  // all reads of this sweep's source columns happen before any overwrite
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if (((bmask >> c) & 1u) == 0u && ((cx.inter_any >> c) & 1u)) design[(size_t)(c - 1) * n_pad + rr] = x[c];
+      design[(size_t)(P - 1) * n_pad + rr] = y;
+    }
+    // marked columns are rewritten last: until here every row still saw the representatives' originals
+    __syncthreads();
+    for (uint32_t rr = lane; rr < max_n; rr += LWAVE) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cv : rr - (rr % cv);
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if ((bmask >> c) & 1u) {
+          const float v = design[(size_t)(c - 1) * n_pad + rep];
+          __builtin_amdgcn_wave_barrier();
+          design[(size_t)(c - 1) * n_pad + rr] = v;
+        }
+    }
+    __syncthreads();
+  }
 
   double* rec = prm.lmm_rec;
   constexpr uint32_t MF = lmm_m_fields<P>();

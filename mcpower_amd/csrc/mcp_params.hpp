@@ -66,6 +66,8 @@ struct SimParams {
   uint32_t cluster_v;
   uint32_t n_clusters_max;           // clusters present at max_n
   double tau;                        // sqrt(max(tau_squared, 0))
+  uint32_t between_mask;             // columns broadcast from the cluster's representative row (data_gen.rs:606-636)
+  uint32_t _pad_between;
 
   // outcome
   uint32_t outcome_kind;             // mcp_outcome_kind

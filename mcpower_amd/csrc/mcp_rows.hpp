@@ -234,11 +234,10 @@ __device__ __forceinline__ void row_ctx_init(const SimParams& prm, RowCtx<P>& cx
   }
 }
 
-// one design row + outcome from the staged normals (data_gen.rs:334-363, 509-551, 643-649, 781-857)
-template <int P, bool FACTORS, int STRIDE, int OUTCOME, bool SCEN = false>
-__device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
-                                          const float* st, int r, uint32_t row, float (&x)[P], float& y,
-                                          double u_re = 0.0, const ScenLane<P>* sl = nullptr) {
+// the design row: continuous block, factor dummies, bootstrap copies, interactions; returns the residual draw
+template <int P, bool FACTORS, int STRIDE, bool SCEN>
+__device__ __forceinline__ float build_x(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
+                                         const float* st, int r, uint32_t row, float (&x)[P], const ScenLane<P>* sl) {
   const uint32_t K = cx.K;
   float z[P - 1];
 #pragma unroll
@@ -319,6 +318,27 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
     }
     x[c] = v;
   }
+  return e;
+}
+
+// interaction columns recomputed from (possibly overwritten) component columns (data_gen.rs:643-649)
+template <int P>
+__device__ __forceinline__ void rebuild_interactions(const RowCtx<P>& cx, float (&x)[P]) {
+#pragma unroll
+  for (int c = 1; c < P; ++c) {
+    if ((cx.inter_any >> c) & 1u) {
+      double prod = 1.0;
+#pragma unroll
+      for (int cc = 1; cc < c; ++cc) prod = prod * (((cx.imask[c] >> cc) & 1u) ? (double)x[cc] : 1.0);
+      x[c] = (float)prod;
+    }
+  }
+}
+
+// the outcome of a finished design row (data_gen.rs:781-922)
+template <int P, int OUTCOME, bool SCEN>
+__device__ __forceinline__ void finish_row(const SimParams& prm, const RowCtx<P>& cx, const float (&x)[P], float e,
+                                           float& y, double u_re, const ScenLane<P>* sl) {
   // y = f32( sum_j f64(x_ij) beta_j + f64(eps_i) + u_re )  (data_gen.rs:785-857); zero betas add exact zeros
   double lp = 0.0;
 #pragma unroll
@@ -376,6 +396,15 @@ __device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>&
       y = (float)out;
     }
   }
+}
+
+// one design row + outcome from the staged normals (data_gen.rs:334-363, 509-551, 643-649, 781-857)
+template <int P, bool FACTORS, int STRIDE, int OUTCOME, bool SCEN = false>
+__device__ __forceinline__ void build_row(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
+                                          const float* st, int r, uint32_t row, float (&x)[P], float& y,
+                                          double u_re = 0.0, const ScenLane<P>* sl = nullptr) {
+  const float e = build_x<P, FACTORS, STRIDE, SCEN>(prm, cx, k0, k1, st, r, row, x, sl);
+  finish_row<P, OUTCOME, SCEN>(prm, cx, x, e, y, u_re, sl);
 }
 
 }  // namespace mcp

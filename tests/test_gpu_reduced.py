@@ -414,3 +414,32 @@ def test_ols_on_clustered_data_ignoring_the_clustering(engine, oracle):
     g, o = _both(engine, oracle, spec, [50, 200], 2000, 72)
     for f in ("uncorrected", "corrected", "converged", "overall"):
         assert (getattr(g, f) != getattr(o, f)).mean() < 5e-4, f
+
+
+def test_lmm_cluster_level_predictors_are_broadcast(engine, oracle):
+    """data_gen.rs:606-636: marked columns take the value of the cluster's representative row; a cross-level
+    interaction and the outcome use the broadcast values."""
+    spec = S.SimulationSpec(n_non_factor=2, n_factor_dummies=1, correlation=[1.0, 0.2, 0.2, 1.0],
+                            var_types=[S.Distribution.Normal] * 2, var_params=[0.0, 0.0], factor_n_levels=[2],
+                            factor_proportions=[0.5, 0.5], factor_sampled=[True], interactions=[[1, 2]],
+                            effect_sizes=[0.0, 0.3, 0.4, 0.5, 0.2], target_indices=[1, 2, 3, 4],
+                            between_var_indices=[2, 3], estimator=S.EstimatorSpec.Mle,
+                            cluster=S.ClusterSpec(sizing=("FixedClusters", 12), tau_squared=0.3),
+                            scenario=S.ScenarioPerturbations(name="optimistic", truth_start=True))
+    for sizing in (("FixedClusters", 12), ("FixedSize", 8)):
+        spec.cluster = S.ClusterSpec(sizing=sizing, tau_squared=0.3)
+        g = engine.run_batch(spec, [96, 240], 1500, 81, stat_capture=True)
+        o = oracle.run_batch(spec, [96, 240], 1500, 81, stat_capture=True, n_threads=8)
+        m = ~np.isnan(o.stat_capture)
+        assert np.array_equal(np.isnan(g.stat_capture), ~m)
+        # a replicate whose cluster-level dummy is constant over all clusters (p = 2 * 0.5^12) is a singular design
+        # on both sides: compare all but such degenerate replicates
+        bad = np.abs(g.stat_capture - o.stat_capture) > 1e-4 * np.abs(o.stat_capture) + 1e-6
+        assert (bad & m).any(axis=1).sum() <= 2
+        for f in ("uncorrected", "joint_unc", "converged", "boundary_hit"):
+            assert (getattr(g, f) != getattr(o, f)).mean() < 5e-3, (sizing, f)
+    x, _, ids = oracle.generate_sim_data(spec, 81, 0, 96)
+    for c in np.unique(ids):      # the oracle's rows of one cluster share the marked columns
+        rows = x[ids == c]
+        assert (rows[:, 2] == rows[0, 2]).all() and (rows[:, 3] == rows[0, 3]).all()
+        assert np.allclose(rows[:, 4], rows[:, 1] * rows[:, 2])
