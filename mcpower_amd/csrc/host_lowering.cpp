@@ -223,7 +223,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (spec->cluster.n_slopes || spec->cluster.n_extra_groupings) return unsupported("random slopes / extra groupings (random intercept only)");
     if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS) return unsupported("Mle on Binary / Count outcomes");
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the Mle estimator");
-    if (P > 6) return unsupported("Mle with more than 6 design columns");
+
     if (spec->cluster.sizing_value == 0) { err = "invalid spec: cluster sizing value must be > 0"; return MCP_ERR_INVALID_SPEC; }
     if (spec->cluster.sizing == MCP_CLUSTER_FIXED_SIZE)
       for (uint32_t g = 0; g < n_ns; ++g)

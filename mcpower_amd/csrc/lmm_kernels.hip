@@ -637,7 +637,7 @@ static hipError_t launch_lmm_prepare(int P, const SimParams* d_prm, uint32_t n_s
     hipLaunchKernelGGL((lmm_prepare_kernel<PP, FACTORS, RED, SCEN>), grid, block, lds, st, d_prm);                    \
   } break;
   switch (P) {
-    LL(2) LL(3) LL(4) LL(5) LL(6)
+    LL(2) LL(3) LL(4) LL(5) LL(6) LL(7) LL(8)
     default: return hipErrorInvalidValue;
   }
 #undef LL
@@ -653,6 +653,8 @@ static hipError_t launch_lmm_optimise(int P, const SimParams* d_prm, uint32_t n_
     case 4: hipLaunchKernelGGL((lmm_optimise_kernel<4, RED>), grid, block, 0, st, d_prm); break;
     case 5: hipLaunchKernelGGL((lmm_optimise_kernel<5, RED>), grid, block, 0, st, d_prm); break;
     case 6: hipLaunchKernelGGL((lmm_optimise_kernel<6, RED>), grid, block, 0, st, d_prm); break;
+    case 7: hipLaunchKernelGGL((lmm_optimise_kernel<7, RED>), grid, block, 0, st, d_prm); break;
+    case 8: hipLaunchKernelGGL((lmm_optimise_kernel<8, RED>), grid, block, 0, st, d_prm); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -443,3 +443,22 @@ def test_lmm_cluster_level_predictors_are_broadcast(engine, oracle):
         rows = x[ids == c]
         assert (rows[:, 2] == rows[0, 2]).all() and (rows[:, 3] == rows[0, 3]).all()
         assert np.allclose(rows[:, 4], rows[:, 1] * rows[:, 2])
+
+
+def test_lmm_with_eight_design_columns(engine, oracle):
+    spec = S.SimulationSpec(n_non_factor=3, n_factor_dummies=2, correlation=[1.0, 0.3, 0.0, 0.3, 1.0, 0.1, 0.0, 0.1, 1.0],
+                            var_types=[S.Distribution.Normal] * 3, var_params=[0.0] * 3, factor_n_levels=[3],
+                            factor_proportions=[0.4, 0.3, 0.3], interactions=[[1, 4], [1, 5]],
+                            effect_sizes=[0.0, 0.3, 0.2, 0.1, 0.4, -0.3, 0.2, 0.15], target_indices=[1, 2, 3, 4, 5, 6, 7],
+                            correction_method=S.CorrectionMethod.Holm, estimator=S.EstimatorSpec.Mle,
+                            cluster=S.ClusterSpec(sizing=("FixedClusters", 15), tau_squared=0.25),
+                            factor_min_level_count=5,
+                            scenario=S.ScenarioPerturbations(name="optimistic", truth_start=True))
+    assert spec.n_predictors == 8
+    g = engine.run_batch(spec, [150, 450], 1500, 91, stat_capture=True)
+    o = oracle.run_batch(spec, [150, 450], 1500, 91, stat_capture=True, n_threads=8)
+    m = ~np.isnan(o.stat_capture)
+    assert np.array_equal(np.isnan(g.stat_capture), ~m)
+    assert np.all(np.abs(g.stat_capture[m] - o.stat_capture[m]) <= 1e-5 * o.stat_capture[m] + 1e-8)
+    for f in ("uncorrected", "corrected", "joint_unc", "converged", "boundary_hit"):
+        assert (getattr(g, f) != getattr(o, f)).mean() < 2e-3, f
