@@ -119,27 +119,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lowered = spec.to_c()  # marshalled once, like the reference holding its SimulationSpec across run_batch calls
+
     def step(i):
-        # weak scaling: every rank simulates S new replicates per step; ids never repeat across steps
+        # weak scaling: every rank simulates S new replicates per step; ids never repeat across steps.
+        # The all-reduce of step i is left in flight and collected after step i+1's kernel has run.
         off = (i * world + rank) * S
-        r = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, sim_offset=off, staged=staged)
-        pooled = mdist.allreduce_counters(r.counters)
-        return r, pooled
+        r = engine.run_batch(lowered, ns, S, helpers.BASE_SEED, per_sim=False, sim_offset=off, staged=staged)
+        return r, mdist.allreduce_counters_async(r.counters)
 
     for i in range(args.warmup):
-        step(i)
+        step(i)[1].wait()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = aux_ms = 0.0
     launches = 0
     pooled = None
+    in_flight = None
+    n_pooled_total = 0.0
     for i in range(args.steps):
-        r, pooled = step(args.warmup + i)
+        r, pend = step(args.warmup + i)
+        if in_flight is not None:
+            pooled = in_flight.wait()
+            n_pooled_total += float(pooled[0, r.layout["n_sims"]])
+        in_flight = pend
         kernel_ms += r.kernel_ms
         aux_ms += r.aux_kernel_ms
         launches += r.n_kernel_launches
+    pooled = in_flight.wait()  # every step's counters are pooled inside the timed region
+    n_pooled_total += float(pooled[0, r.layout["n_sims"]])
     barrier()
     elapsed = time.perf_counter() - t0
+    if n_pooled_total != float(S) * world * args.steps:
+        raise SystemExit(f"pooled replicate count {n_pooled_total} != {float(S) * world * args.steps}")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -67,9 +67,25 @@ struct Arena {
     size_t cap = 0;
   };
   Buf slots[28];
+  Buf pinned[2];  // host staging: [0] the upload blob, [1] the counters coming back
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
   int device = -1;
+
+  hipError_t get_pinned(int slot, size_t bytes, void** out) {
+    Buf& b = pinned[slot];
+    if (bytes > b.cap) {
+      if (b.p) (void)hipHostFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+      const size_t want = bytes + (bytes >> 2) + 4096;
+      hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      b.cap = want;
+    }
+    *out = b.p;
+    return hipSuccess;
+  }
 
   hipError_t get(int slot, size_t bytes, void** out) {
     Buf& b = slots[slot];
@@ -264,9 +280,21 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   uint8_t *d_unc = nullptr, *d_cor = nullptr, *d_conv = nullptr, *d_ov = nullptr;
   double* d_stat = nullptr;
   float* d_tile = nullptr;
-  DEV_TRY(ar.get(S_PRM, sizeof(mcp::SimParams) * n_chunks, (void**)&d_prm));
-  DEV_TRY(ar.get(S_CRIT, low.crit.size() * sizeof(double), (void**)&d_crit));
-  DEV_TRY(ar.get(S_LEVELS, low.fixed_levels.size(), (void**)&d_levels));
+  // every small per-call table travels in ONE blob: [SimParams x n_chunks | crit | crit_red | red_row | levels],
+  // staged in pinned host memory so the single upload is a true async copy on the launch stream
+  auto align256 = [](size_t v) { return (v + 255u) & ~(size_t)255u; };
+  const bool any_red = (prm.red_active && !glm) || glm_reduced;
+  const size_t off_crit = align256(sizeof(mcp::SimParams) * n_chunks);
+  const size_t off_crit_red = align256(off_crit + low.crit.size() * sizeof(double));
+  const size_t off_red_row = align256(off_crit_red + (any_red ? (low.crit_red.size() + 1) * sizeof(double) : 0));
+  const size_t off_levels = align256(off_red_row + (any_red ? low.red_row.size() * sizeof(uint16_t) : 0));
+  const size_t blob_bytes = align256(off_levels + low.fixed_levels.size());
+  uint8_t *d_blob = nullptr, *h_blob = nullptr;
+  DEV_TRY(ar.get(S_PRM, blob_bytes, (void**)&d_blob));
+  DEV_TRY(ar.get_pinned(0, blob_bytes, (void**)&h_blob));
+  d_prm = (mcp::SimParams*)d_blob;
+  d_crit = (double*)(d_blob + off_crit);
+  d_levels = d_blob + off_levels;
   const uint32_t n_ctr = n_ns * layout.stride;
   const uint32_t copy_stride = (n_ctr + 15u) & ~15u;  // whole 128-byte lines per copy
   const size_t ctr_words = (size_t)copy_stride * (mcp::CTR_COPIES + 1);  // copies, then the reduced vector
@@ -280,8 +308,8 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
       DEV_TRY(ar.get(S_PH_COR, cells * npc + 1, (void**)&d_ph_cor));
     }
     DEV_TRY(ar.get(S_FX, cells * (spec->n_factors ? spec->n_factors : 1) + 1, (void**)&d_fx));
-    DEV_TRY(ar.get(S_CRIT_RED, (low.crit_red.size() + 1) * sizeof(double), (void**)&d_crit_red));
-    DEV_TRY(ar.get(S_RED_ROW, low.red_row.size() * sizeof(uint16_t), (void**)&d_red_row));
+    d_crit_red = (double*)(d_blob + off_crit_red);
+    d_red_row = (uint16_t*)(d_blob + off_red_row);
   }
   if (per_sim || glm || reduced) {  // these kernels always write flags; a fold kernel counts them
     DEV_TRY(ar.get(S_UNC, cells * nt + 1, (void**)&d_unc));
@@ -337,12 +365,12 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(ar.event(0, &ev_begin));
   DEV_TRY(ar.event(1, &ev_end));
   DEV_TRY(hipEventRecord(ev_begin, st));
-  DEV_TRY(hipMemcpyAsync(d_crit, low.crit.data(), low.crit.size() * sizeof(double), hipMemcpyHostToDevice, st));
-  DEV_TRY(hipMemcpyAsync(d_levels, low.fixed_levels.data(), low.fixed_levels.size(), hipMemcpyHostToDevice, st));
   DEV_TRY(hipMemsetAsync(d_ctr, 0, ctr_words * sizeof(uint64_t), st));
+  std::memcpy(h_blob + off_crit, low.crit.data(), low.crit.size() * sizeof(double));
+  std::memcpy(h_blob + off_levels, low.fixed_levels.data(), low.fixed_levels.size());
   if (reduced || glm_reduced) {
-    DEV_TRY(hipMemcpyAsync(d_crit_red, low.crit_red.data(), low.crit_red.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    DEV_TRY(hipMemcpyAsync(d_red_row, low.red_row.data(), low.red_row.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    std::memcpy(h_blob + off_crit_red, low.crit_red.data(), low.crit_red.size() * sizeof(double));
+    std::memcpy(h_blob + off_red_row, low.red_row.data(), low.red_row.size() * sizeof(uint16_t));
   }
 
   prm.base_seed = base_seed;
@@ -371,14 +399,15 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   prm.scen_tau_sq = d_scen_tau;
   prm.scen_stride = chunk;
   prm.t3_table = d_t3;
-  std::vector<mcp::SimParams> h_prm(n_chunks, prm);
+  mcp::SimParams* h_prm = (mcp::SimParams*)h_blob;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     const uint32_t b = c * chunk;
+    std::memcpy(&h_prm[c], &prm, sizeof prm);
     h_prm[c].sim_begin = sim_offset + b;
     h_prm[c].n_sims = (n_sims - b) < chunk ? (n_sims - b) : chunk;
     h_prm[c].out_base = b;
   }
-  DEV_TRY(hipMemcpyAsync(d_prm, h_prm.data(), sizeof(mcp::SimParams) * n_chunks, hipMemcpyHostToDevice, st));
+  DEV_TRY(hipMemcpyAsync(d_blob, h_blob, blob_bytes, hipMemcpyHostToDevice, st));
 
   // launches, each bracketed by events on the launch stream
   const size_t ev_per_chunk = (staged || glm || reduced) ? 3 : 2;
@@ -430,7 +459,9 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   // results
   unsigned long long* d_ctr_final = d_ctr + (size_t)copy_stride * mcp::CTR_COPIES;
   DEV_TRY(mcp::launch_reduce_counters(d_ctr, copy_stride, n_ctr, d_ctr_final, st));
-  DEV_TRY(hipMemcpyAsync(out->counters, d_ctr_final, (size_t)n_ctr * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  uint64_t* h_ctr = nullptr;
+  DEV_TRY(ar.get_pinned(1, (size_t)n_ctr * sizeof(uint64_t), (void**)&h_ctr));
+  DEV_TRY(hipMemcpyAsync(h_ctr, d_ctr_final, (size_t)n_ctr * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   if (per_sim) {
     out->uncorrected = host_alloc<uint8_t>(cells * nt);
     out->corrected = host_alloc<uint8_t>(cells * nt);
@@ -472,6 +503,7 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   }
   DEV_TRY(hipEventRecord(ev_end, st));
   DEV_TRY(hipStreamSynchronize(st));
+  std::memcpy(out->counters, h_ctr, (size_t)n_ctr * sizeof(uint64_t));
 
   float ms = 0.f;
   DEV_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));

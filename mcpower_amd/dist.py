@@ -40,6 +40,34 @@ def allreduce_counters(counters: np.ndarray, group=None) -> np.ndarray:
     return t.cpu().numpy().astype(np.uint64)
 
 
+class PendingCounters:
+    """An all-reduce in flight: `wait()` returns the pooled (n_ss, stride) uint64 block."""
+
+    def __init__(self, tensor, work, local):
+        self._t, self._work, self._local = tensor, work, local
+
+    def wait(self) -> np.ndarray:
+        if self._t is None:
+            return self._local
+        self._work.wait()
+        return self._t.cpu().numpy().astype(np.uint64)
+
+
+def allreduce_counters_async(counters: np.ndarray, group=None) -> PendingCounters:
+    """`allreduce_counters` without the wait: the collective runs on the process group's own stream while the
+    caller launches its next batch, so its latency hides behind the next simulate kernel."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return PendingCounters(None, None, counters.copy())
+    t = torch.from_numpy(counters.astype(np.int64, copy=True))
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return PendingCounters(t, work, None)
+
+
 def wilson_ci(k: int, n: int):
     """Wilson 95% score interval, z = 1.96 (reference aggregation.rs:18-36) -- recomputed from pooled counts."""
     if n == 0:

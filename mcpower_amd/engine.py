@@ -73,7 +73,7 @@ def set_device(index: int) -> None:
     _check(lib().mcp_set_device(int(index)))
 
 
-def run_batch(spec: S.SimulationSpec, sample_sizes: Sequence[int], n_sims: int, base_seed: int,
+def run_batch(spec: "S.SimulationSpec | S.LoweredSpec", sample_sizes: Sequence[int], n_sims: int, base_seed: int,
               sink: Optional[Callable[[int, int], bool]] = None, *, per_sim: bool = True, stat_capture: bool = False,
               staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0) -> S.BatchResult:
     """`run_batch(spec, sample_sizes, n_sims, base_seed, sink)` (batch.rs:130).
@@ -83,7 +83,7 @@ def run_batch(spec: S.SimulationSpec, sample_sizes: Sequence[int], n_sims: int, 
     `sim_offset` makes this call the shard [sim_offset, sim_offset + n_sims) of a larger run,
     `staged=True` selects the generator -> HBM design tile -> fit pipeline instead of the fused kernel.
     """
-    low = spec.to_c()
+    low = spec if isinstance(spec, S.LoweredSpec) else spec.to_c()  # a marshalled spec may be reused across calls
     ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
     opts = S.CRunOptions()
     opts.flags = (S.WANT_PER_SIM if per_sim else 0) | (S.WANT_STAT_CAPTURE if stat_capture else 0) | (

@@ -36,6 +36,11 @@ def _worker(rank, world, port, n_sims, out_dir):
     local = oracle.run_batch(spec_c2b(), [100, 200], cnt, BASE_SEED, sim_offset=off)
     pooled = mdist.allreduce_counters(local.counters)
     np.save(os.path.join(out_dir, f"pooled_{rank}.npy"), pooled)
+    # the pipelined form bench.py uses: the collective of step i is collected after step i+1 was issued
+    first = mdist.allreduce_counters_async(local.counters)
+    second = mdist.allreduce_counters_async(local.counters * np.uint64(2))
+    a, b = first.wait(), second.wait()
+    assert np.array_equal(a, pooled) and np.array_equal(b, pooled * np.uint64(2))
     dist.destroy_process_group()
 
 
