@@ -262,7 +262,30 @@ def make_contracts():
             f.write(blob)
 
 
+def make_crossings():
+    """End-to-end power goldens: validation/data/cross_*.golden.rds hold the required N per effect that the
+    reference's own dense `find_sample_size` run froze (validation_crossing.rmd:118-122: from 20 to 300 by 2,
+    100 000 sims, seed 2137), with the model of each case from validation/formulas.R:661-677 (CROSS_CASES)."""
+    cases = {
+        "cross_ols": dict(family="ols", effects={"x1": 0.40, "x2": 0.25}),
+        "cross_glm": dict(family="logit", effects={"x1": 0.50, "x2": 0.45}, baseline_probability=0.3),
+        "cross_lme": dict(family="lme", effects={"x1": 0.45}, cluster=dict(ICC=0.2, n_clusters=10)),
+        "cross_partial": dict(family="ols", effects={"x1": 0.40, "x2": 0.05}),
+    }
+    out = {}
+    for name, model in cases.items():
+        g = to_py(read_rds(f"{REF}/validation/data/{name}.golden.rds"))
+        out[name] = dict(model=model, n_sims=int(g["n_sims"][0]), by=int(g["by"][0]), from_size=int(g["from_size"][0]),
+                         to_size=int(g["to_size"][0]), seed=int(g["seed"][0]),
+                         dense={k: dict(status=v["status"][0],
+                                        n_achievable=None if v["n_achievable"] is None else int(v["n_achievable"][0]))
+                                for k, v in g["dense"].items()})
+    with open(f"{HERE}/crossing.json", "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     make_rng_kat()
     make_cases()
     make_contracts()
+    make_crossings()
