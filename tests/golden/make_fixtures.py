@@ -284,8 +284,20 @@ def make_crossings():
         json.dump(out, f, indent=1)
 
 
+def make_scenario_goldens():
+    """validation/data/scenario_golden.rds: the headline statistics the reference froze for its scenario
+    probes (validation_scenarios.rmd:549-575 -- per case, the `est` of every gate plus `golden_only` extras),
+    each a deterministic function of generated data at committed seeds.  Values only; the probes themselves
+    are restated in tests/test_scenario_goldens.py."""
+    g = to_py(read_rds(f"{REF}/validation/data/scenario_golden.rds"))
+    out = {case: {k: float(v) for k, v in vals.items()} for case, vals in g.items()}
+    with open(f"{HERE}/scenario_golden.json", "w") as f:
+        json.dump(out, f, indent=1, ensure_ascii=False)
+
+
 if __name__ == "__main__":
     make_rng_kat()
     make_cases()
     make_contracts()
     make_crossings()
+    make_scenario_goldens()
