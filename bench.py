@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--pipeline", default="fused", choices=["fused", "staged"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo only to rehearse the N>1 logic with several ranks on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -99,11 +101,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if engine.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    engine.set_device(local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % engine.device_count()
+    torch.cuda.set_device(dev_index)
+    engine.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
 
     fac, n_obs, ops_per_fit, bytes_per_fit = WORKLOADS[args.workload]
     spec = getattr(helpers, fac)()
@@ -121,39 +127,50 @@ def main():
 
     lowered = spec.to_c()  # marshalled once, like the reference holding its SimulationSpec across run_batch calls
 
-    def step(i):
-        # weak scaling: every rank simulates S new replicates per step; ids never repeat across steps.
-        # The all-reduce of step i is left in flight and collected after step i+1's kernel has run.
+    def submit(i):
+        # weak scaling: every rank simulates S new replicates per step; ids never repeat across steps
         off = (i * world + rank) * S
-        r = engine.run_batch(lowered, ns, S, helpers.BASE_SEED, per_sim=False, sim_offset=off, staged=staged)
-        return r, mdist.allreduce_counters_async(r.counters)
+        return engine.submit_batch(lowered, ns, S, helpers.BASE_SEED, sim_offset=off, staged=staged)
 
-    for i in range(args.warmup):
-        step(i)[1].wait()
+    def run_steps(first, count):
+        """`count` steps, software-pipelined two deep: batch i+1 is enqueued (its host-side lowering and upload
+        hide behind batch i's kernel) before batch i is collected, and the all-reduce of batch i's counters is
+        collected one step later still.  Every batch and every collective completes before this returns."""
+        acc = dict(kernel_ms=0.0, aux_ms=0.0, launches=0, pooled_sims=0.0, pooled=None, last=None)
+        if count <= 0:
+            return acc
+
+        def absorb(pend):
+            acc["pooled"] = pend.wait()
+            acc["pooled_sims"] += float(acc["pooled"][0, acc["last"].layout["n_sims"]])
+
+        ticket = submit(first)
+        reduce_in_flight = None
+        for i in range(count):
+            nxt = submit(first + i + 1) if i + 1 < count else None
+            r = ticket.collect()
+            acc["last"] = r
+            acc["kernel_ms"] += r.kernel_ms
+            acc["aux_ms"] += r.aux_kernel_ms
+            acc["launches"] += r.n_kernel_launches
+            if reduce_in_flight is not None:
+                absorb(reduce_in_flight)
+            reduce_in_flight = mdist.allreduce_counters_async(r.counters)
+            ticket = nxt
+        absorb(reduce_in_flight)
+        return acc
+
+    run_steps(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = aux_ms = 0.0
-    launches = 0
-    pooled = None
-    in_flight = None
-    n_pooled_total = 0.0
-    for i in range(args.steps):
-        r, pend = step(args.warmup + i)
-        if in_flight is not None:
-            pooled = in_flight.wait()
-            n_pooled_total += float(pooled[0, r.layout["n_sims"]])
-        in_flight = pend
-        kernel_ms += r.kernel_ms
-        aux_ms += r.aux_kernel_ms
-        launches += r.n_kernel_launches
-    pooled = in_flight.wait()  # every step's counters are pooled inside the timed region
-    n_pooled_total += float(pooled[0, r.layout["n_sims"]])
+    acc = run_steps(args.warmup, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if n_pooled_total != float(S) * world * args.steps:
-        raise SystemExit(f"pooled replicate count {n_pooled_total} != {float(S) * world * args.steps}")
+    kernel_ms, aux_ms, launches, pooled, r = acc["kernel_ms"], acc["aux_ms"], acc["launches"], acc["pooled"], acc["last"]
+    if acc["pooled_sims"] != float(S) * world * args.steps:
+        raise SystemExit(f"pooled replicate count {acc['pooled_sims']} != {float(S) * world * args.steps}")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -284,6 +284,18 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* sample_sizes, uint32_t n
 
 void mcp_free_result(mcp_batch_result* r);
 
+/* Asynchronous form of mcp_run_batch for back-to-back batches (no reference counterpart: the reference's
+ * run_batch blocks, batch.rs:130; its callers overlap work by calling it from several host threads).
+ * `submit` validates, lowers and enqueues the whole batch on the launch stream and returns at once with a
+ * ticket; `collect` waits for that batch and fills `*out` (counters, layout, shape, timings -- the reduced
+ * form: MCP_WANT_PER_SIM / MCP_WANT_STAT_CAPTURE are rejected, there is no progress callback).  Up to four
+ * batches may be in flight per host thread; they execute in submission order on one stream, so the host-side
+ * work of batch i+1 hides behind the kernels of batch i.  A ticket is collected exactly once, on the thread
+ * that submitted it; the result is released with mcp_free_result. */
+int mcp_run_batch_submit(const mcp_spec* spec, const uint32_t* sample_sizes, uint32_t n_sample_sizes,
+                         uint32_t n_sims, uint64_t base_seed, const mcp_run_options* opts, uint64_t* ticket_out);
+int mcp_run_batch_collect(uint64_t ticket, mcp_batch_result* out);
+
 /* Host-only part of run_batch (no device): validation (batch.rs:208-330) and
  * the critical-value table (critvals.rs:827-1012).  `crit_out` receives, per
  * sample size, [t_crit_sq_uncorrected, correction_t_crit_sq[0..n_targets),

@@ -113,10 +113,25 @@ struct Arena {
   }
 };
 thread_local Arena g_arena;
+// batches in flight (mcp_run_batch_submit / _collect): each ticket owns an arena, all share g_arena's stream so
+// the kernels of successive batches run back to back, in order, and their event timings stay per kernel
+constexpr int MAX_IN_FLIGHT = 4;
+struct Ticket {
+  bool busy = false;
+  Arena arena;
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_upload = nullptr;
+  uint64_t* h_ctr = nullptr;
+  uint32_t n_ctr = 0, launched = 0;
+  size_t ev_per_chunk = 0;
+  bool glm = false, reduced = false, staged = false;
+  mcp_batch_result shell;
+};
+thread_local Ticket g_tickets[MAX_IN_FLIGHT];
+thread_local hipStream_t g_upload_stream = nullptr;  // a batch in flight uploads its tables beside the running kernel
 
 enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS };
 
-int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
+int ensure_device(hipStream_t* st, const mcp_run_options* opts, Arena* extra = nullptr) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(MCP_ERR_DEVICE, "no HIP device visible: the MI355X path cannot run (there is no CPU fallback)");
@@ -125,6 +140,10 @@ int ensure_device(hipStream_t* st, const mcp_run_options* opts) {
   if (g_arena.device != g_device) {
     g_arena = Arena();
     g_arena.device = g_device;
+  }
+  if (extra && extra->device != g_device) {
+    *extra = Arena();
+    extra->device = g_device;
   }
   if (opts && opts->hip_stream) {
     *st = (hipStream_t)opts->hip_stream;
@@ -191,8 +210,42 @@ void mcp_free_result(mcp_batch_result* r) {
   std::memset(r, 0, sizeof *r);
 }
 
-int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t n_sims, uint64_t base_seed,
-                  const mcp_run_options* opts, mcp_progress_fn progress, void* progress_user, mcp_batch_result* out) {
+}  // extern "C"
+
+namespace {
+
+// fills the timing fields of a finished batch from the events recorded around its launches
+int finish_timing(Arena& ar, hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t launched, size_t ev_per_chunk, bool glm,
+                  bool reduced, bool staged, mcp_batch_result* out) {
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+  out->device_ms = ms;
+  double kernel_ms = 0.0, aux_ms = 0.0;
+  for (uint32_t c = 0; c < launched; ++c) {
+    hipEvent_t e0 = ar.events[2 + c * ev_per_chunk], e1 = ar.events[3 + c * ev_per_chunk];
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (glm || reduced) {
+      kernel_ms += ms;  // simulate kernel
+      HIP_TRY(hipEventElapsedTime(&ms, e1, ar.events[4 + c * ev_per_chunk]));
+      aux_ms += ms;  // counter fold
+    } else if (!staged) {
+      kernel_ms += ms;
+    } else {
+      aux_ms += ms;  // generator
+      HIP_TRY(hipEventElapsedTime(&ms, e1, ar.events[4 + c * ev_per_chunk]));
+      kernel_ms += ms;  // fit
+    }
+  }
+  out->kernel_ms = kernel_ms;
+  out->aux_kernel_ms = aux_ms;
+  out->n_kernel_launches = launched;
+  return MCP_OK;
+}
+
+// `defer` != nullptr: counters-only batch left in flight on the ticket's arena (no host wait here)
+int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t n_sims, uint64_t base_seed,
+                   const mcp_run_options* opts, mcp_progress_fn progress, void* progress_user, mcp_batch_result* out,
+                   Ticket* defer) {
   if (!out) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null result pointer");
   std::memset(out, 0, sizeof *out);
   std::string err;
@@ -238,9 +291,9 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   }
 
   hipStream_t st = nullptr;
-  rc = ensure_device(&st, opts);
+  rc = ensure_device(&st, opts, defer ? &defer->arena : nullptr);
   if (rc) { mcp_free_result(out); return rc; }
-  Arena& ar = g_arena;
+  Arena& ar = defer ? defer->arena : g_arena;
 
   // chunking: the callback cadence of the reference is ~50 reports per run (batch.rs:450)
   uint32_t chunk = opts && opts->chunk_sims ? opts->chunk_sims : 0;
@@ -365,7 +418,13 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
   DEV_TRY(ar.event(0, &ev_begin));
   DEV_TRY(ar.event(1, &ev_end));
   DEV_TRY(hipEventRecord(ev_begin, st));
-  DEV_TRY(hipMemsetAsync(d_ctr, 0, ctr_words * sizeof(uint64_t), st));
+  hipStream_t up = st;  // where the counter reset and the table upload go
+  if (defer) {
+    if (!g_upload_stream) DEV_TRY(hipStreamCreateWithFlags(&g_upload_stream, hipStreamNonBlocking));
+    if (!defer->ev_upload) DEV_TRY(hipEventCreateWithFlags(&defer->ev_upload, hipEventDisableTiming));
+    up = g_upload_stream;
+  }
+  DEV_TRY(hipMemsetAsync(d_ctr, 0, ctr_words * sizeof(uint64_t), up));
   std::memcpy(h_blob + off_crit, low.crit.data(), low.crit.size() * sizeof(double));
   std::memcpy(h_blob + off_levels, low.fixed_levels.data(), low.fixed_levels.size());
   if (reduced || glm_reduced) {
@@ -407,7 +466,11 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     h_prm[c].n_sims = (n_sims - b) < chunk ? (n_sims - b) : chunk;
     h_prm[c].out_base = b;
   }
-  DEV_TRY(hipMemcpyAsync(d_blob, h_blob, blob_bytes, hipMemcpyHostToDevice, st));
+  DEV_TRY(hipMemcpyAsync(d_blob, h_blob, blob_bytes, hipMemcpyHostToDevice, up));
+  if (defer) {  // the ticket's arena is its own, so this ran beside the previous batch; the launches below wait for it
+    DEV_TRY(hipEventRecord(defer->ev_upload, up));
+    DEV_TRY(hipStreamWaitEvent(st, defer->ev_upload, 0));
+  }
 
   // launches, each bracketed by events on the launch stream
   const size_t ev_per_chunk = (staged || glm || reduced) ? 3 : 2;
@@ -502,35 +565,71 @@ int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint3
     DEV_TRY(hipMemcpyAsync(out->stat_capture, d_stat, (size_t)n_sims * nt * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   DEV_TRY(hipEventRecord(ev_end, st));
+  if (defer) {  // the caller collects later: remember what the finish needs
+    defer->ev_begin = ev_begin; defer->ev_end = ev_end;
+    defer->h_ctr = h_ctr; defer->n_ctr = n_ctr;
+    defer->launched = launched; defer->ev_per_chunk = ev_per_chunk;
+    defer->glm = glm; defer->reduced = reduced; defer->staged = staged;
+    return MCP_OK;
+  }
   DEV_TRY(hipStreamSynchronize(st));
   std::memcpy(out->counters, h_ctr, (size_t)n_ctr * sizeof(uint64_t));
-
-  float ms = 0.f;
-  DEV_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
-  out->device_ms = ms;
-  double kernel_ms = 0.0, aux_ms = 0.0;
-  for (uint32_t c = 0; c < launched; ++c) {
-    hipEvent_t e0 = ar.events[2 + c * ev_per_chunk], e1 = ar.events[3 + c * ev_per_chunk];
-    DEV_TRY(hipEventElapsedTime(&ms, e0, e1));
-    if (glm || reduced) {
-      kernel_ms += ms;  // simulate kernel
-      DEV_TRY(hipEventElapsedTime(&ms, e1, ar.events[4 + c * ev_per_chunk]));
-      aux_ms += ms;  // counter fold
-    } else if (!staged) {
-      kernel_ms += ms;
-    } else {
-      aux_ms += ms;  // generator
-      DEV_TRY(hipEventElapsedTime(&ms, e1, ar.events[4 + c * ev_per_chunk]));
-      kernel_ms += ms;  // fit
-    }
-  }
   if (mle && per_sim)  // pinned_components bit 0 = the intercept variance pinned at 0 (spec.rs:566-573)
     for (size_t i = 0; i < cells; ++i) out->pinned_components[i] = out->boundary_hit[i] == 1 ? 1ull : 0ull;
-  out->kernel_ms = kernel_ms;
-  out->aux_kernel_ms = aux_ms;
-  out->n_kernel_launches = launched;
 #undef DEV_TRY
+  rc = finish_timing(ar, ev_begin, ev_end, launched, ev_per_chunk, glm, reduced, staged, out);
+  if (rc) mcp_free_result(out);
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcp_run_batch(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t n_sims, uint64_t base_seed,
+                  const mcp_run_options* opts, mcp_progress_fn progress, void* progress_user, mcp_batch_result* out) {
+  return run_batch_impl(spec, ns, n_ns, n_sims, base_seed, opts, progress, progress_user, out, nullptr);
+}
+
+int mcp_run_batch_submit(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t n_sims, uint64_t base_seed,
+                         const mcp_run_options* opts, uint64_t* ticket_out) {
+  if (!ticket_out) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null ticket pointer");
+  if (opts && (opts->flags & (MCP_WANT_PER_SIM | MCP_WANT_STAT_CAPTURE)))
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: mcp_run_batch_submit returns counters only (no per-sim tensors, no statistic capture)");
+  if (n_sims == 0) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: mcp_run_batch_submit needs n_sims > 0");
+  int slot = -1;
+  for (int i = 0; i < MAX_IN_FLIGHT; ++i)
+    if (!g_tickets[i].busy) { slot = i; break; }
+  if (slot < 0) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: too many batches in flight on this thread (collect one first)");
+  Ticket& t = g_tickets[slot];
+  mcp_run_options o;
+  std::memset(&o, 0, sizeof o);
+  if (opts) o = *opts;
+  o.flags &= ~(uint32_t)MCP_WANT_PER_SIM;
+  int rc = run_batch_impl(spec, ns, n_ns, n_sims, base_seed, &o, nullptr, nullptr, &t.shell, &t);
+  if (rc) return rc;
+  t.busy = true;
+  *ticket_out = (uint64_t)slot + 1u;
   return MCP_OK;
+}
+
+int mcp_run_batch_collect(uint64_t ticket, mcp_batch_result* out) {
+  if (!out) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null result pointer");
+  if (ticket == 0 || ticket > (uint64_t)MAX_IN_FLIGHT || !g_tickets[ticket - 1].busy)
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: unknown ticket (tickets are collected once, on the thread that submitted them)");
+  Ticket& t = g_tickets[ticket - 1];
+  t.busy = false;
+  *out = t.shell;
+  std::memset(&t.shell, 0, sizeof t.shell);
+  hipError_t e = hipEventSynchronize(t.ev_end);
+  if (e != hipSuccess) {
+    mcp_free_result(out);
+    return fail(MCP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e) + " at hipEventSynchronize");
+  }
+  std::memcpy(out->counters, t.h_ctr, (size_t)t.n_ctr * sizeof(uint64_t));
+  int rc = finish_timing(t.arena, t.ev_begin, t.ev_end, t.launched, t.ev_per_chunk, t.glm, t.reduced, t.staged, out);
+  if (rc) mcp_free_result(out);
+  return rc;
 }
 
 int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, uint64_t base_seed, uint64_t sim_offset,

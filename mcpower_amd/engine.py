@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "_build", "libmcpower_hip.so")
 EXPORTS = (
     "mcp_abi_version", "mcp_last_error", "mcp_set_device", "mcp_device_count", "mcp_run_batch", "mcp_free_result",
     "mcp_build_crit_table", "mcp_t_ppf", "mcp_norm_ppf", "mcp_chi2_ppf", "mcp_f_ppf", "mcp_generate_design",
-    "mcp_fit_design", "mcp_icdf_probe",
+    "mcp_fit_design", "mcp_icdf_probe", "mcp_run_batch_submit", "mcp_run_batch_collect",
 )
 _lib = None
 
@@ -50,6 +50,11 @@ def lib() -> C.CDLL:
         L.mcp_run_batch.argtypes = [C.POINTER(S.CSpec), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint64,
                                     C.POINTER(S.CRunOptions), S.PROGRESS_FN, C.c_void_p, C.POINTER(S.CBatchResult)]
         L.mcp_free_result.argtypes = [C.POINTER(S.CBatchResult)]
+        L.mcp_run_batch_submit.restype = C.c_int
+        L.mcp_run_batch_submit.argtypes = [C.POINTER(S.CSpec), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32,
+                                           C.c_uint64, C.POINTER(S.CRunOptions), C.POINTER(C.c_uint64)]
+        L.mcp_run_batch_collect.restype = C.c_int
+        L.mcp_run_batch_collect.argtypes = [C.c_uint64, C.POINTER(S.CBatchResult)]
         for name, n in (("mcp_t_ppf", 2), ("mcp_norm_ppf", 1), ("mcp_chi2_ppf", 2), ("mcp_f_ppf", 3)):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double] * n
@@ -100,6 +105,43 @@ def run_batch(spec: "S.SimulationSpec | S.LoweredSpec", sample_sizes: Sequence[i
         return S.result_from_c(res)
     finally:
         lib().mcp_free_result(C.byref(res))
+
+
+class PendingBatch:
+    """A counters-only batch in flight on the device (`mcp_run_batch_submit`); `collect()` waits for it."""
+
+    def __init__(self, ticket: int, keep):
+        self._ticket, self._keep = ticket, keep
+
+    def collect(self) -> S.BatchResult:
+        if self._ticket is None:
+            raise RuntimeError("batch already collected")
+        res = S.CBatchResult()
+        ticket, self._ticket = self._ticket, None
+        _check(lib().mcp_run_batch_collect(C.c_uint64(ticket), C.byref(res)))
+        self._keep = None
+        try:
+            return S.result_from_c(res)
+        finally:
+            lib().mcp_free_result(C.byref(res))
+
+
+def submit_batch(spec: "S.SimulationSpec | S.LoweredSpec", sample_sizes: Sequence[int], n_sims: int, base_seed: int, *,
+                 staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0) -> PendingBatch:
+    """Enqueue a counters-only `run_batch` and return without waiting: up to four batches may be in flight per
+    host thread, executing in order on one stream, so the host work of the next batch hides behind the kernels
+    of the previous one.  Collect on the same thread."""
+    low = spec if isinstance(spec, S.LoweredSpec) else spec.to_c()
+    ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
+    opts = S.CRunOptions()
+    opts.flags = S.PIPELINE_STAGED if staged else 0
+    opts.chunk_sims = int(chunk_sims)
+    opts.sim_offset = int(sim_offset)
+    opts.hip_stream = hip_stream or None
+    ticket = C.c_uint64(0)
+    _check(lib().mcp_run_batch_submit(low.byref(), ns.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(ns.size),
+                                      C.c_uint32(n_sims), C.c_uint64(base_seed), C.byref(opts), C.byref(ticket)))
+    return PendingBatch(ticket.value, (low, ns))
 
 
 def run_batch_st(spec, sample_sizes, n_sims, base_seed, sink=None, **kw) -> S.BatchResult:

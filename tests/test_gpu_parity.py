@@ -235,6 +235,31 @@ def test_counters_only_mode_matches_per_sim_fold(engine):
     assert full.counter("hist_unc", 3)[0].sum() == 4000
 
 
+def test_batches_in_flight_equal_blocking_calls(engine):
+    """mcp_run_batch_submit / _collect: four batches enqueued before the first is collected, across estimators
+    and with a marshalled spec reused, give the counters of the blocking call; tickets are single-use."""
+    from helpers import spec_c3, spec_c4
+    jobs = [(spec_c2b(), [100, 200], 30000, 0), (spec_c2a(), [200], 50000, 7), (spec_c3(), [500], 3000, 11),
+            (spec_c4(), [600], 1000, 5)]
+    want = [engine.run_batch(sp, ns, n, BASE_SEED, per_sim=False, sim_offset=off).counters for sp, ns, n, off in jobs]
+    pending = [engine.submit_batch(sp, ns, n, BASE_SEED, sim_offset=off) for sp, ns, n, off in jobs]
+    with pytest.raises(S.EngineError) as e:                      # a fifth batch has no slot until one is collected
+        engine.submit_batch(spec_c2b(), [200], 100, BASE_SEED)
+    assert "in flight" in str(e.value)
+    got = [p.collect() for p in reversed(pending)][::-1]          # collection order is free
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g.counters) and g.uncorrected is None and g.kernel_ms > 0
+    with pytest.raises(RuntimeError):
+        pending[0].collect()
+    low = spec_c2b().to_c()
+    a = engine.submit_batch(low, [200], 20000, BASE_SEED, sim_offset=0)
+    b = engine.submit_batch(low, [200], 20000, BASE_SEED, sim_offset=20000)
+    whole = engine.run_batch(low, [200], 40000, BASE_SEED, per_sim=False)
+    assert np.array_equal(a.collect().counters + b.collect().counters, whole.counters)
+    staged = engine.submit_batch(low, [200], 20000, BASE_SEED, staged=True).collect()
+    assert np.array_equal(staged.counters, engine.run_batch(low, [200], 20000, BASE_SEED, per_sim=False).counters)
+
+
 def test_progress_reports_and_cancel(engine):
     spec = spec_c2b()
     seen = []
