@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 1u
+#define MCP_ABI_VERSION 2u
 
 /* ---- status codes (EngineError, spec.rs:20-29) --------------------------- */
 typedef enum mcp_status {
@@ -119,16 +119,43 @@ typedef struct mcp_scenario {
   double lme_icc_noise_sd;
 } mcp_scenario;
 
-/* ---- ClusterSpec (random intercept; slopes / extra groupings are reported
- *      MCP_ERR_UNSUPPORTED on this path for now) --------------------------- */
+/* ---- ClusterSpec (engine-contract/src/generation.rs:121-428) ----------------
+ * Primary grouping (random intercept + optional random slopes) and up to two
+ * extra groupings, crossed with or nested within the primary. */
+#define MCP_MAX_RE_SLOPES 2u          /* random slopes per grouping: q = 1 + n_slopes <= 3 */
+#define MCP_MAX_EXTRA_GROUPINGS 2u
+
+typedef enum mcp_grouping_relation {  /* GroupingRelation, generation.rs:244-252 */
+  MCP_GROUPING_CROSSED = 0,           /* count = n_clusters */
+  MCP_GROUPING_NESTED_WITHIN = 1      /* count = n_per_parent */
+} mcp_grouping_relation;
+
+/* the SlopeTerm list of one grouping (generation.rs:196-241), already resolved to kernel design columns
+ * (spec.cluster_slope_design_cols / spec.extra_slope_cols, contract_adapter.rs) */
+typedef struct mcp_re_slopes {
+  uint32_t n_slopes;
+  uint32_t design_cols[MCP_MAX_RE_SLOPES];   /* kernel design column of each slope (intercept = column 0) */
+  uint32_t _pad;
+  double variance[MCP_MAX_RE_SLOPES];
+  double re_corr[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)]; /* re_correlation_matrix(): row-major q x q over [intercept, slopes...], q = 1 + n_slopes */
+} mcp_re_slopes;
+
+typedef struct mcp_grouping {         /* GroupingSpec */
+  int32_t relation;                   /* mcp_grouping_relation */
+  uint32_t count;
+  double tau_squared;
+  mcp_re_slopes slopes;
+} mcp_grouping;
+
 typedef struct mcp_cluster {
   uint8_t present;                      /* spec.cluster.is_some() */
   uint8_t _pad[3];
   int32_t sizing;                       /* mcp_cluster_sizing */
   uint32_t sizing_value;                /* n_clusters or cluster_size */
+  uint32_t n_extra_groupings;
   double tau_squared;
-  uint32_t n_slopes;                    /* must be 0 (unsupported otherwise) */
-  uint32_t n_extra_groupings;           /* must be 0 (unsupported otherwise) */
+  mcp_re_slopes slopes;                 /* primary random slopes */
+  mcp_grouping extra[MCP_MAX_EXTRA_GROUPINGS];
 } mcp_cluster;
 
 /* ---- SimulationSpec (spec.rs:251-417), field for field -------------------- */

@@ -220,7 +220,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (spec->n_factors > (uint32_t)MAX_FACTORS) return unsupported("more than " + std::to_string(MAX_FACTORS) + " factors");
   if (spec->n_factor_proportions > (uint32_t)MAX_LEVELS) return unsupported("more than " + std::to_string(MAX_LEVELS) + " factor levels in total");
   if (spec->estimator == MCP_EST_MLE) {
-    if (spec->cluster.n_slopes || spec->cluster.n_extra_groupings) return unsupported("random slopes / extra groupings (random intercept only)");
+    if (spec->cluster.slopes.n_slopes || spec->cluster.n_extra_groupings) return unsupported("random slopes / extra groupings (random intercept only)");
     if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS) return unsupported("Mle on Binary / Count outcomes");
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the Mle estimator");
 
@@ -240,7 +240,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
   if (spec->cluster.present && spec->estimator == MCP_EST_GLM) return unsupported("clustered GLM (GLMM: Laplace / AGQ fits)");
-  if (spec->cluster.present && (spec->cluster.n_slopes || spec->cluster.n_extra_groupings))
+  if (spec->cluster.present && (spec->cluster.slopes.n_slopes || spec->cluster.n_extra_groupings))
     return unsupported("random slopes / extra groupings (random intercept only)");
   if (spec->cluster.present && spec->cluster.sizing_value == 0) { err = "invalid spec: cluster sizing value must be > 0"; return MCP_ERR_INVALID_SPEC; }
   if (spec->cluster.present && spec->cluster.sizing == MCP_CLUSTER_FIXED_SIZE)

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Distribution(enum.IntEnum):  # engine_contract::Distribution
@@ -117,16 +117,66 @@ class CScenario(C.Structure):
     ]
 
 
+MAX_RE_SLOPES = 2
+MAX_EXTRA_GROUPINGS = 2
+
+
+class CReSlopes(C.Structure):
+    _fields_ = [
+        ("n_slopes", C.c_uint32),
+        ("design_cols", C.c_uint32 * MAX_RE_SLOPES),
+        ("_pad", C.c_uint32),
+        ("variance", C.c_double * MAX_RE_SLOPES),
+        ("re_corr", C.c_double * ((1 + MAX_RE_SLOPES) ** 2)),
+    ]
+
+
+class CGrouping(C.Structure):
+    _fields_ = [
+        ("relation", C.c_int32),
+        ("count", C.c_uint32),
+        ("tau_squared", C.c_double),
+        ("slopes", CReSlopes),
+    ]
+
+
 class CCluster(C.Structure):
     _fields_ = [
         ("present", C.c_uint8),
         ("_pad", C.c_uint8 * 3),
         ("sizing", C.c_int32),
         ("sizing_value", C.c_uint32),
-        ("tau_squared", C.c_double),
-        ("n_slopes", C.c_uint32),
         ("n_extra_groupings", C.c_uint32),
+        ("tau_squared", C.c_double),
+        ("slopes", CReSlopes),
+        ("extra", CGrouping * MAX_EXTRA_GROUPINGS),
     ]
+
+
+def re_correlation_matrix(slopes) -> List[float]:
+    """`re_correlation_from_slopes` (generation.rs:226-241): row-major q x q over [intercept, slope_0, ...]."""
+    q = 1 + len(slopes)
+    r = [0.0] * (q * q)
+    for d in range(q):
+        r[d * q + d] = 1.0
+    for k, s in enumerate(slopes):
+        r[k + 1] = r[(k + 1) * q] = float(s.get("corr_with_intercept", 0.0))
+        for i, cik in enumerate(s.get("corr_with", []) or []):
+            r[(i + 1) * q + (k + 1)] = r[(k + 1) * q + (i + 1)] = float(cik)
+    return r
+
+
+def _fill_re_slopes(dst: CReSlopes, slopes, design_cols, what: str):
+    if len(slopes) > MAX_RE_SLOPES:
+        raise EngineError(Status.Unsupported, f"unsupported on the device path: more than {MAX_RE_SLOPES} random slopes on {what}")
+    if len(design_cols) != len(slopes):
+        raise EngineError(Status.InvalidSpec, f"invalid spec: {what} has {len(slopes)} random slopes but {len(design_cols)} resolved design columns")
+    dst.n_slopes = len(slopes)
+    for k, (s, col) in enumerate(zip(slopes, design_cols)):
+        dst.design_cols[k] = int(col)
+        dst.variance[k] = float(s["variance"])
+    for i, v in enumerate(re_correlation_matrix(slopes)):
+        dst.re_corr[i] = v
 
 
 class CSpec(C.Structure):
@@ -411,8 +461,18 @@ class LoweredSpec:
             c.cluster.sizing = 0 if kind == "FixedClusters" else 1
             c.cluster.sizing_value = int(v)
             c.cluster.tau_squared = float(s.cluster.tau_squared)
-            c.cluster.n_slopes = len(s.cluster.slopes)
+            _fill_re_slopes(c.cluster.slopes, s.cluster.slopes, s.cluster_slope_design_cols, "the primary grouping")
+            if len(s.cluster.extra_groupings) > MAX_EXTRA_GROUPINGS:
+                raise EngineError(Status.Unsupported, f"unsupported on the device path: more than {MAX_EXTRA_GROUPINGS} extra groupings")
             c.cluster.n_extra_groupings = len(s.cluster.extra_groupings)
+            for g, grp in enumerate(s.cluster.extra_groupings):
+                (rel, body), = grp["relation"].items() if isinstance(grp["relation"], dict) else ((grp["relation"], {}),)
+                dst = c.cluster.extra[g]
+                dst.relation = 0 if rel == "Crossed" else 1
+                dst.count = int(body["n_clusters"] if rel == "Crossed" else body["n_per_parent"])
+                dst.tau_squared = float(grp["tau_squared"])
+                cols = s.extra_slope_cols[g] if g < len(s.extra_slope_cols) else []
+                _fill_re_slopes(dst.slopes, grp.get("slopes", []) or [], cols, f"extra grouping {g}")
         sc = s.scenario
         c.scenario.heterogeneity = sc.heterogeneity
         c.scenario.heteroskedasticity_ratio = sc.heteroskedasticity_ratio

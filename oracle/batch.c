@@ -232,7 +232,7 @@ static void* worker(void* arg) {
   const mcp_spec* spec = jb->spec;
   uint32_t ncl = spec->cluster.present ? mcpo_n_clusters_at(&spec->cluster, jb->max_n) : 0;
   mcpo_ws* ws = mcpo_ws_new(jb->max_n, jb->p, spec->n_non_factor, ncl);
-  if (!ws) { jb->rc = MCP_ERR_DEVICE; return NULL; }
+  if (!ws || mcpo_ws_size_extras(ws, spec, jb->max_n)) { jb->rc = MCP_ERR_DEVICE; mcpo_ws_free(ws); return NULL; }
   mcp_batch_result* R = jb->out;
   const uint32_t nt = jb->nt, n_ns = jb->n_ns, cs = nt + 4;
   for (uint32_t s = jb->sim_begin; s < jb->sim_end; ++s) {

@@ -20,7 +20,7 @@
  * heteroskedastic scaling and the logit draw use libm here -- and the scenario
  * PSD repair (faer self_adjoint_eigen replaced by a cyclic Jacobi sweep).
  * Unsupported (returns MCP_ERR_UNSUPPORTED): uploaded-data marginals,
- * bootstrap frame maps, random slopes and extra groupings.
+ * bootstrap frame maps.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -348,7 +348,14 @@ void mcpo_compute_het_coeffs(const mcp_spec* spec, double* lp_mean, double* lp_s
 
 int mcpo_spec_supported(const mcp_spec* spec) {
   if (spec->n_non_factor > MCPO_MAX_K) return 0;
-  if (spec->cluster.present && (spec->cluster.n_slopes || spec->cluster.n_extra_groupings)) return 0;
+  if (spec->cluster.present) { /* capacity of the shared POD layout */
+    const mcp_cluster* c = &spec->cluster;
+    if (c->slopes.n_slopes > MCP_MAX_RE_SLOPES || c->n_extra_groupings > MCP_MAX_EXTRA_GROUPINGS) return 0;
+    for (uint32_t g = 0; g < c->n_extra_groupings; ++g) {
+      if (c->extra[g].slopes.n_slopes > MCP_MAX_RE_SLOPES) return 0;
+      if (c->extra[g].relation == MCP_GROUPING_CROSSED && c->sizing != MCP_CLUSTER_FIXED_CLUSTERS) return 0; /* validate(): crossed x FixedSize */
+    }
+  }
   /* uploaded frames: shapes must be consistent (contract_adapter.rs:356-469 builds them) */
   if (spec->upload_normal_rows && spec->upload_normal_cols != spec->n_non_factor) return 0;
   if (spec->n_bootstrap_frame_map) {
@@ -368,6 +375,52 @@ uint32_t mcpo_n_clusters_at(const mcp_cluster* c, uint32_t n) {
   return c->sizing == MCP_CLUSTER_FIXED_CLUSTERS ? v : n / v;
 }
 
+/* extra_n_levels_at (generation.rs:302-317) */
+uint32_t mcpo_extra_n_levels_at(const mcp_cluster* c, uint32_t g, uint32_t n) {
+  const mcp_grouping* e = &c->extra[g];
+  uint32_t cnt = e->count ? e->count : 1;
+  if (e->relation == MCP_GROUPING_CROSSED) return cnt;
+  uint32_t v = c->sizing_value ? c->sizing_value : 1;
+  uint32_t parents = c->sizing == MCP_CLUSTER_FIXED_CLUSTERS ? v : (n + v - 1) / v;
+  return parents * cnt;
+}
+/* extra_level_of_row (generation.rs:402-427): one lexicographic stride chain, primary fastest */
+uint32_t mcpo_extra_level_of_row(const mcp_cluster* c, uint32_t g, uint32_t i) {
+  const mcp_grouping* e = &c->extra[g];
+  uint32_t bl = e->count ? e->count : 1;
+  uint32_t v = c->sizing_value ? c->sizing_value : 1;
+  if (c->sizing == MCP_CLUSTER_FIXED_CLUSTERS) {
+    uint64_t stride = v;
+    for (uint32_t h = 0; h < g; ++h) stride *= c->extra[h].count ? c->extra[h].count : 1;
+    uint32_t within = (uint32_t)((i / stride) % bl);
+    return e->relation == MCP_GROUPING_CROSSED ? within : (i % v) * bl + within;
+  }
+  return (i / v) * bl + (i % v) % bl;
+}
+
+/* u_k = sum_{j<=k} L[k][j] z_j for k >= 1, with L = chol(diag(tau) R diag(tau)) (data_gen.rs:163-214, 242-283) */
+static void slope_cholesky(const mcp_re_slopes* sl, double tau0, double* l /* q*q row-major */) {
+  uint32_t q = 1 + sl->n_slopes;
+  double tv[1 + MCP_MAX_RE_SLOPES], d[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)];
+  tv[0] = tau0;
+  for (uint32_t k = 0; k < sl->n_slopes; ++k) tv[k + 1] = sqrt(fmax(sl->variance[k], 0.0));
+  for (uint32_t i = 0; i < q; ++i)
+    for (uint32_t j = 0; j < q; ++j) d[i * q + j] = tv[i] * sl->re_corr[i * q + j] * tv[j];
+  /* chol_lower (data_gen.rs:55-80): row-major lower factor, non-positive pivots give a zero column */
+  for (uint32_t i = 0; i < q * q; ++i) l[i] = 0.0;
+  for (uint32_t j = 0; j < q; ++j) {
+    double sum = d[j * q + j];
+    for (uint32_t t = 0; t < j; ++t) sum -= l[j * q + t] * l[j * q + t];
+    double diag = sum > 0.0 ? sqrt(sum) : 0.0;
+    l[j * q + j] = diag;
+    for (uint32_t i = j + 1; i < q; ++i) {
+      double v = d[i * q + j];
+      for (uint32_t t = 0; t < j; ++t) v -= l[i * q + t] * l[j * q + t];
+      l[i * q + j] = diag > 0.0 ? v / diag : 0.0;
+    }
+  }
+}
+
 /* generate_sim_data, data_gen.rs:87-925.  ws buffers sized for (max_n, p). */
 int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, uint32_t max_n, mcpo_ws* ws) {
   const uint32_t k = spec->n_non_factor, nfd = spec->n_factor_dummies, nf = spec->n_factors;
@@ -382,6 +435,9 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
   int resid_dist = spec->residual_dist;
   double resid_df = spec->scenario.residual_df;
   double tau_sq = spec->cluster.present ? spec->cluster.tau_squared : 0.0;
+  double extra_tau_sq[MCP_MAX_EXTRA_GROUPINGS] = {0.0, 0.0};
+  for (uint32_t g = 0; spec->cluster.present && g < spec->cluster.n_extra_groupings; ++g)
+    extra_tau_sq[g] = spec->cluster.extra[g].tau_squared;
   if (scenario_is_optimistic(&spec->scenario)) {
     memcpy(L, spec->correlation, sizeof(double) * k * k);
     if (k && mcpo_chol_colmajor(L, k)) return MCP_ERR_CORRELATION_NOT_PSD;
@@ -432,6 +488,11 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
     if (sc->has_lme && sc->lme_icc_noise_sd > 0.0) { /* data_gen.rs:1069-1076 */
       double jit = (double)mcpo_simrng_next_normal(&srng) * sc->lme_icc_noise_sd;
       tau_sq = fmax(tau_sq + jit, 0.0);
+      /* one independent jitter per extra grouping, declaration order (data_gen.rs:1077-1092) */
+      for (uint32_t g = 0; spec->cluster.present && g < spec->cluster.n_extra_groupings; ++g) {
+        double jg = (double)mcpo_simrng_next_normal(&srng) * sc->lme_icc_noise_sd;
+        extra_tau_sq[g] = fmax(spec->cluster.extra[g].tau_squared + jg, 0.0);
+      }
     }
   }
 
@@ -446,6 +507,46 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
     n_clusters = mcpo_n_clusters_at(&spec->cluster, max_n);
     if (n_clusters > ws->cap_clusters) return MCP_ERR_INVALID_SPEC;
     for (uint32_t c = 0; c < n_clusters; ++c) ws->cluster_u[c] = (float)(draw_residual(&rng, re_dist, re_df) * tau);
+    const mcp_cluster* cl = &spec->cluster;
+    /* 2a'. primary random slopes: z0 recovered from the f32 intercept draw (data_gen.rs:163-214) */
+    if (cl->slopes.n_slopes) {
+      uint32_t nsl = cl->slopes.n_slopes, q = 1 + nsl;
+      double l[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)], z[1 + MCP_MAX_RE_SLOPES];
+      slope_cholesky(&cl->slopes, tau, l);
+      for (uint32_t c = 0; c < n_clusters; ++c) {
+        z[0] = tau > 0.0 ? (double)ws->cluster_u[c] / tau : 0.0;
+        for (uint32_t j = 1; j < q; ++j) z[j] = draw_residual(&rng, re_dist, re_df);
+        for (uint32_t k = 1; k < q; ++k) {
+          double uk = 0.0;
+          for (uint32_t j = 0; j <= k; ++j) uk += l[k * q + j] * z[j];
+          ws->slope_u[c * nsl + (k - 1)] = (float)uk;
+        }
+      }
+    }
+    /* 2b. extra-grouping intercepts, then 2b'. their slopes -- all intercepts first (data_gen.rs:216-283) */
+    for (uint32_t g = 0; g < cl->n_extra_groupings; ++g) {
+      double tau_g = sqrt(fmax(extra_tau_sq[g], 0.0));
+      uint32_t qg = 1 + cl->extra[g].slopes.n_slopes, nl = mcpo_extra_n_levels_at(cl, g, max_n);
+      if ((size_t)nl * qg > ws->cap_extra[g]) return MCP_ERR_INVALID_SPEC;
+      for (uint32_t c = 0; c < nl; ++c) ws->extra_u[g][c * qg] = (float)(draw_residual(&rng, re_dist, re_df) * tau_g);
+    }
+    for (uint32_t g = 0; g < cl->n_extra_groupings; ++g) {
+      const mcp_re_slopes* sl = &cl->extra[g].slopes;
+      if (!sl->n_slopes) continue;
+      double tau0 = sqrt(fmax(extra_tau_sq[g], 0.0));
+      uint32_t qg = 1 + sl->n_slopes, nl = mcpo_extra_n_levels_at(cl, g, max_n);
+      double l[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)], z[1 + MCP_MAX_RE_SLOPES];
+      slope_cholesky(sl, tau0, l);
+      for (uint32_t c = 0; c < nl; ++c) {
+        z[0] = tau0 > 0.0 ? (double)ws->extra_u[g][c * qg] / tau0 : 0.0;
+        for (uint32_t j = 1; j < qg; ++j) z[j] = draw_residual(&rng, re_dist, re_df);
+        for (uint32_t d = 1; d < qg; ++d) {
+          double ud = 0.0;
+          for (uint32_t j = 0; j <= d; ++j) ud += l[d * qg + j] * z[j];
+          ws->extra_u[g][c * qg + d] = (float)ud;
+        }
+      }
+    }
   }
 
   for (uint32_t i = 0; i < max_n; ++i) x[i] = 1.0f; /* column 0 */
@@ -635,6 +736,17 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
       uint32_t cid = mcpo_cluster_of_row(&spec->cluster, i);
       if (ws->cluster_ids) ws->cluster_ids[i] = cid;
       u_re = (double)ws->cluster_u[cid];
+      const mcp_cluster* cl = &spec->cluster;
+      for (uint32_t g = 0; g < cl->n_extra_groupings; ++g) { /* data_gen.rs:819-836 */
+        const mcp_re_slopes* sl = &cl->extra[g].slopes;
+        uint32_t qg = 1 + sl->n_slopes, lvl = mcpo_extra_level_of_row(cl, g, i);
+        ws->extra_ids[g][i] = lvl;
+        u_re += (double)ws->extra_u[g][lvl * qg];
+        for (uint32_t d = 0; d < sl->n_slopes; ++d)
+          u_re += (double)ws->extra_u[g][lvl * qg + 1 + d] * (double)x[(size_t)sl->design_cols[d] * max_n + i];
+      }
+      for (uint32_t k = 0; k < cl->slopes.n_slopes; ++k) /* :837-842 */
+        u_re += (double)ws->slope_u[cid * cl->slopes.n_slopes + k] * (double)x[(size_t)cl->slopes.design_cols[k] * max_n + i];
     }
     if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS && !apply_hsk) y[i] = (float)(lp + (double)resid[i] + u_re);
     else ws->eta[i] = lp + u_re;
@@ -688,28 +800,53 @@ mcpo_ws* mcpo_ws_new(uint32_t max_n, uint32_t p, uint32_t k, uint32_t cap_cluste
   ws->cluster_u = (float*)malloc(sizeof(float) * (cap_clusters ? cap_clusters : 1));
   ws->cluster_ids = (uint32_t*)malloc(sizeof(uint32_t) * max_n);
   ws->cap_clusters = cap_clusters;
+  ws->slope_u = (float*)calloc((size_t)(cap_clusters ? cap_clusters : 1) * MCP_MAX_RE_SLOPES, sizeof(float));
   return ws;
+}
+
+/* buffers of the extra groupings (levels at max_n x q_g draws, one level id per row) */
+int mcpo_ws_size_extras(mcpo_ws* ws, const mcp_spec* spec, uint32_t max_n) {
+  for (uint32_t g = 0; spec->cluster.present && g < spec->cluster.n_extra_groupings && g < MCP_MAX_EXTRA_GROUPINGS; ++g) {
+    size_t need = (size_t)mcpo_extra_n_levels_at(&spec->cluster, g, max_n) * (1 + MCP_MAX_RE_SLOPES);
+    if (need > ws->cap_extra[g]) {
+      free(ws->extra_u[g]);
+      ws->extra_u[g] = (float*)calloc(need ? need : 1, sizeof(float));
+      ws->cap_extra[g] = need;
+    }
+    if (!ws->extra_ids[g]) ws->extra_ids[g] = (uint32_t*)calloc(max_n ? max_n : 1, sizeof(uint32_t));
+    if (!ws->extra_u[g] || !ws->extra_ids[g]) return MCP_ERR_DEVICE;
+  }
+  return MCP_OK;
 }
 
 void mcpo_ws_free(mcpo_ws* ws) {
   if (!ws) return;
   free(ws->x); free(ws->y); free(ws->z); free(ws->resid); free(ws->resid_g);
-  free(ws->acc); free(ws->eta); free(ws->cluster_u); free(ws->cluster_ids);
+  free(ws->acc); free(ws->eta); free(ws->cluster_u); free(ws->cluster_ids); free(ws->slope_u);
+  for (uint32_t g = 0; g < MCP_MAX_EXTRA_GROUPINGS; ++g) { free(ws->extra_u[g]); free(ws->extra_ids[g]); }
   free(ws);
 }
 
 int mcpo_generate_sim_data(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, uint32_t max_n, float* x_out,
                            float* y_out, uint32_t* cluster_ids_out) {
+  return mcpo_generate_sim_data_ids(spec, base_seed, sim_id, max_n, x_out, y_out, cluster_ids_out, NULL);
+}
+
+int mcpo_generate_sim_data_ids(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, uint32_t max_n, float* x_out,
+                               float* y_out, uint32_t* cluster_ids_out, uint32_t* extra_ids_out) {
   uint32_t k = spec->n_non_factor;
   uint32_t p = 1 + k + spec->n_factor_dummies + spec->n_interactions;
   uint32_t ncl = spec->cluster.present ? mcpo_n_clusters_at(&spec->cluster, max_n) : 0;
   mcpo_ws* ws = mcpo_ws_new(max_n, p, k, ncl);
   if (!ws) return MCP_ERR_DEVICE;
-  int rc = mcpo_generate_ws(spec, base_seed, sim_id, max_n, ws);
+  int rc = mcpo_ws_size_extras(ws, spec, max_n);
+  if (rc == MCP_OK) rc = mcpo_generate_ws(spec, base_seed, sim_id, max_n, ws);
   if (rc == MCP_OK) {
     memcpy(x_out, ws->x, sizeof(float) * (size_t)max_n * p);
     memcpy(y_out, ws->y, sizeof(float) * max_n);
     if (cluster_ids_out && spec->cluster.present) memcpy(cluster_ids_out, ws->cluster_ids, sizeof(uint32_t) * max_n);
+    for (uint32_t g = 0; extra_ids_out && spec->cluster.present && g < spec->cluster.n_extra_groupings; ++g)
+      memcpy(extra_ids_out + (size_t)g * max_n, ws->extra_ids[g], sizeof(uint32_t) * max_n);
   }
   mcpo_ws_free(ws);
   return rc;

@@ -302,7 +302,7 @@ int mcpo_lmm_fit(const float* x, const float* y, const uint32_t* cluster_ids, ui
 int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
                  uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row) {
-  if (!spec->cluster.present || spec->cluster.n_slopes || spec->cluster.n_extra_groupings) return MCP_ERR_UNSUPPORTED;
+  if (!spec->cluster.present || spec->cluster.slopes.n_slopes || spec->cluster.n_extra_groupings) return MCP_ERR_UNSUPPORTED;
   if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS || spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;
   const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
   const uint32_t nt = spec->n_target_indices, nf = spec->n_factors;

@@ -85,6 +85,9 @@ void mcpo_apply_correction(int method, const double* t_sq, uint32_t t, double cr
  * x_out: max_n x p column-major f32; y_out: max_n f32; cluster_ids_out may be NULL. */
 int mcpo_generate_sim_data(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, uint32_t max_n,
                            float* x_out, float* y_out, uint32_t* cluster_ids_out);
+/* same, plus the level ids of the extra groupings: extra_ids_out is n_extra_groupings x max_n (may be NULL) */
+int mcpo_generate_sim_data_ids(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, uint32_t max_n,
+                               float* x_out, float* y_out, uint32_t* cluster_ids_out, uint32_t* extra_ids_out);
 
 /* ---- OLS fit on provided bytes (glmm fit_suff_stats_t_sq, inferred from
  *      batch.rs:958-1142, posthoc.rs:62-99, introspect.rs:280-284) ----------- */

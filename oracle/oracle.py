@@ -164,6 +164,23 @@ def generate_sim_data(spec: S.SimulationSpec, base_seed: int, sim_id: int, max_n
     return x.T, y, (ids if spec.cluster is not None else None)
 
 
+def generate_sim_data_ids(spec: S.SimulationSpec, base_seed: int, sim_id: int, max_n: int):
+    """`generate_sim_data` plus the level ids of the extra groupings: (design, outcome, cluster_ids, [ids_g ...])."""
+    low = spec.to_c()
+    p = spec.n_predictors
+    x = np.zeros((p, max_n), dtype=np.float32)
+    y = np.zeros(max_n, dtype=np.float32)
+    ids = np.zeros(max_n, dtype=np.uint32)
+    ng = len(spec.cluster.extra_groupings) if spec.cluster is not None else 0
+    ex = np.zeros((max(ng, 1), max_n), dtype=np.uint32)
+    rc = lib().mcpo_generate_sim_data_ids(low.byref(), C.c_uint64(base_seed), C.c_uint64(sim_id), C.c_uint32(max_n),
+                                          x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                                          ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          ex.ctypes.data_as(C.POINTER(C.c_uint32)))
+    _check(rc)
+    return x.T, y, (ids if spec.cluster is not None else None), [ex[g] for g in range(ng)]
+
+
 def build_crit_table(spec: S.SimulationSpec, sample_sizes) -> np.ndarray:
     low = spec.to_c()
     ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)

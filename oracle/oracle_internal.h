@@ -19,7 +19,14 @@ typedef struct mcpo_ws {
   float* cluster_u;  /* cap_clusters */
   uint32_t* cluster_ids;
   uint32_t cap_clusters;
+  float* slope_u;                                 /* cap_clusters x MCP_MAX_RE_SLOPES: primary slope draws, [c * n_slopes + k] */
+  float* extra_u[MCP_MAX_EXTRA_GROUPINGS];        /* levels x q_g */
+  uint32_t* extra_ids[MCP_MAX_EXTRA_GROUPINGS];   /* max_n */
+  size_t cap_extra[MCP_MAX_EXTRA_GROUPINGS];
 } mcpo_ws;
+int mcpo_ws_size_extras(mcpo_ws* ws, const mcp_spec* spec, uint32_t max_n);
+uint32_t mcpo_extra_n_levels_at(const mcp_cluster* c, uint32_t g, uint32_t n);
+uint32_t mcpo_extra_level_of_row(const mcp_cluster* c, uint32_t g, uint32_t i);
 
 mcpo_ws* mcpo_ws_new(uint32_t max_n, uint32_t p, uint32_t k, uint32_t cap_clusters);
 void mcpo_ws_free(mcpo_ws* ws);

@@ -248,6 +248,67 @@ def make_cases():
         json.dump(index, fh, indent=1)
 
 
+MIXED_CASES = ("lmm_crossed_a", "lmm_crossed_b", "lmm_nested_a", "lmm_nested_b", "lmm_crossed_nested_a", "lmm_slope_a",
+               "lmm_slope_b", "lmm_multislope", "lmm_slope_crossed", "lmm_slope_crossed_extra_slopes",
+               "lmm_slope_nested_extra_slopes")
+
+
+def _one(v):
+    return v[0] if isinstance(v, (list, np.ndarray)) and len(v) == 1 else v
+
+
+def _slope_list(slopes):
+    return [dict(column=int(_one(s["column"])), variance=float(_one(s["variance"])),
+                 corr_with_intercept=float(_one(s["corr_with_intercept"])),
+                 corr_with=[float(v) for v in np.atleast_1d(s["corr_with"])]) for s in (slopes or [])]
+
+
+def make_mixed_cases():
+    """The general mixed-model datasets of validation/formulas.R:382-539 (M2 crossed / nested intercepts, M3 random
+    slopes and their compositions): sim-0 design / outcome / level ids captured by the reference, with lme4's
+    REML fit (beta, Wald z, variance components, RE correlations, sigma^2) as goldens.  Extra groupings are stored
+    in the contract's shape ({relation: {Crossed: {n_clusters}} | {NestedWithin: {n_per_parent}}, tau_squared,
+    slopes}); common.R:84-110 shows the M3 `extra` list being translated the same way."""
+    os.makedirs(f"{HERE}/mixed", exist_ok=True)
+    index = {}
+    for name in MIXED_CASES:
+        d = to_py(read_rds(f"{REF}/validation/data/{name}.rds"))
+        g = to_py(read_rds(f"{REF}/validation/data/{name}.golden.rds"))
+        sp = d["spec"]
+        low = lower_case(sp, d["columns"])
+        low["cluster"]["slopes"] = _slope_list(sp.get("slopes"))
+        extras = []
+        for e in (sp.get("extra_groupings") or []):                       # M2: already the contract shape
+            (rel, body), = e["relation"].items()
+            extras.append(dict(relation={rel: {k: int(_one(v)) for k, v in body.items()}},
+                               tau_squared=float(_one(e["tau_squared"])), slopes=_slope_list(e.get("slopes"))))
+        for e in (sp.get("extra") or []):                                 # M3: var / kind / n_clusters
+            cnt = int(_one(e["n_clusters"]))
+            rel = {"Crossed": {"n_clusters": cnt}} if _one(e["kind"]) == "crossed" else {"NestedWithin": {"n_per_parent": cnt}}
+            extras.append(dict(relation=rel, tau_squared=float(_one(e["tau_squared"])), slopes=_slope_list(e.get("slopes"))))
+        low["cluster"]["extra_groupings"] = extras
+        low["lmer_re"] = _one(sp["lmer_re"])
+        design = np.asarray(d["design"], dtype=np.float64)
+        outcome = np.asarray(d["outcome"], dtype=np.float64)
+        assert np.array_equal(design.astype(np.float32).astype(np.float64), design), name
+        assert np.array_equal(outcome.astype(np.float32).astype(np.float64), outcome), name
+        ex = d.get("extra_grouping_ids") or []
+        gv = g["vars"]
+        arrays = dict(design=design.astype(np.float32), outcome=outcome.astype(np.float32),
+                      cluster_ids=np.asarray(d["cluster_ids"], dtype=np.int64),
+                      extra_ids=np.asarray(ex, dtype=np.int64).reshape(len(ex), design.shape[0]),
+                      golden_beta=np.asarray(g["beta"], dtype=np.float64), golden_z=np.asarray(g["z"], dtype=np.float64),
+                      golden_vars=np.asarray(list(gv.values()) if isinstance(gv, dict) else gv, dtype=np.float64),
+                      golden_corr=np.asarray(g["corr"], dtype=np.float64),
+                      golden_sigma2=np.asarray(g["sigma2"], dtype=np.float64))
+        low["hash"] = _one(d["hash"])
+        np.savez_compressed(os.path.join(HERE, "mixed", f"{name}.npz"), spec_json=np.array(json.dumps(low)), **arrays)
+        index[name] = dict(n=low["n"], p=len(d["columns"]), lmer_re=low["lmer_re"])
+        print(name, design.shape, low["lmer_re"], arrays["golden_vars"], arrays["golden_corr"])
+    with open(os.path.join(HERE, "mixed", "cases.json"), "w") as fh:
+        json.dump(index, fh, indent=1)
+
+
 # quantile known answers restated from crates/engine-core/src/critvals.rs tests (:1807-1926) are checked
 # against scipy in tests/test_oracle_critvals.py; the per-case `crit` goldens above pin t_ppf/norm_ppf to R.
 
@@ -301,3 +362,4 @@ if __name__ == "__main__":
     make_contracts()
     make_crossings()
     make_scenario_goldens()
+    make_mixed_cases()

@@ -41,9 +41,13 @@ def case_names(family=None):
     return [k for k, v in idx.items() if family is None or v["family"] == family]
 
 
+def mixed_case_names():
+    return sorted(json.load(open(os.path.join(GOLDEN, "mixed", "cases.json"))))
+
+
 def load_case(name):
     """-> (SimulationSpec, base_seed, arrays dict, lowered-json dict)."""
-    z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    z = np.load(os.path.join(GOLDEN, "mixed" if name.startswith("lmm_") else "", f"{name}.npz"))
     low = json.loads(str(z["spec_json"]))
     k = low["n_non_factor"]
     p = 1 + k + low["n_factor_dummies"] + len(low["interactions"])
@@ -67,8 +71,12 @@ def load_case(name):
         intercept=low["effect_sizes"][0],
     )
     if "cluster" in low:
-        spec.cluster = S.ClusterSpec(sizing=("FixedClusters", low["cluster"]["n_clusters"]),
-                                     tau_squared=low["cluster"]["tau_squared"])
+        cl = low["cluster"]
+        spec.cluster = S.ClusterSpec(sizing=("FixedClusters", cl["n_clusters"]), tau_squared=cl["tau_squared"],
+                                     slopes=cl.get("slopes", []), extra_groupings=cl.get("extra_groupings", []))
+        # slope columns name generation columns; these cases are continuous-only, so design column = 1 + column
+        spec.cluster_slope_design_cols = [1 + s["column"] for s in spec.cluster.slopes]
+        spec.extra_slope_cols = [[1 + s["column"] for s in g.get("slopes", [])] for g in spec.cluster.extra_groupings]
     base_seed = splitmix64(low["user_seed"])
     arrays = {k2: z[k2] for k2 in z.files if k2 != "spec_json"}
     return spec, base_seed, arrays, low

@@ -34,7 +34,7 @@ def test_struct_sizes_are_stable():
     # guards the ctypes mirror against silent layout drift (sizes from the C compiler: tests/test_abi_sizes)
     assert C.sizeof(S.CRunOptions) == 24
     assert C.sizeof(S.CCounterLayout) == 64
-    assert C.sizeof(S.CCluster) == 32
+    assert C.sizeof(S.CCluster) == 368 and C.sizeof(S.CReSlopes) == 104 and C.sizeof(S.CGrouping) == 120
     assert C.sizeof(S.CSpec) % 8 == 0
 
 
@@ -97,7 +97,9 @@ def test_unsupported_fails_loudly_never_falls_back(engine):
     assert e.value.status == S.Status.Unsupported and "design columns" in str(e.value)
     s = spec_c2b()
     s.estimator = S.EstimatorSpec.Mle
-    s.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2, slopes=[{"column": 0}])
+    s.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2,
+                              slopes=[{"column": 0, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": []}])
+    s.cluster_slope_design_cols = [1]
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(s, [100], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "random slopes" in str(e.value)
