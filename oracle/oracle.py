@@ -228,6 +228,62 @@ def glm_fit(design: np.ndarray, outcome: np.ndarray, beta_start=None, family: st
                 converged=bool(conv.value), n_iter=nit.value)
 
 
+def truth_theta(spec: S.SimulationSpec, include_slopes: bool = True):
+    """`truth_theta` (mixed_workspace.rs:112-198): per grouping the column-major vech of chol(diag(tau) R diag(tau))."""
+    out = []
+    groups = [(spec.cluster.tau_squared, spec.cluster.slopes)] + [
+        (g["tau_squared"], g.get("slopes", []) or []) for g in spec.cluster.extra_groupings]
+    for tau_sq, slopes in groups:
+        if not include_slopes or not slopes:
+            out.append(max(tau_sq, 0.0) ** 0.5)
+            continue
+        q = 1 + len(slopes)
+        tau = np.array([max(tau_sq, 0.0) ** 0.5] + [max(s["variance"], 0.0) ** 0.5 for s in slopes])
+        d = tau[:, None] * np.array(S.re_correlation_matrix(slopes)).reshape(q, q) * tau[None, :]
+        l = np.zeros((q, q))
+        for j in range(q):                      # chol_lower (data_gen.rs:55-75)
+            diag = d[j, j] - (l[j, :j] ** 2).sum()
+            l[j, j] = max(diag, 0.0) ** 0.5
+            for i in range(j + 1, q):
+                if l[j, j] > 0.0:
+                    l[i, j] = (d[i, j] - (l[i, :j] * l[j, :j]).sum()) / l[j, j]
+        out += [l[r, c] for c in range(q) for r in range(c, q)]
+    return out
+
+
+def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, slope_cols, theta_start=None):
+    """General REML LMM on provided bytes.  term_ids: list of (n,) 0-based level ids, primary first;
+    term_q: RE width per term (1 + slopes); slope_cols: per term the design columns of its slopes."""
+    n, p = design.shape
+    x = np.ascontiguousarray(design.T, dtype=np.float32)
+    y = np.ascontiguousarray(outcome, dtype=np.float32)
+    nt = len(term_ids)
+    ids = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.uint32) for v in term_ids]))
+    q = np.asarray(term_q, dtype=np.uint32)
+    levels = np.asarray([int(v.max()) + 1 for v in ids], dtype=np.uint32)
+    cols = np.zeros((nt, S.MAX_RE_SLOPES), dtype=np.uint32)
+    for t, cs in enumerate(slope_cols):
+        cols[t, :len(cs)] = cs
+    n_theta = int(sum(int(v) * (int(v) + 1) // 2 for v in q))
+    beta, se, zsq = (np.zeros(p) for _ in range(3))
+    theta = np.zeros(max(n_theta, 1))
+    vars_out = np.zeros((nt, 3, 3))
+    s2 = C.c_double()
+    conv, bh, ne, pinned = C.c_uint8(), C.c_uint8(), C.c_uint32(), C.c_uint64()
+    pd, pu = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+    t0 = None if theta_start is None else np.ascontiguousarray(theta_start, dtype=np.float64)
+    rc = lib().mcpo_lmm_general_fit(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
+                                    C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), C.c_uint32(nt), q.ctypes.data_as(pu),
+                                    levels.ctypes.data_as(pu), ids.ctypes.data_as(pu), cols.ctypes.data_as(pu),
+                                    None if t0 is None else t0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
+                                    se.ctypes.data_as(pd), zsq.ctypes.data_as(pd), theta.ctypes.data_as(pd),
+                                    C.byref(s2), vars_out.ctypes.data_as(pd), C.byref(conv), C.byref(bh),
+                                    C.byref(pinned), C.byref(ne))
+    _check(rc)
+    return dict(beta=beta, se=se, z_sq=zsq, theta=theta[:n_theta], sigma_sq=s2.value, cov=vars_out,
+                converged=bool(conv.value), boundary_hit=conv.value and bh.value, pinned=pinned.value, n_eval=ne.value)
+
+
 def lmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, theta_start: float = 0.0):
     """Random-intercept REML on provided bytes: design (n, p), outcome (n,), 0-based cluster ids (n,)."""
     n, p = design.shape

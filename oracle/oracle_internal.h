@@ -37,6 +37,26 @@ uint32_t mcpo_cluster_of_row(const mcp_cluster* c, uint32_t i);
 uint32_t mcpo_n_clusters_at(const mcp_cluster* c, uint32_t n);
 void mcpo_compute_het_coeffs(const mcp_spec* spec, double* lp_mean, double* lp_std, double* col_mean, double* col_std);
 
+/* general mixed model (fit_lmm_general.c): one term per grouping, primary first */
+#define MCPO_GEN_MAX_TERMS (1 + MCP_MAX_EXTRA_GROUPINGS)
+typedef struct mcpo_re_term {
+  uint32_t q, n_levels;
+  const uint32_t* ids;                  /* level id per row */
+  uint32_t cols[MCP_MAX_RE_SLOPES];     /* design column of each slope */
+} mcpo_re_term;
+typedef struct mcpo_gen_fit {
+  int converged;
+  uint8_t boundary_hit, at_upper;
+  uint64_t pinned;                      /* bit k: diagonal variance component k at 0, order [primary intercept, slopes.., extra_1 ..] */
+  uint32_t n_eval, n_theta, p;
+  double theta[12];
+  double dev, sigma_sq;
+  double beta[MCPO_MAX_P];
+  double L[MCPO_MAX_P * MCPO_MAX_P];    /* row-major lower Cholesky factor of RX'RX (= X'V^-1X up to sigma^2) */
+} mcpo_gen_fit;
+int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
+                               const mcpo_re_term* terms, uint32_t n_terms, const double* theta_start, mcpo_gen_fit* f);
+
 /* OLS sufficient statistics + fit (fit_ols.c) */
 typedef struct mcpo_olsfit_t {
   uint32_t p;

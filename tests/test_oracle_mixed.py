@@ -20,3 +20,29 @@ def test_mixed_model_datasets_are_reproduced_bit_exact(name, oracle):
         assert np.array_equal(e, a["extra_ids"][g]), g
     assert np.array_equal(x, a["design"])
     assert np.array_equal(y, a["outcome"])
+
+
+def _terms(spec, a):
+    ids = [a["cluster_ids"]] + [a["extra_ids"][g] for g in range(a["extra_ids"].shape[0])]
+    q = [1 + len(spec.cluster.slopes)] + [1 + len(g.get("slopes", [])) for g in spec.cluster.extra_groupings]
+    cols = [spec.cluster_slope_design_cols] + list(spec.extra_slope_cols)
+    return ids, q, cols
+
+
+@pytest.mark.parametrize("name", mixed_case_names())
+def test_general_reml_fit_matches_lme4_goldens(name, oracle):
+    """validation/tolerances.R:38-49: beta and Wald z at 1e-4 relative, variance components at 1e-3."""
+    spec, _, a, low = load_case(name)
+    ids, q, cols = _terms(spec, a)
+    for start in (None, "truth"):
+        th0 = None
+        if start == "truth":
+            th0 = oracle.truth_theta(spec)
+        r = oracle.lmm_general_fit(a["design"], a["outcome"], ids, q, cols, theta_start=th0)
+        assert r["converged"], (name, start, r)
+        assert np.allclose(r["beta"], a["golden_beta"], rtol=1e-4, atol=1e-6), (name, start, r["beta"], a["golden_beta"])
+        z = r["beta"] / r["se"]
+        assert np.allclose(z, a["golden_z"], rtol=1e-4, atol=1e-5), (name, start, z, a["golden_z"])
+        assert abs(r["sigma_sq"] - a["golden_sigma2"][0]) <= 1e-3 * a["golden_sigma2"][0]
+        got_vars = sorted(v for t, qq in enumerate(q) for v in np.diag(r["cov"][t])[:qq])
+        assert np.allclose(got_vars, sorted(a["golden_vars"]), rtol=2e-3, atol=2e-5), (name, start, got_vars, a["golden_vars"])
