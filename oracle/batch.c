@@ -34,7 +34,7 @@ int mcpo_glm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
                  uint8_t* conv, uint8_t* overall, uint8_t* fx, double* stat_row);
 int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
-                 uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row);
+                 uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row, uint64_t* pinned);
 
 static uint32_t total_posthoc_contrasts(const mcp_spec* spec) {
   uint32_t tot = 0;
@@ -252,10 +252,9 @@ static void* worker(void* arg) {
       rc = mcpo_mle_arm(spec, ws, jb->max_n, jb->ns, n_ns, jb->crit, cs, R->uncorrected + cell0 * nt,
                         R->corrected + cell0 * nt, R->converged + cell0, R->boundary_hit + cell0,
                         R->joint_unc + cell0, R->joint_cor + cell0, fx,
-                        R->stat_capture ? R->stat_capture + (size_t)s * nt : NULL);
+                        R->stat_capture ? R->stat_capture + (size_t)s * nt : NULL,
+                        R->pinned_components + cell0); /* bit k = diagonal variance component k pinned at 0 (spec.rs:566-573) */
       if (rc) { jb->rc = rc; break; }
-      for (uint32_t g = 0; g < n_ns; ++g) /* bit 0 = intercept variance pinned at 0 (spec.rs:566-573) */
-        R->pinned_components[cell0 + g] = R->boundary_hit[cell0 + g] == 1 ? 1u : 0u;
     }
   }
   mcpo_ws_free(ws);

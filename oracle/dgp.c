@@ -399,7 +399,7 @@ uint32_t mcpo_extra_level_of_row(const mcp_cluster* c, uint32_t g, uint32_t i) {
 }
 
 /* u_k = sum_{j<=k} L[k][j] z_j for k >= 1, with L = chol(diag(tau) R diag(tau)) (data_gen.rs:163-214, 242-283) */
-static void slope_cholesky(const mcp_re_slopes* sl, double tau0, double* l /* q*q row-major */) {
+void mcpo_slope_cholesky(const mcp_re_slopes* sl, double tau0, double* l /* q*q row-major */) {
   uint32_t q = 1 + sl->n_slopes;
   double tv[1 + MCP_MAX_RE_SLOPES], d[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)];
   tv[0] = tau0;
@@ -512,7 +512,7 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
     if (cl->slopes.n_slopes) {
       uint32_t nsl = cl->slopes.n_slopes, q = 1 + nsl;
       double l[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)], z[1 + MCP_MAX_RE_SLOPES];
-      slope_cholesky(&cl->slopes, tau, l);
+      mcpo_slope_cholesky(&cl->slopes, tau, l);
       for (uint32_t c = 0; c < n_clusters; ++c) {
         z[0] = tau > 0.0 ? (double)ws->cluster_u[c] / tau : 0.0;
         for (uint32_t j = 1; j < q; ++j) z[j] = draw_residual(&rng, re_dist, re_df);
@@ -536,7 +536,7 @@ int mcpo_generate_ws(const mcp_spec* spec, uint64_t base_seed, uint64_t sim_id, 
       double tau0 = sqrt(fmax(extra_tau_sq[g], 0.0));
       uint32_t qg = 1 + sl->n_slopes, nl = mcpo_extra_n_levels_at(cl, g, max_n);
       double l[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)], z[1 + MCP_MAX_RE_SLOPES];
-      slope_cholesky(sl, tau0, l);
+      mcpo_slope_cholesky(sl, tau0, l);
       for (uint32_t c = 0; c < nl; ++c) {
         z[0] = tau0 > 0.0 ? (double)ws->extra_u[g][c * qg] / tau0 : 0.0;
         for (uint32_t j = 1; j < qg; ++j) z[j] = draw_residual(&rng, re_dist, re_df);

@@ -301,8 +301,12 @@ int mcpo_lmm_fit(const float* x, const float* y, const uint32_t* cluster_ids, ui
  * (:1456-1468); marginal / correction thresholds are Wald-z, df-free, and stay on the full table. */
 int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
-                 uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row) {
-  if (!spec->cluster.present || spec->cluster.slopes.n_slopes || spec->cluster.n_extra_groupings) return MCP_ERR_UNSUPPORTED;
+                 uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row, uint64_t* pinned) {
+  if (!spec->cluster.present) return MCP_ERR_UNSUPPORTED;
+  const mcp_cluster* cl = &spec->cluster;
+  /* random slopes or extra groupings: the general solver (fit_lmm_general.c); a random intercept alone keeps Brent */
+  int general = cl->slopes.n_slopes || cl->n_extra_groupings;
+  for (uint32_t e = 0; e < cl->n_extra_groupings; ++e) general |= cl->extra[e].slopes.n_slopes != 0;
   if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS || spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;
   const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
   const uint32_t nt = spec->n_target_indices, nf = spec->n_factors;
@@ -316,6 +320,12 @@ int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
   for (uint32_t i = 0; i < max_n; ++i) ids[i] = mcpo_cluster_of_row(&spec->cluster, i);
   int has_prev = 0;
   double theta_carry = 0.0;
+  double gen_carry[12];
+  uint32_t* extra_ids[MCP_MAX_EXTRA_GROUPINGS] = {NULL, NULL};
+  for (uint32_t e = 0; general && e < cl->n_extra_groupings; ++e) {
+    extra_ids[e] = (uint32_t*)malloc(sizeof(uint32_t) * max_n);
+    for (uint32_t i = 0; i < max_n; ++i) extra_ids[e][i] = mcpo_extra_level_of_row(cl, e, i);
+  }
   uint32_t prefix_counts[MCPO_MAX_LEVELS], kept[MCPO_MAX_P];
   int32_t remap[MCPO_MAX_P];
   uint8_t flags[16] = {0};
@@ -343,15 +353,47 @@ int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
     }
     /* clusters that own at least one of the first n rows (generation.rs:152-157); empty ones are skipped */
     uint32_t ncl = fixed_clusters ? cv : (n + cv - 1) / cv;
-    lmm_data d;
-    rc = build_lmm_data(xfit, ws->y, ids, n, max_n, p_red, ncl, &d, csum);
-    if (rc) break;
-    double start = has_prev ? theta_carry
-                            : (spec->scenario.truth_start ? sqrt(fmax(spec->cluster.tau_squared, 0.0)) : THETA_BLIND);
-    if (start < 0.01) start = 0.01; /* THETA_TRUTH_FLOOR, batch.rs:1316-1321 */
     lmm_fit f;
-    lmm_fit_data(&d, start, &f);
-    if (!reduced && f.converged) { theta_carry = f.theta; has_prev = 1; }
+    uint64_t pin = 0;
+    if (!general) {
+      lmm_data d;
+      rc = build_lmm_data(xfit, ws->y, ids, n, max_n, p_red, ncl, &d, csum);
+      if (rc) break;
+      double start = has_prev ? theta_carry
+                              : (spec->scenario.truth_start ? sqrt(fmax(spec->cluster.tau_squared, 0.0)) : THETA_BLIND);
+      if (start < 0.01) start = 0.01; /* THETA_TRUTH_FLOOR, batch.rs:1316-1321 */
+      lmm_fit_data(&d, start, &f);
+      if (!reduced && f.converged) { theta_carry = f.theta; has_prev = 1; }
+      pin = f.boundary_hit == 1 ? 1u : 0u;
+    } else {
+      /* one term per grouping; a reduced round strips every random slope (batch.rs:1359-1376) and never
+       * feeds or reads the theta carry (its theta has another shape, :1414-1428) */
+      mcpo_re_term terms[MCPO_GEN_MAX_TERMS];
+      memset(terms, 0, sizeof terms);
+      uint32_t n_terms = 1 + cl->n_extra_groupings;
+      for (uint32_t t = 0; t < n_terms; ++t) {
+        const mcp_re_slopes* sl = t == 0 ? &cl->slopes : &cl->extra[t - 1].slopes;
+        terms[t].q = reduced ? 1u : 1u + sl->n_slopes;
+        terms[t].n_levels = t == 0 ? ncl : mcpo_extra_n_levels_at(cl, t - 1, n);
+        terms[t].ids = t == 0 ? ids : extra_ids[t - 1];
+        for (uint32_t d = 0; d < sl->n_slopes; ++d) terms[t].cols[d] = sl->design_cols[d];
+      }
+      double th0[12];
+      const double* start = NULL;
+      if (!reduced && has_prev) start = gen_carry;
+      else if (spec->scenario.truth_start) { mcpo_truth_theta(cl, !reduced, th0); start = th0; }
+      mcpo_gen_fit gf;
+      rc = mcpo_lmm_general_fit_terms(xfit, ws->y, n, max_n, p_red, terms, n_terms, start, &gf);
+      if (rc) break;
+      memset(&f, 0, sizeof f);
+      f.converged = gf.converged; f.boundary_hit = gf.boundary_hit; f.sigma_sq = gf.sigma_sq;
+      f.ev.ok = gf.converged; f.ev.sigma_sq = gf.sigma_sq;
+      memcpy(f.ev.beta, gf.beta, sizeof gf.beta);
+      memcpy(f.ev.L, gf.L, sizeof gf.L);
+      pin = gf.pinned;
+      if (!reduced && gf.converged) { memcpy(gen_carry, gf.theta, sizeof(double) * gf.n_theta); has_prev = 1; }
+    }
+    if (pinned) pinned[g] = f.converged ? pin : 0;
     const double* crow = crit + (size_t)g * crit_stride;
     conv[g] = (uint8_t)f.converged;
     bh[g] = f.boundary_hit;
@@ -383,5 +425,6 @@ int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
   free(csum);
   free(ids);
   free(xr);
+  for (uint32_t e = 0; e < MCP_MAX_EXTRA_GROUPINGS; ++e) free(extra_ids[e]);
   return rc;
 }

@@ -331,7 +331,7 @@ static void gen_minimise(gen_model* m, const double* theta_start, mcpo_gen_fit* 
   double th[GEN_MAX_THETA];
   for (uint32_t k = 0; k < d; ++k) {
     th[k] = theta_start ? theta_start[k] : (is_diag[k] ? 1.0 : 0.0);  /* blind: lme4's start */
-    if (theta_start && th[k] < 0.01 && is_diag[k]) th[k] = 0.01;       /* THETA_TRUTH_FLOOR on the diagonals */
+    if (theta_start && th[k] < 0.01) th[k] = 0.01;  /* THETA_TRUTH_FLOOR: every component of a given start, off-diagonals too (batch.rs:1316-1321) */
   }
   memset(f, 0, sizeof *f);
   uint32_t n_eval = 0;
@@ -368,6 +368,22 @@ static void gen_minimise(gen_model* m, const double* theta_start, mcpo_gen_fit* 
   }
   f->boundary_hit = !f->converged ? 0 : (f->at_upper ? 2 : (f->pinned ? 1 : 0));
   if (f->at_upper) f->converged = 0;
+}
+
+/* truth_theta (mixed_workspace.rs:112-198): per grouping the column-major vech of chol(diag(tau) R diag(tau)) */
+uint32_t mcpo_truth_theta(const mcp_cluster* c, int include_slopes, double* theta) {
+  uint32_t k = 0;
+  for (uint32_t t = 0; t <= c->n_extra_groupings; ++t) {
+    const mcp_re_slopes* sl = t == 0 ? &c->slopes : &c->extra[t - 1].slopes;
+    double tau0 = sqrt(fmax(t == 0 ? c->tau_squared : c->extra[t - 1].tau_squared, 0.0));
+    if (!include_slopes || sl->n_slopes == 0) { theta[k++] = tau0; continue; }
+    uint32_t q = 1 + sl->n_slopes;
+    double l[(1 + MCP_MAX_RE_SLOPES) * (1 + MCP_MAX_RE_SLOPES)];
+    mcpo_slope_cholesky(sl, tau0, l);
+    for (uint32_t col = 0; col < q; ++col)
+      for (uint32_t row = col; row < q; ++row) theta[k++] = l[row * q + col];
+  }
+  return k;
 }
 
 int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,

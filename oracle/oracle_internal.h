@@ -54,6 +54,8 @@ typedef struct mcpo_gen_fit {
   double beta[MCPO_MAX_P];
   double L[MCPO_MAX_P * MCPO_MAX_P];    /* row-major lower Cholesky factor of RX'RX (= X'V^-1X up to sigma^2) */
 } mcpo_gen_fit;
+void mcpo_slope_cholesky(const mcp_re_slopes* sl, double tau0, double* l);
+uint32_t mcpo_truth_theta(const mcp_cluster* c, int include_slopes, double* theta);
 int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                const mcpo_re_term* terms, uint32_t n_terms, const double* theta_start, mcpo_gen_fit* f);
 

@@ -46,3 +46,43 @@ def test_general_reml_fit_matches_lme4_goldens(name, oracle):
         assert abs(r["sigma_sq"] - a["golden_sigma2"][0]) <= 1e-3 * a["golden_sigma2"][0]
         got_vars = sorted(v for t, qq in enumerate(q) for v in np.diag(r["cov"][t])[:qq])
         assert np.allclose(got_vars, sorted(a["golden_vars"]), rtol=2e-3, atol=2e-5), (name, start, got_vars, a["golden_vars"])
+
+
+def test_run_batch_general_arm_power_and_flags(oracle):
+    """The Mle arm over the general solver: per-replicate Wald decisions equal a refit of the same bytes, the grid
+    carries theta-hat forward, pinned bits only appear on converged singular fits, and power sits where the
+    standard errors of the golden fit put it."""
+    from helpers import BASE_SEED
+    spec, _, a, low = load_case("lmm_slope_a")
+    spec.target_indices = [1]
+    spec.scenario.truth_start = True
+    r = oracle.run_batch(spec, [240, 480], 60, BASE_SEED, n_threads=4)
+    assert r.converged.mean() > 0.95 and r.boundary_hit.max() <= 2
+    crit = oracle.build_crit_table(spec, [240, 480])
+    for sim in range(6):
+        x, y, ids, _ = oracle.generate_sim_data_ids(spec, BASE_SEED, sim, 480)
+        for gi, n in enumerate((240, 480)):
+            f = oracle.lmm_general_fit(x[:n], y[:n], [ids[:n]], [2], [[1]], theta_start=oracle.truth_theta(spec))
+            if gi == 0 and f["converged"] and r.converged[sim, gi]:
+                assert bool(f["z_sq"][1] > crit[gi, 0]) == bool(r.uncorrected[sim, gi, 0])
+    assert r.uncorrected[:, 1, 0].mean() > 0.9                 # beta 0.30, se ~ 0.076 at n = 480
+    assert (r.pinned_components[r.converged == 0] == 0).all()
+    assert np.array_equal(r.joint_unc, r.joint_cor)
+
+
+def test_reduced_round_strips_slopes_but_keeps_extra_intercepts(oracle):
+    """batch.rs:1359-1376: a test_formula / exclusion round fits intercept-only groupings on the kept columns."""
+    from helpers import BASE_SEED
+    spec, _, a, low = load_case("lmm_slope_crossed")
+    spec.n_non_factor = 1
+    spec.target_indices = [1]
+    full = oracle.run_batch(spec, [480], 20, BASE_SEED, n_threads=4)
+    assert full.converged.mean() > 0.9
+    two, _, _, _ = load_case("lmm_crossed_a")                   # y ~ x1 + x2 with a crossed extra, no slopes
+    two.fit_columns = [0, 1]
+    two.target_indices = [1]
+    red = oracle.run_batch(two, [480], 20, BASE_SEED, n_threads=4)
+    x, y, ids, ex = oracle.generate_sim_data_ids(two, BASE_SEED, 0, 480)
+    f = oracle.lmm_general_fit(x[:, :2], y, [ids, ex[0]], [1, 1], [[], []])
+    crit = oracle.build_crit_table(two, [480])
+    assert bool(f["z_sq"][1] > crit[0, 0]) == bool(red.uncorrected[0, 0, 0])
