@@ -39,6 +39,8 @@ hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32
                           bool reduced, bool scen, hipStream_t st);
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 size_t lmm_rec_fields(int P, uint32_t ncl_max);
+hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
+size_t lmg_lds_bytes(const SimParams& prm);
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st);
 }  // namespace mcp
@@ -66,7 +68,7 @@ struct Arena {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Buf slots[28];
+  Buf slots[29];
   Buf pinned[2];  // host staging: [0] the upload blob, [1] the counters coming back
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
@@ -129,7 +131,7 @@ struct Ticket {
 thread_local Ticket g_tickets[MAX_IN_FLIGHT];
 thread_local hipStream_t g_upload_stream = nullptr;  // a batch in flight uploads its tables beside the running kernel
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS, S_PINNED };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts, Arena* extra = nullptr) {
   int n = 0;
@@ -281,7 +283,16 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
-  if (mle && mcp::lmm_lds_bytes((int)P, prm.max_n, prm.n_clusters_max) > 150u * 1024u) {
+  const bool lmg = mle && prm.lmg_active;  // random slopes / extra groupings: the general mixed-model kernel
+  if (lmg && prm.scen_active) {
+    mcp_free_result(out);
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: random slopes / extra groupings on the general (scenario / upload) data path");
+  }
+  if (lmg && mcp::lmg_lds_bytes(prm) > 158u * 1024u) {
+    mcp_free_result(out);
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the random-effect structure does not fit one wave's LDS budget");
+  }
+  if (mle && !lmg && mcp::lmm_lds_bytes((int)P, prm.max_n, prm.n_clusters_max) > 150u * 1024u) {
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: LMM design + cluster sums do not fit one wave's LDS budget");
   }
@@ -305,7 +316,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
       if (step < chunk) chunk = step;
     }
   }
-  if (mle) {  // the cluster-sum records between the two LMM kernels: keep one chunk's worth under 1 GiB
+  if (mle && !lmg) {  // the cluster-sum records between the two LMM kernels: keep one chunk's worth under 1 GiB
     const size_t per_rep = mcp::lmm_rec_fields((int)P, prm.n_clusters_max) * n_ns * sizeof(double);
     const size_t cap = ((size_t)1 << 30) / (per_rep ? per_rep : 1);
     if (cap < 64) {
@@ -374,9 +385,13 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   double* d_lmm_rec = nullptr;
   uint32_t* d_lmm_flags = nullptr;
   const uint32_t lmm_stride = (chunk + 63u) & ~63u;
+  uint16_t* d_pinned = nullptr;
+  if (lmg) DEV_TRY(ar.get(S_PINNED, (cells + 1) * sizeof(uint16_t), (void**)&d_pinned));
   if (mle) {
     DEV_TRY(ar.get(S_BOUNDARY, cells + 1, (void**)&d_bh));
     DEV_TRY(ar.get(S_JOINT, cells + 1, (void**)&d_joint));
+  }
+  if (mle && !lmg) {
     DEV_TRY(ar.get(S_LMM_REC, mcp::lmm_rec_fields((int)P, prm.n_clusters_max) * n_ns * lmm_stride * sizeof(double), (void**)&d_lmm_rec));
     DEV_TRY(ar.get(S_LMM_FLAGS, (size_t)n_ns * lmm_stride * sizeof(uint32_t), (void**)&d_lmm_flags));
   }
@@ -450,6 +465,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   prm.ctr_posthoc_unc = layout.posthoc_unc; prm.ctr_posthoc_cor = layout.posthoc_cor;
   prm.ctr_excl_sparse = layout.excl_sparse; prm.ctr_excl_sep = layout.excl_sep;
   prm.lmm_rec = d_lmm_rec; prm.lmm_rec_flags = d_lmm_flags; prm.lmm_rec_stride = lmm_stride;
+  prm.pinned = d_pinned;
   prm.tile = d_tile;
   prm.tile_sims = chunk;
   prm.scen_L = d_scen_L;
@@ -484,7 +500,8 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));
+      if (lmg) DEV_TRY(mcp::launch_lmm_general((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
+      else if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));
       else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, scen, prm.glm_family == 0u, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
@@ -522,6 +539,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   // results
   unsigned long long* d_ctr_final = d_ctr + (size_t)copy_stride * mcp::CTR_COPIES;
   DEV_TRY(mcp::launch_reduce_counters(d_ctr, copy_stride, n_ctr, d_ctr_final, st));
+  std::vector<uint16_t> h_pinned;
   uint64_t* h_ctr = nullptr;
   DEV_TRY(ar.get_pinned(1, (size_t)n_ctr * sizeof(uint64_t), (void**)&h_ctr));
   DEV_TRY(hipMemcpyAsync(h_ctr, d_ctr_final, (size_t)n_ctr * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -559,6 +577,10 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
       DEV_TRY(hipMemcpyAsync(out->joint_unc, d_joint, cells, hipMemcpyDeviceToHost, st));
       DEV_TRY(hipMemcpyAsync(out->joint_cor, d_joint, cells, hipMemcpyDeviceToHost, st));
     }
+    if (lmg) {  // pinned-component bits travel as u16 and are widened below
+      h_pinned.resize(cells);
+      DEV_TRY(hipMemcpyAsync(h_pinned.data(), d_pinned, cells * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+    }
   }
   if (want_stat) {
     out->stat_capture = host_alloc<double>((size_t)n_sims * nt);
@@ -574,8 +596,9 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   }
   DEV_TRY(hipStreamSynchronize(st));
   std::memcpy(out->counters, h_ctr, (size_t)n_ctr * sizeof(uint64_t));
-  if (mle && per_sim)  // pinned_components bit 0 = the intercept variance pinned at 0 (spec.rs:566-573)
-    for (size_t i = 0; i < cells; ++i) out->pinned_components[i] = out->boundary_hit[i] == 1 ? 1ull : 0ull;
+  if (mle && per_sim)  // pinned_components: bit k = diagonal variance component k pinned at 0 (spec.rs:566-573)
+    for (size_t i = 0; i < cells; ++i)
+      out->pinned_components[i] = lmg ? (uint64_t)h_pinned[i] : (out->boundary_hit[i] == 1 ? 1ull : 0ull);
 #undef DEV_TRY
   rc = finish_timing(ar, ev_begin, ev_end, launched, ev_per_chunk, glm, reduced, staged, out);
   if (rc) mcp_free_result(out);

@@ -219,8 +219,13 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (n_ns > (uint32_t)MAX_GRID) return unsupported("more than " + std::to_string(MAX_GRID) + " sample sizes per call");
   if (spec->n_factors > (uint32_t)MAX_FACTORS) return unsupported("more than " + std::to_string(MAX_FACTORS) + " factors");
   if (spec->n_factor_proportions > (uint32_t)MAX_LEVELS) return unsupported("more than " + std::to_string(MAX_LEVELS) + " factor levels in total");
+  bool lmm_general = false;  // random slopes / extra groupings: the general mixed-model kernel
+  if (spec->cluster.present) {
+    lmm_general = spec->cluster.slopes.n_slopes != 0 || spec->cluster.n_extra_groupings != 0;
+    if (spec->cluster.slopes.n_slopes > MCP_MAX_RE_SLOPES || spec->cluster.n_extra_groupings > MCP_MAX_EXTRA_GROUPINGS)
+      return unsupported("more than 2 random slopes per grouping or more than 2 extra groupings");
+  }
   if (spec->estimator == MCP_EST_MLE) {
-    if (spec->cluster.slopes.n_slopes || spec->cluster.n_extra_groupings) return unsupported("random slopes / extra groupings (random intercept only)");
     if (spec->outcome_kind != MCP_OUTCOME_CONTINUOUS) return unsupported("Mle on Binary / Count outcomes");
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the Mle estimator");
 
@@ -240,8 +245,26 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
   if (spec->cluster.present && spec->estimator == MCP_EST_GLM) return unsupported("clustered GLM (GLMM: Laplace / AGQ fits)");
-  if (spec->cluster.present && (spec->cluster.slopes.n_slopes || spec->cluster.n_extra_groupings))
-    return unsupported("random slopes / extra groupings (random intercept only)");
+  if (lmm_general) {
+    if (spec->estimator != MCP_EST_MLE) return unsupported("random slopes / extra groupings outside the Mle estimator");
+    if (spec->n_factors) return unsupported("random slopes / extra groupings together with factor predictors");
+    if (spec->n_fit_columns) return unsupported("random slopes / extra groupings together with a test_formula column subset");
+    if (spec->n_between_var_indices) return unsupported("random slopes / extra groupings together with cluster-level predictors");
+    if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");
+    for (uint32_t t = 0; t <= spec->cluster.n_extra_groupings; ++t) {
+      const mcp_re_slopes& sl = t == 0 ? spec->cluster.slopes : spec->cluster.extra[t - 1].slopes;
+      if (sl.n_slopes > MCP_MAX_RE_SLOPES) return unsupported("more than 2 random slopes per grouping");
+      for (uint32_t d = 0; d < sl.n_slopes; ++d)
+        if (sl.design_cols[d] == 0 || sl.design_cols[d] >= P) { err = "invalid spec: random-slope design column out of range"; return MCP_ERR_INVALID_SPEC; }
+      if (t > 0) {
+        if (spec->cluster.extra[t - 1].count == 0) { err = "invalid spec: extra grouping with zero levels"; return MCP_ERR_INVALID_SPEC; }
+        if (spec->cluster.extra[t - 1].relation == MCP_GROUPING_CROSSED && spec->cluster.sizing != MCP_CLUSTER_FIXED_CLUSTERS) {
+          err = "invalid spec: a crossed grouping needs FixedClusters sizing";  // validate(): crossed x FixedSize
+          return MCP_ERR_INVALID_SPEC;
+        }
+      }
+    }
+  }
   if (spec->cluster.present && spec->cluster.sizing_value == 0) { err = "invalid spec: cluster sizing value must be > 0"; return MCP_ERR_INVALID_SPEC; }
   if (spec->cluster.present && spec->cluster.sizing == MCP_CLUSTER_FIXED_SIZE)
     for (uint32_t g = 0; g < n_ns; ++g)
@@ -367,6 +390,73 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
                                  : ((prm.lme_re_dist == 2u || prm.lme_re_dist == 3u) ? (uint32_t)dfi : 1u);
     }
     prm.n_seq_pre = prm.n_clusters_max * prm.re_draws_per_cluster;
+    if (lmm_general) {
+      if (general) return unsupported("random slopes / extra groupings on the general (scenario) data path");
+      const mcp_cluster& cl = spec->cluster;
+      prm.lmg_active = 1;
+      prm.lmg_n_terms = 1 + cl.n_extra_groupings;
+      uint32_t toff = 0, roff = 0, seq = 0;
+      for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) {
+        const mcp_re_slopes& sl = t == 0 ? cl.slopes : cl.extra[t - 1].slopes;
+        const uint32_t q = 1 + sl.n_slopes;
+        prm.lmg_q[t] = q;
+        prm.lmg_theta_off[t] = toff;
+        toff += q * (q + 1) / 2;
+        if (t == 0) {
+          prm.lmg_levels[0] = prm.n_clusters_max;
+        } else {
+          const mcp_grouping& e = cl.extra[t - 1];
+          prm.lmg_relation[t] = e.relation == MCP_GROUPING_CROSSED ? 0u : 1u;
+          prm.lmg_count[t] = e.count;
+          const uint32_t parents = prm.cluster_fixed_clusters ? prm.cluster_v : (max_n + prm.cluster_v - 1) / prm.cluster_v;
+          prm.lmg_levels[t] = e.relation == MCP_GROUPING_CROSSED ? e.count : parents * e.count;  // extra_n_levels_at
+          prm.lmg_roff[t] = roff;
+          roff += prm.lmg_levels[t] * q;
+        }
+        for (uint32_t d = 0; d < sl.n_slopes; ++d) prm.lmg_cols[t][d] = sl.design_cols[d];
+        const double tau_sq = t == 0 ? cl.tau_squared : cl.extra[t - 1].tau_squared;
+        prm.lmg_tau[t] = std::sqrt(tau_sq > 0.0 ? tau_sq : 0.0);
+        // chol_lower of D = diag(tau) R diag(tau) (data_gen.rs:55-75): the slope draws and the truth start share it
+        double tv[3] = {prm.lmg_tau[t], 0.0, 0.0}, dm[9] = {0}, l[9] = {0};
+        for (uint32_t d = 0; d < sl.n_slopes; ++d) tv[d + 1] = std::sqrt(sl.variance[d] > 0.0 ? sl.variance[d] : 0.0);
+        for (uint32_t i = 0; i < q; ++i)
+          for (uint32_t j = 0; j < q; ++j) dm[i * q + j] = tv[i] * sl.re_corr[i * q + j] * tv[j];
+        for (uint32_t j = 0; j < q; ++j) {
+          double diag = dm[j * q + j];
+          for (uint32_t k = 0; k < j; ++k) diag -= l[j * q + k] * l[j * q + k];
+          const double ljj = std::sqrt(diag > 0.0 ? diag : 0.0);
+          l[j * q + j] = ljj;
+          for (uint32_t i = j + 1; i < q; ++i)
+            if (ljj > 0.0) {
+              double sacc = dm[i * q + j];
+              for (uint32_t k = 0; k < j; ++k) sacc -= l[i * q + k] * l[j * q + k];
+              l[i * q + j] = sacc / ljj;
+            }
+        }
+        for (uint32_t i = 0; i < 9; ++i) prm.lmg_chol[t][i] = i < q * q ? l[i] : 0.0;
+        // truth_theta (mixed_workspace.rs:112-198): column-major lower vech of the same factor
+        uint32_t k = prm.lmg_theta_off[t];
+        if (sl.n_slopes == 0) prm.lmg_theta_truth[k] = prm.lmg_tau[t];
+        else
+          for (uint32_t col = 0; col < q; ++col)
+            for (uint32_t row = col; row < q; ++row) prm.lmg_theta_truth[k++] = l[row * q + col];
+      }
+      prm.lmg_n_theta = toff;
+      prm.lmg_R = roff;
+      prm.lmg_W = roff + P + 1;
+      // sequential-stream layout (data_gen.rs:146-284): primary intercepts, primary slopes, every extra grouping's
+      // intercepts, then every extra grouping's slopes; one word per Normal draw
+      prm.lmg_seq[0] = 0;
+      seq = prm.lmg_levels[0];
+      prm.lmg_seq[1] = seq;
+      seq += prm.lmg_levels[0] * (prm.lmg_q[0] - 1);
+      for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) { prm.lmg_seq[2 * t] = seq; seq += prm.lmg_levels[t]; }
+      for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) { prm.lmg_seq[2 * t + 1] = seq; seq += prm.lmg_levels[t] * (prm.lmg_q[t] - 1); }
+      prm.n_seq_pre = seq;
+      if (prm.lmg_n_theta > (uint32_t)LMG_MAX_THETA) return unsupported("random-effect structures with more than 12 covariance parameters");
+      if (prm.lmg_W > 128u) return unsupported("extra groupings with more than ~120 random-effect columns in total");
+      if (prm.lme_re_dist != 0u) return unsupported("non-normal random effects together with random slopes / extra groupings");
+    }
   }
   prm.truth_start = spec->scenario.truth_start ? 1u : 0u;
   low.fixed_levels.assign((size_t)max_n * (spec->n_factors ? spec->n_factors : 1), 0);

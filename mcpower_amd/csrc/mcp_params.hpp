@@ -24,6 +24,10 @@ constexpr int MAX_PC = 28;       // post-hoc pairwise contrasts per fit (<= 7 du
 // 256 copies, each on its own cache lines, takes that off the critical path; a tiny kernel sums the copies.
 constexpr int CTR_COPIES = 256;
 
+constexpr int LMG_MAX_TERMS = 3;   // primary + MCP_MAX_EXTRA_GROUPINGS
+constexpr int LMG_MAX_SLOPES = 2;  // MCP_MAX_RE_SLOPES
+constexpr int LMG_MAX_THETA = 12;
+
 struct SimParams {
   uint64_t base_seed;
   uint64_t sim_begin;      // sim_id of lane 0 of block 0
@@ -160,6 +164,25 @@ struct SimParams {
   uint32_t* lmm_rec_flags;         // [n_grid][lmm_rec_stride]: exclusion flag bits | LMM_FLAG_BALANCED
   uint32_t lmm_rec_stride;         // replicates per chunk, padded to 64
   uint32_t _pad_lmm;
+
+  // ---- general mixed model: random slopes, crossed / nested extra groupings (generation.rs:196-427,
+  //      data_gen.rs:163-284, 812-842; mixed_workspace.rs:57-198).  Term 0 = primary grouping ----
+  uint32_t lmg_active;
+  uint32_t lmg_n_terms;              // 1 + extra groupings
+  uint32_t lmg_q[LMG_MAX_TERMS];     // random-effect width per term (1 + slopes)
+  uint32_t lmg_levels[LMG_MAX_TERMS];  // levels at max_n
+  uint32_t lmg_relation[LMG_MAX_TERMS];  // term >= 1: 0 crossed, 1 nested within the primary
+  uint32_t lmg_count[LMG_MAX_TERMS];   // term >= 1: n_clusters (crossed) / n_per_parent (nested)
+  uint32_t lmg_cols[LMG_MAX_TERMS][LMG_MAX_SLOPES];  // design column of each slope
+  uint32_t lmg_roff[LMG_MAX_TERMS];  // first column of term t >= 1 inside the dense "rest" block
+  uint32_t lmg_theta_off[LMG_MAX_TERMS];
+  uint32_t lmg_n_theta, lmg_R, lmg_W;  // theta length; rest width; W = R + P + 1
+  uint32_t lmg_seq[2 * LMG_MAX_TERMS];   // first sequential-stream word of [intercepts of term t | slopes of term t]
+  uint32_t _pad_lmg;
+  double lmg_tau[LMG_MAX_TERMS];     // sqrt(max(tau^2, 0)) per term
+  double lmg_chol[LMG_MAX_TERMS][9]; // row-major lower chol(diag(tau) R diag(tau)) per term: the slope draws
+  double lmg_theta_truth[LMG_MAX_THETA];
+  uint16_t* pinned;                  // [n_sims_total][n_grid] pinned-component bits (spec.rs:566-573) or null
 
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;
