@@ -52,17 +52,24 @@ __device__ __forceinline__ uint32_t lmg_level_of_row(const SimParams& prm, uint3
   return (i / v) * bl + (i % v) % bl;
 }
 
+// LDS-qualified pointers: 32-bit, ds_* instructions, and provably disjoint from private memory -- with generic
+// pointers every access went through flat instructions and the struct of pointers was re-read from scratch
+// after each store (measured: 10x slower)
+typedef __attribute__((address_space(3))) double ldd;
+typedef __attribute__((address_space(3))) float ldf;
+typedef __attribute__((address_space(3))) uint32_t ldu;
+
 // LDS map of one replicate (doubles first, then floats)
 struct LmgLds {
-  double *gzz, *gzw, *gww, *S, *B, *simplex, *fv, *tm, *misc, *tail, *carry;
-  uint32_t* nzl;  // per primary level: [count, columns...] (W + 1 entries each)
-  uint32_t* ridx;
-  double* rval;
-  float *design, *u0, *us, *ux, *st;
+  ldd *gzz, *gzw, *gww, *S, *B, *ld, *simplex, *fv, *tm, *misc, *tail, *carry;
+  ldu* ridx;
+  ldd* rval;
+  ldf *design, *u0, *us, *ux;
+  float* st;  // staging of the row generator (generic: shared with mcp_rows.hpp)
 };
 
 // template entries T_t[r][c] of every term from theta (column-major vech per term, mixed_workspace.rs:189-196)
-__device__ __forceinline__ void lmg_templates(const SimParams& prm, const double* th, double* tm, uint32_t lane) {
+__device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* th, ldd* tm, uint32_t lane) {
   if (lane < 27u) {
     const uint32_t t = lane / 9u, r = (lane % 9u) / 3u, c = lane % 3u;
     double v = 0.0;
@@ -80,7 +87,7 @@ __device__ __forceinline__ void lmg_templates(const SimParams& prm, const double
 // one evaluation of the profiled REML criterion at theta `th` (LDS, n_theta doubles).  Returns the deviance (inf
 // when a pivot fails); leaves sigma^2 in misc[0], beta in tail[0..p), the lower factor of RX'RX in tail[8 + a*8 + b].
 template <int Q0>
-__device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds& m, const double* th, uint32_t lane, double n_rows) {
+__device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows) {
   const uint32_t W = prm.lmg_W, R = prm.lmg_R, p = prm.P, L0 = prm.lmg_levels[0];
   const double inf = __builtin_inf();
   lmg_templates(prm, th, m.tm, lane);
@@ -123,17 +130,21 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds& m, c
     }
   }
   lmg_sync();
-  // ---- eliminate the primary blocks, one level at a time ----
-  double logdet = 0.0;
+  // ---- eliminate the primary blocks: lane = level ----
+  // Each lane factors its level's q0 x q0 block and forward-solves the level's strip B_c = Lc^-1 T0' [Gzw Lambda~]
+  // (q0 x W, zeros where the level has no rows) into LDS; then S -= sum_k B[k]' B[k] runs as a small matrix product
+  // with lanes over the (i, j) pairs and k = (level, a) ascending -- the oracle's summation order.
+  double logdet = 0.0, pd = 1.0;
+  uint32_t npd = 0;
   bool ok = true;
   double T0[Q0][Q0];
 #pragma unroll
   for (int r = 0; r < Q0; ++r)
 #pragma unroll
     for (int c = 0; c < Q0; ++c) T0[r][c] = m.tm[r * 3 + c];
-  for (uint32_t c = 0; c < L0; ++c) {
-    const double* G = m.gzz + (size_t)c * Q0 * Q0;
-    double A[Q0][Q0], Lc[Q0][Q0];
+  for (uint32_t c = lane; c < L0; c += GW) {
+    const ldd* G = m.gzz + (size_t)c * Q0 * Q0;
+    double A[Q0][Q0], Lc[Q0][Q0], pdc = 1.0;
 #pragma unroll
     for (int a = 0; a < Q0; ++a)
 #pragma unroll
@@ -154,7 +165,7 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds& m, c
         if (k < j) d -= Lc[j][k] * Lc[j][k];
       ok = ok && (d > 0.0);
       Lc[j][j] = __builtin_sqrt(d);
-      logdet += 2.0 * log(Lc[j][j]);
+      pdc *= d;
 #pragma unroll
       for (int i = 0; i < Q0; ++i)
         if (i > j) {
@@ -165,55 +176,80 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds& m, c
           Lc[i][j] = v / Lc[j][j];
         }
     }
-    // B = Lc^-1 T0' [Gzw Lambda_rest | Gzx | Gzy] on the columns this level touches
-    const uint32_t* nz = m.nzl + (size_t)c * (W + 1u);
-    const uint32_t cnt = nz[0];
-    for (uint32_t e = lane; e < cnt; e += GW) {
-      const uint32_t j = nz[1u + e];
-      uint32_t tj = 0, bj = 0, qj = 1, sj = j;
-      if (j < R) {
-        tj = 1;
-        while (tj + 1u < prm.lmg_n_terms && j >= prm.lmg_roff[tj + 1u]) ++tj;
-        qj = prm.lmg_q[tj];
-        bj = (j - prm.lmg_roff[tj]) % qj;
-        sj = j - bj;
-      }
-      double zw[Q0];
+    m.ld[c] = log(pdc);
+    // columns this level can meet: every crossed column, its own nested children, X and y
+    for (uint32_t tj = 1; tj <= prm.lmg_n_terms; ++tj) {
+      const bool xy = tj == prm.lmg_n_terms;
+      const uint32_t qj = xy ? 1u : prm.lmg_q[tj];
+      uint32_t jlo, jhi;
+      if (xy) { jlo = R; jhi = W; }
+      else if (prm.lmg_relation[tj] == 1u) { jlo = prm.lmg_roff[tj] + c * prm.lmg_count[tj] * qj; jhi = jlo + prm.lmg_count[tj] * qj; }
+      else { jlo = prm.lmg_roff[tj]; jhi = jlo + prm.lmg_levels[tj] * qj; }
+      for (uint32_t sj = jlo; sj < jhi; sj += qj) {
+        for (uint32_t bj = 0; bj < qj; ++bj) {
+          const uint32_t j = sj + bj;
+          double zw[Q0];
 #pragma unroll
-      for (int r = 0; r < Q0; ++r) {
-        const double* row = m.gzw + ((size_t)c * Q0 + r) * W;
-        double s = 0.0;
-        for (uint32_t d = bj; d < qj; ++d) s += (j < R ? m.tm[tj * 9u + d * 3u + bj] : 1.0) * row[sj + d];
-        zw[r] = s;
-      }
-      double bcol[Q0];
+          for (int r = 0; r < Q0; ++r) {
+            const ldd* row = m.gzw + ((size_t)c * Q0 + r) * W;
+            double sacc = 0.0;
+            if (!xy) {
+              for (uint32_t d = bj; d < qj; ++d) sacc += m.tm[tj * 9u + d * 3u + bj] * row[sj + d];
+            } else {
+              sacc = row[j];
+            }
+            zw[r] = sacc;
+          }
+          double bcol[Q0];
 #pragma unroll
-      for (int a = 0; a < Q0; ++a) {
-        double s = 0.0;
+          for (int a = 0; a < Q0; ++a) {
+            double sacc = 0.0;
 #pragma unroll
-        for (int r = 0; r < Q0; ++r)
-          if (r >= a) s += T0[r][a] * zw[r];
+            for (int r = 0; r < Q0; ++r)
+              if (r >= a) sacc += T0[r][a] * zw[r];
 #pragma unroll
-        for (int k = 0; k < Q0; ++k)
-          if (k < a) s -= Lc[a][k] * bcol[k];
-        bcol[a] = s / Lc[a][a];
-        m.B[(size_t)a * W + j] = bcol[a];
-      }
-    }
-    lmg_sync();
-    // S -= B'B on the lower-triangular pairs of the touched columns (the list is ascending)
-    for (uint32_t e1 = 0; e1 < cnt; ++e1) {
-      const uint32_t i = nz[1u + e1];
-      for (uint32_t e2 = lane; e2 <= e1; e2 += GW) {
-        const uint32_t j = nz[1u + e2];
-        double s = m.S[(size_t)i * W + j];
-#pragma unroll
-        for (int a = 0; a < Q0; ++a) s -= m.B[(size_t)a * W + i] * m.B[(size_t)a * W + j];
-        m.S[(size_t)i * W + j] = s;
+            for (int k = 0; k < Q0; ++k)
+              if (k < a) sacc -= Lc[a][k] * bcol[k];
+            bcol[a] = sacc / Lc[a][a];
+            m.B[((size_t)c * Q0 + a) * W + j] = bcol[a];
+          }
+        }
       }
     }
-    lmg_sync();
   }
+  ok = __ballot(!ok) == 0ull;
+  lmg_sync();
+  for (uint32_t c = 0; c < L0; ++c) logdet += m.ld[c];  // level order, as the oracle sums
+  {
+    const uint32_t KT = L0 * Q0;
+    for (uint32_t i = 0; i < W; ++i) {
+      // a nested child column only meets its own parent's rows of B
+      uint32_t pi = 0xffffffffu;
+      if (i < R) {
+        uint32_t ti = 1;
+        while (ti + 1u < prm.lmg_n_terms && i >= prm.lmg_roff[ti + 1u]) ++ti;
+        if (prm.lmg_relation[ti] == 1u) pi = ((i - prm.lmg_roff[ti]) / prm.lmg_q[ti]) / prm.lmg_count[ti];
+      }
+      for (uint32_t j = lane; j <= i; j += GW) {
+        uint32_t pj = 0xffffffffu;
+        if (j < R) {
+          uint32_t tj = 1;
+          while (tj + 1u < prm.lmg_n_terms && j >= prm.lmg_roff[tj + 1u]) ++tj;
+          if (prm.lmg_relation[tj] == 1u) pj = ((j - prm.lmg_roff[tj]) / prm.lmg_q[tj]) / prm.lmg_count[tj];
+        }
+        uint32_t klo = 0, khi = KT;
+        if (pi != 0xffffffffu) { klo = pi * Q0; khi = klo + Q0; }
+        if (pj != 0xffffffffu) {
+          if (pi != 0xffffffffu && pi != pj) khi = klo;  // children of different parents never share a row
+          else { klo = pj * Q0; khi = klo + Q0; }
+        }
+        double sacc = m.S[(size_t)i * W + j];
+        for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
+        m.S[(size_t)i * W + j] = sacc;
+      }
+    }
+  }
+  lmg_sync();
   // ---- left-looking Cholesky over [rest | X], y is the last row ----
   const uint32_t M = R + p;
   for (uint32_t j = 0; j < M; ++j) {
@@ -229,7 +265,8 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds& m, c
     const double d = m.misc[1];
     ok = ok && (d > 0.0) && (d < inf);
     const double ljj = __builtin_sqrt(d);
-    logdet += 2.0 * log(ljj);
+    pd *= d;
+    if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; }
     cntr = 0;
     for (uint32_t i = j + lane; i < W; i += GW) {
       m.S[(size_t)i * W + j] = i == j ? ljj : vv[cntr] / ljj;
@@ -237,6 +274,7 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds& m, c
     }
     lmg_sync();
   }
+  logdet += log(pd);
   double pwrss = m.S[(size_t)M * W + M];
   for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[(size_t)M * W + k] * m.S[(size_t)M * W + k];
   const double dfr = n_rows - (double)p;
@@ -275,7 +313,7 @@ __device__ __forceinline__ bool lmg_is_diag(const SimParams& prm, uint32_t k) {
   return false;
 }
 
-__device__ __forceinline__ void lmg_clamp(const SimParams& prm, double* x, uint32_t lane) {
+__device__ __forceinline__ void lmg_clamp(const SimParams& prm, ldd* x, uint32_t lane) {
   const uint32_t d = prm.lmg_n_theta;
   if (lane < d) {
     double v = x[lane];
@@ -287,7 +325,7 @@ __device__ __forceinline__ void lmg_clamp(const SimParams& prm, double* x, uint3
 }
 
 template <int Q0>
-__device__ __forceinline__ double lmg_f(const SimParams& prm, const LmgLds& m, double* x, uint32_t lane, double n_rows,
+__device__ __forceinline__ double lmg_f(const SimParams& prm, const LmgLds& m, ldd* x, uint32_t lane, double n_rows,
                                         uint32_t& n_eval) {
   lmg_clamp(prm, x, lane);
   ++n_eval;
@@ -296,19 +334,19 @@ __device__ __forceinline__ double lmg_f(const SimParams& prm, const LmgLds& m, d
 
 // one Nelder-Mead run from x0 (simplex row 0) with initial edge `step`; the best point ends in row 0
 template <int Q0>
-__device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLds& m, double step, double ftol, double xtol,
+__device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLds m, double step, double ftol, double xtol,
                                                uint32_t lane, double n_rows, uint32_t& n_eval) {
   const uint32_t d = prm.lmg_n_theta;
-  double* sx = m.simplex;            // (d + 4) rows of LMG_MAX_THETA: vertices 0..d, then centroid, xr, xe
-  double* fv = m.fv;
-  double* cen = sx + (size_t)(d + 1u) * LMG_MAX_THETA;
-  double* xr = cen + LMG_MAX_THETA;
-  double* xe = xr + LMG_MAX_THETA;
+  ldd* sx = m.simplex;            // (d + 4) rows of LMG_MAX_THETA: vertices 0..d, then centroid, xr, xe
+  ldd* fv = m.fv;
+  ldd* cen = sx + (size_t)(d + 1u) * LMG_MAX_THETA;
+  ldd* xr = cen + LMG_MAX_THETA;
+  ldd* xe = xr + LMG_MAX_THETA;
   const double inf = __builtin_inf();
   double f0 = lmg_f<Q0>(prm, m, sx, lane, n_rows, n_eval);
   if (lane == 0u) fv[0] = f0;
   for (uint32_t i = 0; i < d; ++i) {
-    double* v = sx + (size_t)(i + 1u) * LMG_MAX_THETA;
+    ldd* v = sx + (size_t)(i + 1u) * LMG_MAX_THETA;
     if (lane < d) v[lane] = sx[lane] + (lane == i ? ((lmg_is_diag(prm, i) || sx[i] >= 0.0) ? step : -step) : 0.0);
     lmg_sync();
     const double fi = lmg_f<Q0>(prm, m, v, lane, n_rows, n_eval);
@@ -343,7 +381,7 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
     }
     lmg_sync();
     const double fr = lmg_f<Q0>(prm, m, xr, lane, n_rows, n_eval);
-    double* worst = sx + (size_t)hi * LMG_MAX_THETA;
+    ldd* worst = sx + (size_t)hi * LMG_MAX_THETA;
     if (fr < flo) {
       if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
       lmg_sync();
@@ -364,7 +402,7 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
       } else {
         for (uint32_t i = 0; i <= d; ++i) {
           if (i == lo) continue;
-          double* v = sx + (size_t)i * LMG_MAX_THETA;
+          ldd* v = sx + (size_t)i * LMG_MAX_THETA;
           if (lane < d) v[lane] = sx[(size_t)lo * LMG_MAX_THETA + lane] + 0.5 * (v[lane] - sx[(size_t)lo * LMG_MAX_THETA + lane]);
           lmg_sync();
           const double fi = lmg_f<Q0>(prm, m, v, lane, n_rows, n_eval);
@@ -391,9 +429,9 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
 // LDS bytes of one replicate
 size_t lmg_lds_bytes(const SimParams& prm) {
   const size_t W = prm.lmg_W, L0 = prm.lmg_levels[0], q0 = prm.lmg_q[0], d = prm.lmg_n_theta;
-  size_t dbl = L0 * q0 * q0 + L0 * q0 * W + 2 * W * W + q0 * W + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8) +
+  size_t dbl = L0 * q0 * q0 + 2 * L0 * q0 * W + L0 + 2 * W * W + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8) +
                LMG_MAX_NZ + LMG_MAX_THETA;
-  size_t u32 = L0 * (W + 1) + LMG_MAX_NZ;
+  size_t u32 = LMG_MAX_NZ;
   const size_t n_pad = ((size_t)prm.max_n + 3u) & ~(size_t)3u;
   size_t nlev = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) nlev += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
@@ -414,12 +452,13 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
   const uint32_t W = prm.lmg_W, R = prm.lmg_R, L0 = prm.lmg_levels[0], d = prm.lmg_n_theta, nterms = prm.lmg_n_terms;
   LmgLds m;
   {
-    double* q = lds_d;
+    ldd* q = (ldd*)lds_d;
     m.gzz = q; q += (size_t)L0 * Q0 * Q0;
     m.gzw = q; q += (size_t)L0 * Q0 * W;
     m.gww = q; q += (size_t)W * W;
     m.S = q; q += (size_t)W * W;
-    m.B = q; q += (size_t)Q0 * W;
+    m.B = q; q += (size_t)L0 * Q0 * W;
+    m.ld = q; q += L0;
     m.simplex = q; q += (size_t)(d + 4u) * LMG_MAX_THETA;
     m.fv = q; q += d + 1u;
     m.tm = q; q += 27;
@@ -427,17 +466,15 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
     m.tail = q; q += 8 + 64 + 64 + 64 + 8 + 8;  // beta | L | U | Lc | cj | tsq
     m.rval = q; q += LMG_MAX_NZ;
     m.carry = q; q += LMG_MAX_THETA;
-    uint32_t* u = (uint32_t*)q;
-    m.nzl = u; u += (size_t)L0 * (W + 1u);
+    ldu* u = (ldu*)q;
     m.ridx = u; u += LMG_MAX_NZ;
-    if (((uintptr_t)u) & 7u) ++u;
-    float* f = (float*)u;
+    ldf* f = (ldf*)u;
     m.design = f; f += (size_t)P * n_pad;
     m.u0 = f; f += L0;
     m.us = f; f += (size_t)L0 * LMG_MAX_SLOPES;
     m.ux = f;
     for (uint32_t t = 1; t < nterms; ++t) f += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
-    m.st = f + lane;
+    m.st = (float*)f + lane;
   }
   // ---- 1. random effects on the sequential stream (data_gen.rs:146-284), Normal shape ----
   for (uint32_t c = lane; c < L0; c += GW) {
@@ -463,7 +500,7 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
     }
   }
   {
-    float* ux = m.ux;
+    ldf* ux = m.ux;
     for (uint32_t t = 1; t < nterms; ++t) {
       const uint32_t q = prm.lmg_q[t], nl = prm.lmg_levels[t];
       for (uint32_t c = lane; c < nl; c += GW) {
@@ -503,7 +540,7 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
         // latent-scale random effect in the reference's order: primary intercept, extras (intercept, slopes), primary slopes
         const uint32_t cid = lmg_level_of_row(prm, 0u, rr);
         double u_re = (double)m.u0[cid];
-        const float* ux = m.ux;
+        const ldf* ux = m.ux;
         for (uint32_t t = 1; t < nterms; ++t) {
           const uint32_t q = prm.lmg_q[t], lvl = lmg_level_of_row(prm, t, rr);
           u_re += (double)ux[(size_t)lvl * q];
@@ -568,40 +605,21 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
       for (uint32_t pr = lane; pr < (uint32_t)Q0 * nz; pr += GW) {
         const uint32_t a = pr / nz, b = pr % nz;
         const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * n_pad + i];
-        double* cell = m.gzw + ((size_t)c * Q0 + a) * W + m.ridx[b];
+        ldd* cell = m.gzw + ((size_t)c * Q0 + a) * W + m.ridx[b];
         *cell = __builtin_fma(za, m.rval[b], *cell);
       }
       if (lane < (uint32_t)(Q0 * Q0)) {
         const uint32_t a = lane / Q0, b = lane % Q0;
         const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * n_pad + i];
         const double zb = b == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][b - 1u] - 1u) * n_pad + i];
-        double* cell = m.gzz + (size_t)c * Q0 * Q0 + lane;
+        ldd* cell = m.gzz + (size_t)c * Q0 * Q0 + lane;
         *cell = __builtin_fma(za, zb, *cell);
       }
       lmg_sync();
     }
     prev_n = n;
-    // columns each primary level touches (ascending), from the strips themselves
-    for (uint32_t c = 0; c < L0; ++c) {
-      uint32_t* lst = m.nzl + (size_t)c * (W + 1u);
-      uint32_t cnt = 0;
-      for (uint32_t j0 = 0; j0 < W; j0 += GW) {
-        const uint32_t j = j0 + lane;
-        bool hit = false;
-        if (j < W) {
-#pragma unroll
-          for (int a = 0; a < Q0; ++a) hit = hit || m.gzw[((size_t)c * Q0 + a) * W + j] != 0.0;
-        }
-        const uint64_t bal = __ballot(hit);
-        if (hit) lst[1u + cnt + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = j;
-        cnt += (uint32_t)__popcll(bal);
-      }
-      if (lane == 0u) lst[0] = cnt;
-    }
-    lmg_sync();
-
     // ---- minimise: truth start / carried theta-hat / blind start (batch.rs:1316-1332) ----
-    double* x0 = m.simplex;
+    ldd* x0 = m.simplex;
     if (lane < d) {
       double v;
       if (has_prev) v = m.carry[lane];  // theta-hat of the last converged grid point
@@ -654,11 +672,11 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
     // ---- Wald z^2, joint Wald chi2, decisions: scalar work of one lane ----
     if (lane == 0u) {
       const uint32_t p = (uint32_t)P;
-      const double* beta = m.tail;
-      const double* Lx = m.tail + 8;
-      double* U = m.tail + 8 + 64;
-      double* Lc = U + 64;
-      double* cj = Lc + 64;
+      const ldd* beta = m.tail;
+      const ldd* Lx = m.tail + 8;
+      ldd* U = m.tail + 8 + 64;
+      ldd* Lc = U + 64;
+      ldd* cj = Lc + 64;
       const double sigma_sq = m.misc[0];
       const double* crow = prm.crit + (size_t)g * prm.crit_stride;
       double tsq[MAX_T_WAVE];

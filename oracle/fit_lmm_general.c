@@ -151,12 +151,17 @@ static void gen_evaluate(gen_model* m, const double* theta, gen_eval* e) {
   for (uint32_t j = 0; j < W; ++j) gen_lambda_t_cols(m, theta, S + j, W);          /* columns: act on the row index */
   for (uint32_t i = 0; i < W; ++i) gen_lambda_t_cols(m, theta, S + (size_t)i * W, 1); /* rows: act on the column index */
   for (uint32_t r = 0; r < R; ++r) S[(size_t)r * W + r] += 1.0;
-  double logdet = 0.0, T0[3][3];
+  /* log-determinant: one log() per primary level (of the product of its squared pivots, each >= 1), summed in
+   * level order; the dense columns multiply their squared pivots up four at a time -- the grouping the device
+   * kernel uses (it would otherwise spend most of an evaluation in log()) */
+  double logdet = 0.0, pd = 1.0, T0[3][3];
+  uint32_t npd = 0;
+#define GEN_PIVOT(dv) do { pd *= (dv); if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; } } while (0)
   gen_template(m, 0, theta, T0);
   for (uint32_t c = 0; c < m->L0; ++c) {
     /* A = T0' Gzz T0 + I, lower Cholesky in place */
     const double* G = m->gzz + (size_t)c * q0 * q0;
-    double A[3][3], Lc[3][3];
+    double A[3][3], Lc[3][3], pdc = 1.0;
     for (uint32_t a = 0; a < q0; ++a)
       for (uint32_t b = 0; b < q0; ++b) {
         double s = 0.0;
@@ -169,13 +174,14 @@ static void gen_evaluate(gen_model* m, const double* theta, gen_eval* e) {
       for (uint32_t k = 0; k < j; ++k) d -= Lc[j][k] * Lc[j][k];
       if (!(d > 0.0)) return;
       Lc[j][j] = sqrt(d);
-      logdet += 2.0 * log(Lc[j][j]);
+      pdc *= d;
       for (uint32_t i = j + 1; i < q0; ++i) {
         double v = A[i][j];
         for (uint32_t k = 0; k < j; ++k) v -= Lc[i][k] * Lc[j][k];
         Lc[i][j] = v / Lc[j][j];
       }
     }
+    logdet += log(pdc);
     /* B = Lc^-1 T0' [Gzw Lambda_r | Gzx | Gzy]  (q0 x W);  S -= B'B */
     double* zw = m->zw;
     memcpy(zw, m->gzw + (size_t)c * q0 * W, sizeof(double) * q0 * W);
@@ -212,13 +218,15 @@ static void gen_evaluate(gen_model* m, const double* theta, gen_eval* e) {
     if (!(d > 0.0) || !isfinite(d)) return;
     double ljj = sqrt(d);
     S[(size_t)j * W + j] = ljj;
-    logdet += 2.0 * log(ljj);   /* log|L|^2 over the rest block and log|RX|^2 over the X block */
+    GEN_PIVOT(d);   /* log|L|^2 over the rest block and log|RX|^2 over the X block */
     for (uint32_t i = j + 1; i < W; ++i) {
       double v = S[(size_t)i * W + j];
       for (uint32_t k = 0; k < j; ++k) v -= S[(size_t)i * W + k] * S[(size_t)j * W + k];
       S[(size_t)i * W + j] = v / ljj;
     }
   }
+  logdet += log(pd);
+#undef GEN_PIVOT
   double pwrss = S[(size_t)M * W + M];
   for (uint32_t k = 0; k < M; ++k) pwrss -= S[(size_t)M * W + k] * S[(size_t)M * W + k];
   const double dfr = (double)m->n - (double)p;
