@@ -170,4 +170,18 @@ def preset(name: str) -> S.ScenarioPerturbations:
     raise KeyError(name)
 
 
+def spec_lmm_slope() -> S.SimulationSpec:
+    """Reference case lmm_slope_a (validation/formulas.R:461-469): y ~ x1 + (1 + x1 | g), 24 clusters x 20."""
+    spec = load_case("lmm_slope_a")[0]
+    spec.scenario.truth_start = True
+    return spec
+
+
+def spec_lmm_crossed() -> S.SimulationSpec:
+    """Reference case lmm_crossed_a (formulas.R:385-395): y ~ x1 + x2 + (1 | subj) + (1 | item), 20 x 12 levels."""
+    spec = load_case("lmm_crossed_a")[0]
+    spec.scenario.truth_start = True
+    return spec
+
+
 C5_GRID = list(range(50, 1001, 50))  # BASELINE C5: N = 50, 100, ..., 1000

@@ -337,3 +337,48 @@ def test_find_power_on_device_glm_and_lmm_extras(engine, oracle):
     ref = _engine.find_power(_pack(c), 125, 1500, 3, _runner=_oracle_runner(oracle))["scenarios"]["optimistic"]
     assert dev["power_uncorrected"] == ref["power_uncorrected"] and dev["sample_sizes"] == [120]
     assert dev["estimator_extras"]["joint_uncorrected_rate"] == ref["estimator_extras"]["joint_uncorrected_rate"]
+
+
+# ---------------------------------------------------------------------------------------------
+# contracts with random slopes / extra groupings reach the general mixed-model solver
+# ---------------------------------------------------------------------------------------------
+def _mixed_contract():
+    c = _contract()
+    c["generation"]["cluster"] = {
+        "sizing": {"FixedClusters": {"n_clusters": 12}}, "tau_squared": 0.25,
+        "slopes": [{"column": 0, "variance": 0.10, "corr_with_intercept": 0.3, "corr_with": []}],
+        "extra_groupings": [{"relation": {"Crossed": {"n_clusters": 4}}, "tau_squared": 0.16, "slopes": []}]}
+    c["estimator"] = "mle"
+    c["outcome"]["coefficients"] = [0.0, 0.30, 0.20]
+    c["test"]["targets"] = [{"kind": "marginal", "term": 1}, {"kind": "marginal", "term": 2}]
+    return c
+
+
+def test_mixed_contract_lowers_slopes_and_groupings():
+    s = K.contract_to_simulation_spec(_mixed_contract())
+    assert s.estimator == S.EstimatorSpec.Mle and s.cluster.sizing == ("FixedClusters", 12)
+    assert s.cluster_slope_design_cols == [1] and s.extra_slope_cols == [[]]
+    assert K.cluster_atom(_mixed_contract()) == 48                      # generation.rs:291-295: sizing atom x block levels
+    low = s.to_c()
+    assert low.c.cluster.slopes.n_slopes == 1 and low.c.cluster.slopes.design_cols[0] == 1
+    assert list(low.c.cluster.slopes.re_corr)[:4] == [1.0, 0.3, 0.3, 1.0]
+    assert low.c.cluster.n_extra_groupings == 1 and low.c.cluster.extra[0].count == 4
+
+
+def test_find_power_mixed_contract_on_the_oracle(oracle):
+    r = _engine.find_power(_pack(_mixed_contract()), 240, 60, 2137, None, _runner=_oracle_runner(oracle))
+    sc = r["scenarios"]["optimistic"] if "scenarios" in r else r
+    assert sc["n_sims"] == 60 and len(sc["power_uncorrected"][0]) == 2
+    assert 0.5 < sc["power_uncorrected"][0][0] <= 1.0 and sc["convergence_rate"][0] > 0.9
+
+
+@pytest.mark.gpu
+def test_find_power_mixed_contract_device_equals_oracle(engine, oracle):
+    blob = _pack(_mixed_contract())
+    dev = _engine.find_power(blob, 240, 200, 2137, None)
+    ora = _engine.find_power(blob, 240, 200, 2137, None, _runner=_oracle_runner(oracle))
+    d = dev["scenarios"]["optimistic"] if "scenarios" in dev else dev
+    o = ora["scenarios"]["optimistic"] if "scenarios" in ora else ora
+    for t in range(2):
+        assert abs(d["power_uncorrected"][0][t] - o["power_uncorrected"][0][t]) <= 1.0 / 200 + 1e-12
+    assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 1.0 / 200 + 1e-12
