@@ -247,7 +247,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (spec->cluster.present && spec->estimator == MCP_EST_GLM) return unsupported("clustered GLM (GLMM: Laplace / AGQ fits)");
   if (lmm_general) {
     if (spec->estimator != MCP_EST_MLE) return unsupported("random slopes / extra groupings outside the Mle estimator");
-    if (spec->n_factors) return unsupported("random slopes / extra groupings together with factor predictors");
     if (spec->n_fit_columns) return unsupported("random slopes / extra groupings together with a test_formula column subset");
     if (spec->n_between_var_indices) return unsupported("random slopes / extra groupings together with cluster-level predictors");
     if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");
@@ -703,6 +702,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   // intercept of a row's cluster is re-drawn per row on the reduced-design kernel
   const bool ols_cluster = spec->cluster.present && spec->estimator == MCP_EST_OLS;
   prm.red_active = (npc > 0 || test_reduces || any_excl_possible || wide || ols_cluster) ? 1u : 0u;
+  if (prm.lmg_active && prm.red_active)
+    return unsupported("random slopes / extra groupings together with a factor that can be excluded per replicate (sparse levels or sampled proportions)");
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))
     return unsupported("intercept-free reduced fit under Glm / Mle");
   for (uint32_t k = 0; k <= (uint32_t)MAX_T; ++k)

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
 
   // ---- 2. the replicate's rows (lane = row) ----
   RowCtx<P> cx;
-  row_ctx_init<P, false>(prm, cx);
+  row_ctx_init<P, true>(prm, cx);  // factor columns cost nothing here: generation is a sliver of this kernel
   for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += GW) {
     stage_group<P, GW, 0, false>(prm, k0, k1, ctr, m.st, 0u);
 #pragma unroll
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
       const uint32_t rr = 4u * ctr + r;
       if (rr < max_n) {
         float x[P], y;
-        const float e = build_x<P, false, GW, false>(prm, cx, k0, k1, m.st, r, rr, x, nullptr);
+        const float e = build_x<P, true, GW, false>(prm, cx, k0, k1, m.st, r, rr, x, nullptr);
         // latent-scale random effect in the reference's order: primary intercept, extras (intercept, slopes), primary slopes
         const uint32_t cid = lmg_level_of_row(prm, 0u, rr);
         double u_re = (double)m.u0[cid];

@@ -47,3 +47,26 @@ def test_general_lmm_counters_only_and_shards(engine):
     assert np.array_equal(left.counters + right.counters, whole.counters)
     again = engine.run_batch(spec, [480], 64, BASE_SEED)
     assert np.array_equal(again.uncorrected, whole.uncorrected) and np.array_equal(again.pinned_components, whole.pinned_components)
+
+
+def test_general_lmm_with_a_fixed_allocation_factor(engine, oracle):
+    """y ~ x1 + g + (1 + x1 | grp): a factor whose levels can never be sparse at these N keeps the full model in
+    every replicate, so the general solver takes it; a factor that CAN be excluded per replicate is refused."""
+    from mcpower_amd import spec as S
+    spec, _, a, low = load_case("lmm_slope_a")
+    spec.n_factor_dummies, spec.factor_n_levels, spec.factor_proportions = 2, [3], [0.5, 0.3, 0.2]
+    spec.factor_sampled = [None]
+    spec.effect_sizes = [0.0, 0.30, 0.40, 0.25]
+    spec.target_indices = [1, 2, 3]
+    spec.factor_min_level_count = 5
+    spec.scenario.truth_start = True
+    dev = engine.run_batch(spec, [240, 480], 40, BASE_SEED)
+    ora = oracle.run_batch(spec, [240, 480], 40, BASE_SEED, n_threads=8)
+    assert np.array_equal(dev.uncorrected, ora.uncorrected) and np.array_equal(dev.converged, ora.converged)
+    assert np.array_equal(dev.corrected, ora.corrected) and np.array_equal(dev.joint_unc, ora.joint_unc)
+    assert dev.factor_excluded is None or not dev.factor_excluded.any()
+    spec.scenario.sampled_factor_proportions = True      # counts per replicate: exclusion possible -> reduced rounds
+    spec.scenario.heterogeneity = 0.0
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, [240, 480], 8, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported
