@@ -114,6 +114,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend="gloo")
+        # bring the communicator up before anything is timed (the first RCCL collective builds the rings over xGMI),
+        # whatever --warmup says
+        t_init = torch.zeros(1, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t_init)
+        dist.barrier()
 
     fac, n_obs, ops_per_fit, bytes_per_fit = WORKLOADS[args.workload]
     spec = getattr(helpers, fac)()

@@ -40,6 +40,7 @@ hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 size_t lmm_rec_fields(int P, uint32_t ncl_max);
 hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
+hipError_t launch_lmm_general_scen(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 size_t lmg_lds_bytes(const SimParams& prm);
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st);
@@ -284,10 +285,6 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
   const bool lmg = mle && prm.lmg_active;  // random slopes / extra groupings: the general mixed-model kernel
-  if (lmg && prm.scen_active) {
-    mcp_free_result(out);
-    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: random slopes / extra groupings on the general (scenario / upload) data path");
-  }
   if (lmg && mcp::lmg_lds_bytes(prm) > 158u * 1024u) {
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the random-effect structure does not fit one wave's LDS budget");
@@ -404,7 +401,8 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   uint32_t* d_scen_meta = nullptr;
   if (scen) {
     const uint32_t K = spec->n_non_factor;
-    if (spec->cluster.present) DEV_TRY(ar.get(S_SCEN_TAU, (size_t)chunk * sizeof(double), (void**)&d_scen_tau));
+    if (spec->cluster.present)  // realised tau^2 per replicate: the primary grouping, then each extra grouping
+      DEV_TRY(ar.get(S_SCEN_TAU, (size_t)chunk * (1u + spec->cluster.n_extra_groupings) * sizeof(double), (void**)&d_scen_tau));
     DEV_TRY(ar.get(S_SCEN_L, (size_t)(K * (K + 1) / 2 + 1) * chunk * sizeof(double), (void**)&d_scen_L));
     DEV_TRY(ar.get(S_SCEN_META, (size_t)chunk * sizeof(uint32_t), (void**)&d_scen_meta));
     if (low.need_beta_eff) DEV_TRY(ar.get(S_SCEN_BETA, (size_t)P * chunk * sizeof(double), (void**)&d_scen_beta));
@@ -500,7 +498,8 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (lmg) DEV_TRY(mcp::launch_lmm_general((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
+      if (lmg && scen) DEV_TRY(mcp::launch_lmm_general_scen((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
+      else if (lmg) DEV_TRY(mcp::launch_lmm_general((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));
       else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, scen, prm.glm_family == 0u, st));
       DEV_TRY(hipEventRecord(e1, st));

@@ -390,7 +390,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     }
     prm.n_seq_pre = prm.n_clusters_max * prm.re_draws_per_cluster;
     if (lmm_general) {
-      if (general) return unsupported("random slopes / extra groupings on the general (scenario) data path");
+      if (spec->upload_normal_rows || spec->n_bootstrap_frame_map)
+        return unsupported("random slopes / extra groupings together with uploaded data");
       const mcp_cluster& cl = spec->cluster;
       prm.lmg_active = 1;
       prm.lmg_n_terms = 1 + cl.n_extra_groupings;
@@ -415,6 +416,9 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
         for (uint32_t d = 0; d < sl.n_slopes; ++d) prm.lmg_cols[t][d] = sl.design_cols[d];
         const double tau_sq = t == 0 ? cl.tau_squared : cl.extra[t - 1].tau_squared;
         prm.lmg_tau[t] = std::sqrt(tau_sq > 0.0 ? tau_sq : 0.0);
+        prm.lmg_tau_sq[t] = tau_sq;
+        for (uint32_t d = 0; d < sl.n_slopes; ++d) prm.lmg_slope_sd[t][d] = std::sqrt(sl.variance[d] > 0.0 ? sl.variance[d] : 0.0);
+        for (uint32_t i = 0; i < q * q; ++i) prm.lmg_recorr[t][i] = sl.re_corr[i];
         // chol_lower of D = diag(tau) R diag(tau) (data_gen.rs:55-75): the slope draws and the truth start share it
         double tv[3] = {prm.lmg_tau[t], 0.0, 0.0}, dm[9] = {0}, l[9] = {0};
         for (uint32_t d = 0; d < sl.n_slopes; ++d) tv[d + 1] = std::sqrt(sl.variance[d] > 0.0 ? sl.variance[d] : 0.0);
@@ -444,17 +448,17 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       prm.lmg_R = roff;
       prm.lmg_W = roff + P + 1;
       // sequential-stream layout (data_gen.rs:146-284): primary intercepts, primary slopes, every extra grouping's
-      // intercepts, then every extra grouping's slopes; one word per Normal draw
+      // intercepts, then every extra grouping's slopes -- in units of one random-effect draw
+      // (re_draws_per_cluster words each: 1 for Normal, df or 1 + df for the scenario's other shapes)
       prm.lmg_seq[0] = 0;
       seq = prm.lmg_levels[0];
       prm.lmg_seq[1] = seq;
       seq += prm.lmg_levels[0] * (prm.lmg_q[0] - 1);
       for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) { prm.lmg_seq[2 * t] = seq; seq += prm.lmg_levels[t]; }
       for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) { prm.lmg_seq[2 * t + 1] = seq; seq += prm.lmg_levels[t] * (prm.lmg_q[t] - 1); }
-      prm.n_seq_pre = seq;
+      prm.n_seq_pre = seq * prm.re_draws_per_cluster;
       if (prm.lmg_n_theta > (uint32_t)LMG_MAX_THETA) return unsupported("random-effect structures with more than 12 covariance parameters");
       if (prm.lmg_W > 128u) return unsupported("extra groupings with more than ~120 random-effect columns in total");
-      if (prm.lme_re_dist != 0u) return unsupported("non-normal random effects together with random slopes / extra groupings");
     }
   }
   prm.truth_start = spec->scenario.truth_start ? 1u : 0u;

@@ -1,0 +1,787 @@
+// lmm_general_impl.hpp -- gfx950 kernel of the GENERAL linear mixed model (REML), included by the two translation
+// units that instantiate it (lmm_general_kernels.hip: plain data path; lmm_general_scen_kernels.hip: general path): random slopes on the
+// primary grouping, crossed / nested extra groupings, slopes on those.
+//
+// Reference: crates/engine-core/src/batch.rs:1214-1560 (Mle arm), data_gen.rs:146-284 (draw order of the random
+// effects on the sequential stream: primary intercepts, primary slopes, all extra intercepts, all extra slopes),
+// :812-842 (latent-scale contribution), engine-contract/src/generation.rs:297-427 (row -> level maps),
+// mixed_workspace.rs:57-198 (model terms, theta layout, truth start).  The solver behind `fit_on` (glmm 0.1.2 +
+// bobyqa 0.1.1) is out of tree; this is lme4's penalised least squares (Bates et al. 2015, eqs. 39-41) minimised
+// by a bounded Nelder-Mead simplex -- the same algorithm, constants and operation order as oracle/fit_lmm_general.c.
+//
+// ONE WAVEFRONT PER REPLICATE, everything resident in LDS:
+//   1. the random effects are drawn (lane = level), the n x p design and the outcome are generated (lane = row);
+//   2. rows are folded into the theta-free sufficient statistics in row order (lanes = the <= 15 x 15 products of
+//      one sparse row, so the summation order -- hence every bit -- is fixed):  per primary level c the q0 x q0
+//      block Z0'Z0 and the q0 x W strip Z0'[Zr | X | y], plus the W x W Gram matrix of [Zr | X | y]
+//      (Zr = columns of the extra groupings, W = R + p + 1);
+//   3. per grid N the criterion is minimised.  One evaluation = block Cholesky in the order [primary blocks | rest |
+//      X | y]: the primary blocks are eliminated one level at a time (only the columns that level actually touches:
+//      a nested child touches one parent, so its strip is short), then a left-looking dense Cholesky (lane = row)
+//      runs over the rest and X columns with y riding along as the right-hand side.
+// Wave-uniform control flow throughout: all 64 lanes carry the same simplex and take the same branches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mcp_device.hpp"
+#include "mcp_params.hpp"
+#include "mcp_scenario.hpp"
+#include "mcp_rows.hpp"
+#include "mcp_decide.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mcp {
+namespace {
+
+constexpr int GW = 64;
+constexpr double LMG_THETA_ZERO = 1e-6;
+constexpr double LMG_THETA_MAX = 32.0;
+constexpr uint32_t LMG_MAX_EVAL = 6000;
+constexpr double LMG_NEAR_ZERO = 1e-30;
+constexpr int LMG_MAX_NZ = 2 * LMG_MAX_SLOPES + 2 + MAX_P_WAVE + 1;  // sparse row of [Zr | X | y]
+
+__device__ __forceinline__ void lmg_sync() { __syncthreads(); }  // one wave per block
+
+// extra_level_of_row (generation.rs:402-427)
+__device__ __forceinline__ uint32_t lmg_level_of_row(const SimParams& prm, uint32_t t, uint32_t i) {
+  const uint32_t v = prm.cluster_v;
+  if (t == 0u) return prm.cluster_fixed_clusters ? i % v : i / v;
+  const uint32_t bl = prm.lmg_count[t];
+  if (prm.cluster_fixed_clusters) {
+    uint32_t stride = v;
+    for (uint32_t h = 1; h < t; ++h) stride *= prm.lmg_count[h];
+    const uint32_t within = (i / stride) % bl;
+    return prm.lmg_relation[t] == 0u ? within : (i % v) * bl + within;
+  }
+  return (i / v) * bl + (i % v) % bl;
+}
+
+// LDS-qualified pointers: 32-bit, ds_* instructions, and provably disjoint from private memory -- with generic
+// pointers every access went through flat instructions and the struct of pointers was re-read from scratch
+// after each store (measured: 10x slower)
+typedef __attribute__((address_space(3))) double ldd;
+typedef __attribute__((address_space(3))) float ldf;
+typedef __attribute__((address_space(3))) uint32_t ldu;
+
+// LDS map of one replicate (doubles first, then floats)
+struct LmgLds {
+  ldd *gzz, *gzw, *gww, *S, *B, *ld, *simplex, *fv, *tm, *misc, *tail, *carry;
+  ldu* ridx;
+  ldd* rval;
+  ldf *design, *u0, *us, *ux;
+  float* st;  // staging of the row generator (generic: shared with mcp_rows.hpp)
+};
+
+// template entries T_t[r][c] of every term from theta (column-major vech per term, mixed_workspace.rs:189-196)
+__device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* th, ldd* tm, uint32_t lane) {
+  if (lane < 27u) {
+    const uint32_t t = lane / 9u, r = (lane % 9u) / 3u, c = lane % 3u;
+    double v = 0.0;
+    if (t < prm.lmg_n_terms && r < prm.lmg_q[t] && c <= r) {
+      const uint32_t q = prm.lmg_q[t];
+      // column-major lower vech: entries of columns 0..c-1 come first
+      uint32_t k = prm.lmg_theta_off[t];
+      for (uint32_t cc = 0; cc < c; ++cc) k += q - cc;
+      v = th[k + (r - c)];
+    }
+    tm[lane] = v;
+  }
+}
+
+// one evaluation of the profiled REML criterion at theta `th` (LDS, n_theta doubles).  Returns the deviance (inf
+// when a pivot fails); leaves sigma^2 in misc[0], beta in tail[0..p), the lower factor of RX'RX in tail[8 + a*8 + b].
+template <int Q0>
+__device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows) {
+  const uint32_t W = prm.lmg_W, R = prm.lmg_R, p = prm.P, L0 = prm.lmg_levels[0];
+  const double inf = __builtin_inf();
+  lmg_templates(prm, th, m.tm, lane);
+  lmg_sync();
+  // ---- S (lower triangle) = Lambda~' Gww Lambda~ (+ I on the rest block), Lambda~ = diag(Lambda_rest, I) ----
+  for (uint32_t i = 0; i < W; ++i) {
+    // block of row index i
+    uint32_t ti = 0, bi = 0, qi = 1, si = i;
+    if (i < R) {
+      ti = 1;
+      while (ti + 1u < prm.lmg_n_terms && i >= prm.lmg_roff[ti + 1u]) ++ti;
+      qi = prm.lmg_q[ti];
+      const uint32_t rel = i - prm.lmg_roff[ti];
+      bi = rel % qi;
+      si = i - bi;
+    }
+    for (uint32_t j = lane; j <= i; j += GW) {
+      uint32_t tj = 0, bj = 0, qj = 1, sj = j;
+      if (j < R) {
+        tj = 1;
+        while (tj + 1u < prm.lmg_n_terms && j >= prm.lmg_roff[tj + 1u]) ++tj;
+        qj = prm.lmg_q[tj];
+        const uint32_t rel = j - prm.lmg_roff[tj];
+        bj = rel % qj;
+        sj = j - bj;
+      }
+      // the oracle applies Lambda' along the row index first, then along the column index: keep that association
+      double acc = 0.0;
+      for (uint32_t e = bj; e < qj; ++e) {
+        double inner = 0.0;
+        for (uint32_t d = bi; d < qi; ++d) {
+          const uint32_t a = si + d, b = sj + e;
+          const double g = a >= b ? m.gww[(size_t)a * W + b] : m.gww[(size_t)b * W + a];
+          inner = i < R ? inner + m.tm[ti * 9u + d * 3u + bi] * g : g;
+        }
+        acc = j < R ? acc + m.tm[tj * 9u + e * 3u + bj] * inner : inner;
+      }
+      if (i == j && i < R) acc += 1.0;
+      m.S[(size_t)i * W + j] = acc;
+    }
+  }
+  lmg_sync();
+  // ---- eliminate the primary blocks: lane = level ----
+  // Each lane factors its level's q0 x q0 block and forward-solves the level's strip B_c = Lc^-1 T0' [Gzw Lambda~]
+  // (q0 x W, zeros where the level has no rows) into LDS; then S -= sum_k B[k]' B[k] runs as a small matrix product
+  // with lanes over the (i, j) pairs and k = (level, a) ascending -- the oracle's summation order.
+  double logdet = 0.0, pd = 1.0;
+  uint32_t npd = 0;
+  bool ok = true;
+  double T0[Q0][Q0];
+#pragma unroll
+  for (int r = 0; r < Q0; ++r)
+#pragma unroll
+    for (int c = 0; c < Q0; ++c) T0[r][c] = m.tm[r * 3 + c];
+  for (uint32_t c = lane; c < L0; c += GW) {
+    const ldd* G = m.gzz + (size_t)c * Q0 * Q0;
+    double A[Q0][Q0], Lc[Q0][Q0], pdc = 1.0;
+#pragma unroll
+    for (int a = 0; a < Q0; ++a)
+#pragma unroll
+      for (int b = 0; b < Q0; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < Q0; ++r)
+#pragma unroll
+          for (int cc = 0; cc < Q0; ++cc)
+            if (r >= a && cc >= b) s += T0[r][a] * G[r * Q0 + cc] * T0[cc][b];
+        A[a][b] = s + (a == b ? 1.0 : 0.0);
+      }
+#pragma unroll
+    for (int j = 0; j < Q0; ++j) {
+      double d = A[j][j];
+#pragma unroll
+      for (int k = 0; k < Q0; ++k)
+        if (k < j) d -= Lc[j][k] * Lc[j][k];
+      ok = ok && (d > 0.0);
+      Lc[j][j] = __builtin_sqrt(d);
+      pdc *= d;
+#pragma unroll
+      for (int i = 0; i < Q0; ++i)
+        if (i > j) {
+          double v = A[i][j];
+#pragma unroll
+          for (int k = 0; k < Q0; ++k)
+            if (k < j) v -= Lc[i][k] * Lc[j][k];
+          Lc[i][j] = v / Lc[j][j];
+        }
+    }
+    m.ld[c] = log(pdc);
+    // columns this level can meet: every crossed column, its own nested children, X and y
+    for (uint32_t tj = 1; tj <= prm.lmg_n_terms; ++tj) {
+      const bool xy = tj == prm.lmg_n_terms;
+      const uint32_t qj = xy ? 1u : prm.lmg_q[tj];
+      uint32_t jlo, jhi;
+      if (xy) { jlo = R; jhi = W; }
+      else if (prm.lmg_relation[tj] == 1u) { jlo = prm.lmg_roff[tj] + c * prm.lmg_count[tj] * qj; jhi = jlo + prm.lmg_count[tj] * qj; }
+      else { jlo = prm.lmg_roff[tj]; jhi = jlo + prm.lmg_levels[tj] * qj; }
+      for (uint32_t sj = jlo; sj < jhi; sj += qj) {
+        for (uint32_t bj = 0; bj < qj; ++bj) {
+          const uint32_t j = sj + bj;
+          double zw[Q0];
+#pragma unroll
+          for (int r = 0; r < Q0; ++r) {
+            const ldd* row = m.gzw + ((size_t)c * Q0 + r) * W;
+            double sacc = 0.0;
+            if (!xy) {
+              for (uint32_t d = bj; d < qj; ++d) sacc += m.tm[tj * 9u + d * 3u + bj] * row[sj + d];
+            } else {
+              sacc = row[j];
+            }
+            zw[r] = sacc;
+          }
+          double bcol[Q0];
+#pragma unroll
+          for (int a = 0; a < Q0; ++a) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int r = 0; r < Q0; ++r)
+              if (r >= a) sacc += T0[r][a] * zw[r];
+#pragma unroll
+            for (int k = 0; k < Q0; ++k)
+              if (k < a) sacc -= Lc[a][k] * bcol[k];
+            bcol[a] = sacc / Lc[a][a];
+            m.B[((size_t)c * Q0 + a) * W + j] = bcol[a];
+          }
+        }
+      }
+    }
+  }
+  ok = __ballot(!ok) == 0ull;
+  lmg_sync();
+  for (uint32_t c = 0; c < L0; ++c) logdet += m.ld[c];  // level order, as the oracle sums
+  {
+    const uint32_t KT = L0 * Q0;
+    for (uint32_t i = 0; i < W; ++i) {
+      // a nested child column only meets its own parent's rows of B
+      uint32_t pi = 0xffffffffu;
+      if (i < R) {
+        uint32_t ti = 1;
+        while (ti + 1u < prm.lmg_n_terms && i >= prm.lmg_roff[ti + 1u]) ++ti;
+        if (prm.lmg_relation[ti] == 1u) pi = ((i - prm.lmg_roff[ti]) / prm.lmg_q[ti]) / prm.lmg_count[ti];
+      }
+      for (uint32_t j = lane; j <= i; j += GW) {
+        uint32_t pj = 0xffffffffu;
+        if (j < R) {
+          uint32_t tj = 1;
+          while (tj + 1u < prm.lmg_n_terms && j >= prm.lmg_roff[tj + 1u]) ++tj;
+          if (prm.lmg_relation[tj] == 1u) pj = ((j - prm.lmg_roff[tj]) / prm.lmg_q[tj]) / prm.lmg_count[tj];
+        }
+        uint32_t klo = 0, khi = KT;
+        if (pi != 0xffffffffu) { klo = pi * Q0; khi = klo + Q0; }
+        if (pj != 0xffffffffu) {
+          if (pi != 0xffffffffu && pi != pj) khi = klo;  // children of different parents never share a row
+          else { klo = pj * Q0; khi = klo + Q0; }
+        }
+        double sacc = m.S[(size_t)i * W + j];
+        for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
+        m.S[(size_t)i * W + j] = sacc;
+      }
+    }
+  }
+  lmg_sync();
+  // ---- left-looking Cholesky over [rest | X], y is the last row ----
+  const uint32_t M = R + p;
+  for (uint32_t j = 0; j < M; ++j) {
+    double vv[2] = {0.0, 0.0};
+    uint32_t cntr = 0;
+    for (uint32_t i = j + lane; i < W; i += GW) {
+      double v = m.S[(size_t)i * W + j];
+      for (uint32_t k = 0; k < j; ++k) v -= m.S[(size_t)i * W + k] * m.S[(size_t)j * W + k];
+      vv[cntr++] = v;
+      if (i == j) m.misc[1] = v;
+    }
+    lmg_sync();
+    const double d = m.misc[1];
+    ok = ok && (d > 0.0) && (d < inf);
+    const double ljj = __builtin_sqrt(d);
+    pd *= d;
+    if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; }
+    cntr = 0;
+    for (uint32_t i = j + lane; i < W; i += GW) {
+      m.S[(size_t)i * W + j] = i == j ? ljj : vv[cntr] / ljj;
+      ++cntr;
+    }
+    lmg_sync();
+  }
+  logdet += log(pd);
+  double pwrss = m.S[(size_t)M * W + M];
+  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[(size_t)M * W + k] * m.S[(size_t)M * W + k];
+  const double dfr = n_rows - (double)p;
+  double lmin = inf, lmax = 0.0;
+  for (uint32_t a = 0; a < p; ++a) {
+    const double v = __builtin_fabs(m.S[(size_t)(R + a) * W + R + a]);
+    lmin = v < lmin ? v : lmin;
+    lmax = v > lmax ? v : lmax;
+  }
+  ok = ok && (pwrss > 0.0) && (dfr > 0.0) && (lmin / lmax >= 1e-12);
+  if (!ok) return inf;
+  const double dev = logdet + dfr * (1.0 + log(2.0 * 3.14159265358979323846 * pwrss / dfr));
+  if (lane == 0u) {
+    m.misc[0] = pwrss / dfr;
+    for (uint32_t a = 0; a < p; ++a)
+      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[(size_t)(R + a) * W + R + b] : 0.0;
+    for (int a = (int)p - 1; a >= 0; --a) {
+      double v = m.S[(size_t)M * W + R + (uint32_t)a];
+      for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[8u + k * 8u + (uint32_t)a] * m.tail[k];
+      m.tail[a] = v / m.tail[8u + (uint32_t)a * 8u + (uint32_t)a];
+    }
+  }
+  lmg_sync();
+  return (dev < inf && dev > -inf) ? dev : inf;
+}
+
+__device__ __forceinline__ bool lmg_is_diag(const SimParams& prm, uint32_t k) {
+  for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) {
+    uint32_t o = prm.lmg_theta_off[t];
+    const uint32_t q = prm.lmg_q[t];
+    for (uint32_t c = 0; c < q; ++c) {
+      if (k == o) return true;
+      o += q - c;
+    }
+  }
+  return false;
+}
+
+__device__ __forceinline__ void lmg_clamp(const SimParams& prm, ldd* x, uint32_t lane) {
+  const uint32_t d = prm.lmg_n_theta;
+  if (lane < d) {
+    double v = x[lane];
+    if (lmg_is_diag(prm, lane)) v = v < 0.0 ? 0.0 : (v > LMG_THETA_MAX ? LMG_THETA_MAX : v);
+    else v = v < -LMG_THETA_MAX ? -LMG_THETA_MAX : (v > LMG_THETA_MAX ? LMG_THETA_MAX : v);
+    x[lane] = v;
+  }
+  lmg_sync();
+}
+
+template <int Q0>
+__device__ __forceinline__ double lmg_f(const SimParams& prm, const LmgLds& m, ldd* x, uint32_t lane, double n_rows,
+                                        uint32_t& n_eval) {
+  lmg_clamp(prm, x, lane);
+  ++n_eval;
+  return lmg_eval<Q0>(prm, m, x, lane, n_rows);
+}
+
+// one Nelder-Mead run from x0 (simplex row 0) with initial edge `step`; the best point ends in row 0
+template <int Q0>
+__device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLds m, double step, double ftol, double xtol,
+                                               uint32_t lane, double n_rows, uint32_t& n_eval) {
+  const uint32_t d = prm.lmg_n_theta;
+  ldd* sx = m.simplex;            // (d + 4) rows of LMG_MAX_THETA: vertices 0..d, then centroid, xr, xe
+  ldd* fv = m.fv;
+  ldd* cen = sx + (size_t)(d + 1u) * LMG_MAX_THETA;
+  ldd* xr = cen + LMG_MAX_THETA;
+  ldd* xe = xr + LMG_MAX_THETA;
+  const double inf = __builtin_inf();
+  double f0 = lmg_f<Q0>(prm, m, sx, lane, n_rows, n_eval);
+  if (lane == 0u) fv[0] = f0;
+  for (uint32_t i = 0; i < d; ++i) {
+    ldd* v = sx + (size_t)(i + 1u) * LMG_MAX_THETA;
+    if (lane < d) v[lane] = sx[lane] + (lane == i ? ((lmg_is_diag(prm, i) || sx[i] >= 0.0) ? step : -step) : 0.0);
+    lmg_sync();
+    const double fi = lmg_f<Q0>(prm, m, v, lane, n_rows, n_eval);
+    if (lane == 0u) fv[i + 1u] = fi;
+  }
+  lmg_sync();
+  while (n_eval < LMG_MAX_EVAL) {
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t i = 1; i <= d; ++i) {
+      if (fv[i] < fv[lo]) lo = i;
+      if (fv[i] > fv[hi]) hi = i;
+    }
+    uint32_t nh = lo;
+    for (uint32_t i = 0; i <= d; ++i)
+      if (i != hi && fv[i] > fv[nh]) nh = i;
+    double size = 0.0;
+    for (uint32_t i = 0; i <= d; ++i)
+      for (uint32_t k = 0; k < d; ++k) {
+        const double dd = __builtin_fabs(sx[(size_t)i * LMG_MAX_THETA + k] - sx[(size_t)lo * LMG_MAX_THETA + k]);
+        size = dd > size ? dd : size;
+      }
+    if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
+    const double flo = fv[lo], fhi = fv[hi], fnh = fv[nh];
+    lmg_sync();
+    if (lane < d) {
+      double s = 0.0;
+      for (uint32_t i = 0; i <= d; ++i)
+        if (i != hi) s += sx[(size_t)i * LMG_MAX_THETA + lane];
+      const double c = s / (double)d;
+      cen[lane] = c;
+      xr[lane] = c + (c - sx[(size_t)hi * LMG_MAX_THETA + lane]);
+    }
+    lmg_sync();
+    const double fr = lmg_f<Q0>(prm, m, xr, lane, n_rows, n_eval);
+    ldd* worst = sx + (size_t)hi * LMG_MAX_THETA;
+    if (fr < flo) {
+      if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
+      lmg_sync();
+      const double fe = lmg_f<Q0>(prm, m, xe, lane, n_rows, n_eval);
+      if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
+      if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
+    } else if (fr < fnh) {
+      if (lane < d) worst[lane] = xr[lane];
+      if (lane == 0u) fv[hi] = fr;
+    } else {
+      const bool outside = fr < fhi;
+      if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
+      lmg_sync();
+      const double fc = lmg_f<Q0>(prm, m, xe, lane, n_rows, n_eval);
+      if (fc < (outside ? fr : fhi)) {
+        if (lane < d) worst[lane] = xe[lane];
+        if (lane == 0u) fv[hi] = fc;
+      } else {
+        for (uint32_t i = 0; i <= d; ++i) {
+          if (i == lo) continue;
+          ldd* v = sx + (size_t)i * LMG_MAX_THETA;
+          if (lane < d) v[lane] = sx[(size_t)lo * LMG_MAX_THETA + lane] + 0.5 * (v[lane] - sx[(size_t)lo * LMG_MAX_THETA + lane]);
+          lmg_sync();
+          const double fi = lmg_f<Q0>(prm, m, v, lane, n_rows, n_eval);
+          if (lane == 0u) fv[i] = fi;
+          lmg_sync();
+        }
+      }
+    }
+    lmg_sync();
+  }
+  uint32_t lo = 0;
+  for (uint32_t i = 1; i <= d; ++i)
+    if (fv[i] < fv[lo]) lo = i;
+  const double best = fv[lo];
+  lmg_sync();
+  double keep = 0.0;
+  if (lane < d) keep = sx[(size_t)lo * LMG_MAX_THETA + lane];
+  lmg_sync();
+  if (lane < d) sx[lane] = keep;
+  lmg_sync();
+  return best;
+}
+
+// SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
+// heteroskedastic residuals) plus the LME knobs -- random-effect shape, one ICC jitter per grouping
+template <int P, int Q0, bool SCEN>
+__global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ double lds_d[];
+  const SimParams& prm = *pp;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lsim = blockIdx.x;
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
+  const uint32_t W = prm.lmg_W, R = prm.lmg_R, L0 = prm.lmg_levels[0], d = prm.lmg_n_theta, nterms = prm.lmg_n_terms;
+  LmgLds m;
+  {
+    ldd* q = (ldd*)lds_d;
+    m.gzz = q; q += (size_t)L0 * Q0 * Q0;
+    m.gzw = q; q += (size_t)L0 * Q0 * W;
+    m.gww = q; q += (size_t)W * W;
+    m.S = q; q += (size_t)W * W;
+    m.B = q; q += (size_t)L0 * Q0 * W;
+    m.ld = q; q += L0;
+    m.simplex = q; q += (size_t)(d + 4u) * LMG_MAX_THETA;
+    m.fv = q; q += d + 1u;
+    m.tm = q; q += 27;
+    m.misc = q; q += 8;
+    m.tail = q; q += 8 + 64 + 64 + 64 + 8 + 8;  // beta | L | U | Lc | cj | tsq
+    m.rval = q; q += LMG_MAX_NZ;
+    m.carry = q; q += LMG_MAX_THETA;
+    ldu* u = (ldu*)q;
+    m.ridx = u; u += LMG_MAX_NZ;
+    ldf* f = (ldf*)u;
+    m.design = f; f += (size_t)P * n_pad;
+    m.u0 = f; f += L0;
+    m.us = f; f += (size_t)L0 * LMG_MAX_SLOPES;
+    m.ux = f;
+    for (uint32_t t = 1; t < nterms; ++t) f += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
+    m.st = (float*)f + lane;
+  }
+  // ---- 1. random effects on the sequential stream (data_gen.rs:146-284): draw d is the d-th block of
+  //         re_draws_per_cluster words, shaped by the scenario's random_effect_dist on the general path ----
+  auto re_draw = [&](uint32_t ordinal) -> double {
+    if (SCEN) return draw_cluster_effect(prm, k0, k1, ordinal);
+    return (double)norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)ordinal)));
+  };
+  // realised tau per grouping (ICC jitter, data_gen.rs:1069-1092) and the factor of its D = diag(tau) R diag(tau)
+  auto term_tau = [&](uint32_t t) -> double {
+    if (SCEN && prm.scen_tau_sq) {
+      const double t2 = prm.scen_tau_sq[(size_t)t * prm.scen_stride + lsim];
+      return __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
+    }
+    return prm.lmg_tau[t];
+  };
+  auto term_chol = [&](uint32_t t, double tau0, double (&l)[9]) {
+    const uint32_t q = prm.lmg_q[t];
+    if (!SCEN) {
+      for (uint32_t i = 0; i < 9u; ++i) l[i] = prm.lmg_chol[t][i];
+      return;
+    }
+    double tv[3] = {tau0, prm.lmg_slope_sd[t][0], prm.lmg_slope_sd[t][1]}, dm[9];
+    for (uint32_t i = 0; i < 9u; ++i) l[i] = 0.0;
+    for (uint32_t i = 0; i < q; ++i)
+      for (uint32_t j = 0; j < q; ++j) dm[i * q + j] = tv[i] * prm.lmg_recorr[t][i * q + j] * tv[j];
+    for (uint32_t j = 0; j < q; ++j) {  // chol_lower (data_gen.rs:55-75)
+      double diag = dm[j * q + j];
+      for (uint32_t k = 0; k < j; ++k) diag -= l[j * q + k] * l[j * q + k];
+      const double ljj = __builtin_sqrt(diag > 0.0 ? diag : 0.0);
+      l[j * q + j] = ljj;
+      for (uint32_t i = j + 1u; i < q; ++i)
+        if (ljj > 0.0) {
+          double sacc = dm[i * q + j];
+          for (uint32_t k = 0; k < j; ++k) sacc -= l[i * q + k] * l[j * q + k];
+          l[i * q + j] = sacc / ljj;
+        }
+    }
+  };
+  const double tau_p = term_tau(0u);
+  for (uint32_t c = lane; c < L0; c += GW) m.u0[c] = (float)(re_draw(prm.lmg_seq[0] + c) * tau_p);
+  lmg_sync();
+  if (Q0 > 1) {
+    double l0[9];
+    term_chol(0u, tau_p, l0);
+    for (uint32_t c = lane; c < L0; c += GW) {
+      double z[3];
+      z[0] = tau_p > 0.0 ? (double)m.u0[c] / tau_p : 0.0;
+#pragma unroll
+      for (int j = 1; j < Q0; ++j) z[j] = re_draw(prm.lmg_seq[1] + c * (uint32_t)(Q0 - 1) + (uint32_t)(j - 1));
+#pragma unroll
+      for (int k = 1; k < Q0; ++k) {
+        double uk = 0.0;
+#pragma unroll
+        for (int j = 0; j < Q0; ++j)
+          if (j <= k) uk += l0[k * Q0 + j] * z[j];
+        m.us[(size_t)c * (Q0 - 1) + (k - 1)] = (float)uk;
+      }
+    }
+  }
+  {
+    ldf* ux = m.ux;
+    for (uint32_t t = 1; t < nterms; ++t) {
+      const uint32_t q = prm.lmg_q[t], nl = prm.lmg_levels[t];
+      const double tau_t = term_tau(t);
+      for (uint32_t c = lane; c < nl; c += GW) ux[(size_t)c * q] = (float)(re_draw(prm.lmg_seq[2u * t] + c) * tau_t);
+      lmg_sync();
+      if (q > 1u) {
+        double lt[9];
+        term_chol(t, tau_t, lt);
+        for (uint32_t c = lane; c < nl; c += GW) {
+          double z[3];
+          z[0] = tau_t > 0.0 ? (double)ux[(size_t)c * q] / tau_t : 0.0;
+          for (uint32_t j = 1; j < q; ++j) z[j] = re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u) + (j - 1u));
+          for (uint32_t k = 1; k < q; ++k) {
+            double uk = 0.0;
+            for (uint32_t j = 0; j <= k; ++j) uk += lt[k * q + j] * z[j];
+            ux[(size_t)c * q + k] = (float)uk;
+          }
+        }
+      }
+      ux += (size_t)nl * q;
+    }
+  }
+  lmg_sync();
+
+  // ---- 2. the replicate's rows (lane = row) ----
+  RowCtx<P> cx;
+  row_ctx_init<P, true>(prm, cx);  // factor columns cost nothing here: generation is a sliver of this kernel
+  ScenLane<P> sl;
+  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
+  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += GW) {
+    stage_group<P, GW, 0, SCEN>(prm, k0, k1, ctr, m.st, SCEN ? sl.meta : 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t rr = 4u * ctr + r;
+      if (rr < max_n) {
+        float x[P], y;
+        const float e = build_x<P, true, GW, SCEN>(prm, cx, k0, k1, m.st, r, rr, x, &sl);
+        // latent-scale random effect in the reference's order: primary intercept, extras (intercept, slopes), primary slopes
+        const uint32_t cid = lmg_level_of_row(prm, 0u, rr);
+        double u_re = (double)m.u0[cid];
+        const ldf* ux = m.ux;
+        for (uint32_t t = 1; t < nterms; ++t) {
+          const uint32_t q = prm.lmg_q[t], lvl = lmg_level_of_row(prm, t, rr);
+          u_re += (double)ux[(size_t)lvl * q];
+          for (uint32_t s = 1; s < q; ++s) {
+            float xv = 0.0f;
+#pragma unroll
+            for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[t][s - 1u] ? x[c] : xv;
+            u_re += (double)ux[(size_t)lvl * q + s] * (double)xv;
+          }
+          ux += (size_t)prm.lmg_levels[t] * q;
+        }
+#pragma unroll
+        for (int s = 1; s < Q0; ++s) {
+          float xv = 0.0f;
+#pragma unroll
+          for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[0][s - 1] ? x[c] : xv;
+          u_re += (double)m.us[(size_t)cid * (Q0 - 1) + (s - 1)] * (double)xv;
+        }
+        finish_row<P, 0, SCEN>(prm, cx, x, e, y, u_re, &sl);
+#pragma unroll
+        for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
+        m.design[(size_t)(P - 1) * n_pad + rr] = y;
+      }
+    }
+  }
+  // ---- 3. sufficient statistics, zeroed once and grown over the grid ----
+  for (size_t i = lane; i < (size_t)L0 * Q0 * Q0 + (size_t)L0 * Q0 * W + (size_t)W * W; i += GW) m.gzz[i] = 0.0;  // gzz | gzw | gww are contiguous
+  lmg_sync();
+
+  uint32_t nzr = 0;  // non-zeros of the rest part of a row
+  for (uint32_t t = 1; t < nterms; ++t) nzr += prm.lmg_q[t];
+  const uint32_t nz = nzr + (uint32_t)P + 1u;
+  bool has_prev = false;
+  uint32_t prev_n = 0;
+  const uint32_t nt = prm.n_tests;
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n = prm.ns[g];
+    for (uint32_t i = prev_n; i < n; ++i) {
+      if (lane < nz) {
+        uint32_t idx;
+        double val;
+        if (lane < nzr) {
+          uint32_t t = 1, e = lane;
+          while (e >= prm.lmg_q[t]) { e -= prm.lmg_q[t]; ++t; }
+          idx = prm.lmg_roff[t] + lmg_level_of_row(prm, t, i) * prm.lmg_q[t] + e;
+          val = e == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[t][e - 1u] - 1u) * n_pad + i];
+        } else {
+          const uint32_t a = lane - nzr;  // 0..P-1 design column, P = outcome
+          idx = R + a;
+          val = a == 0u ? 1.0 : (double)m.design[(size_t)(a - 1u) * n_pad + i];
+        }
+        m.ridx[lane] = idx;
+        m.rval[lane] = val;
+      }
+      lmg_sync();
+      const uint32_t c = lmg_level_of_row(prm, 0u, i);
+      for (uint32_t pr = lane; pr < nz * nz; pr += GW) {
+        const uint32_t a = pr / nz, b = pr % nz;
+        const uint32_t ia = m.ridx[a], ib = m.ridx[b];
+        if (ib <= ia) m.gww[(size_t)ia * W + ib] = __builtin_fma(m.rval[a], m.rval[b], m.gww[(size_t)ia * W + ib]);
+      }
+      for (uint32_t pr = lane; pr < (uint32_t)Q0 * nz; pr += GW) {
+        const uint32_t a = pr / nz, b = pr % nz;
+        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * n_pad + i];
+        ldd* cell = m.gzw + ((size_t)c * Q0 + a) * W + m.ridx[b];
+        *cell = __builtin_fma(za, m.rval[b], *cell);
+      }
+      if (lane < (uint32_t)(Q0 * Q0)) {
+        const uint32_t a = lane / Q0, b = lane % Q0;
+        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * n_pad + i];
+        const double zb = b == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][b - 1u] - 1u) * n_pad + i];
+        ldd* cell = m.gzz + (size_t)c * Q0 * Q0 + lane;
+        *cell = __builtin_fma(za, zb, *cell);
+      }
+      lmg_sync();
+    }
+    prev_n = n;
+    // ---- minimise: truth start / carried theta-hat / blind start (batch.rs:1316-1332) ----
+    ldd* x0 = m.simplex;
+    if (lane < d) {
+      double v;
+      if (has_prev) v = m.carry[lane];  // theta-hat of the last converged grid point
+      else if (prm.truth_start) v = prm.lmg_theta_truth[lane];
+      else v = lmg_is_diag(prm, lane) ? 1.0 : 0.0;
+      if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;  // THETA_TRUTH_FLOOR on every component of a given start
+      x0[lane] = v;
+    }
+    lmg_sync();
+    uint32_t n_eval = 0;
+    const double n_rows = (double)n;
+    double best = lmg_nelder_mead<Q0>(prm, m, 0.25, 1e-9, 1e-6, lane, n_rows, n_eval);
+    for (int restart = 0; restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
+      const double prev = best;
+      best = lmg_nelder_mead<Q0>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, n_eval);
+      if (!(prev - best > 1e-8)) break;
+    }
+    // snap small diagonals onto the boundary when that costs no deviance
+    double cur = lmg_f<Q0>(prm, m, x0, lane, n_rows, n_eval);
+    for (uint32_t k = 0; k < d; ++k) {
+      const double keep = x0[k];
+      if (!lmg_is_diag(prm, k) || keep == 0.0 || keep > 1e-4) continue;
+      lmg_sync();
+      if (lane == 0u) x0[k] = 0.0;
+      lmg_sync();
+      const double f0 = lmg_f<Q0>(prm, m, x0, lane, n_rows, n_eval);
+      if (f0 <= cur + 1e-8) cur = f0;
+      else {
+        lmg_sync();
+        if (lane == 0u) x0[k] = keep;
+        lmg_sync();
+      }
+    }
+    const double fin = lmg_f<Q0>(prm, m, x0, lane, n_rows, n_eval);
+    bool conv = fin < __builtin_inf() && n_eval < LMG_MAX_EVAL;
+    uint32_t pinned = 0, comp = 0;
+    bool at_upper = false;
+    for (uint32_t k = 0; k < d; ++k) {
+      if (!lmg_is_diag(prm, k)) continue;
+      if (x0[k] < LMG_THETA_ZERO) pinned |= 1u << comp;
+      if (x0[k] > LMG_THETA_MAX - 1e-3) at_upper = true;
+      ++comp;
+    }
+    const uint32_t bh = !conv ? 0u : (at_upper ? 2u : (pinned ? 1u : 0u));
+    if (at_upper) conv = false;
+    if (conv) {  // grid-sequential warm start (batch.rs:1414-1428): a diverged theta-hat never replaces the carry
+      if (lane < d) m.carry[lane] = x0[lane];
+      has_prev = true;
+    }
+    // ---- Wald z^2, joint Wald chi2, decisions: scalar work of one lane ----
+    if (lane == 0u) {
+      const uint32_t p = (uint32_t)P;
+      const ldd* beta = m.tail;
+      const ldd* Lx = m.tail + 8;
+      ldd* U = m.tail + 8 + 64;
+      ldd* Lc = U + 64;
+      ldd* cj = Lc + 64;
+      const double sigma_sq = m.misc[0];
+      const double* crow = prm.crit + (size_t)g * prm.crit_stride;
+      double tsq[MAX_T_WAVE];
+#pragma unroll
+      for (int t = 0; t < MAX_T_WAVE; ++t) {
+        tsq[t] = __builtin_nan("");
+        if ((uint32_t)t < nt && conv) {
+          const double* c = prm.contrast + t * MAX_P;
+          double est = 0.0, nq = 0.0;
+          for (uint32_t i = 0; i < p; ++i) {
+            est = __builtin_fma(c[i], beta[i], est);
+            double acc = c[i];
+            for (uint32_t q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i * 8u + q], U[t * 8 + q], acc);
+            U[t * 8 + i] = acc / Lx[i * 8u + i];
+            nq = __builtin_fma(U[t * 8 + i], U[t * 8 + i], nq);
+          }
+          const double var = sigma_sq * nq;
+          if (var > LMG_NEAR_ZERO && var < __builtin_inf()) tsq[t] = est * est / var;
+        }
+      }
+      bool joint_sig = false;
+      if (conv && nt != 0u) {
+        bool jok = true;
+        double qsum = 0.0;
+        for (uint32_t j = 0; j < nt; ++j) {
+          double dd = 0.0;
+          for (uint32_t i = 0; i < p; ++i) dd = __builtin_fma(U[j * 8u + i], U[j * 8u + i], dd);
+          dd *= sigma_sq;
+          for (uint32_t t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j * 8u + t], Lc[j * 8u + t], dd);
+          jok = jok && (dd > 0.0);
+          Lc[j * 8u + j] = __builtin_sqrt(dd);
+          for (uint32_t i2 = j + 1u; i2 < nt; ++i2) {
+            double vv = 0.0;
+            for (uint32_t i = 0; i < p; ++i) vv = __builtin_fma(U[i2 * 8u + i], U[j * 8u + i], vv);
+            vv *= sigma_sq;
+            for (uint32_t t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2 * 8u + t], Lc[j * 8u + t], vv);
+            Lc[i2 * 8u + j] = vv / Lc[j * 8u + j];
+          }
+        }
+        for (uint32_t i = 0; i < nt; ++i) {
+          const double* c = prm.contrast + i * MAX_P;
+          double vv = 0.0;
+          for (uint32_t q = 0; q < p; ++q) vv = __builtin_fma(c[q], beta[q], vv);
+          for (uint32_t t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i * 8u + t], cj[t], vv);
+          cj[i] = vv / Lc[i * 8u + i];
+          qsum = __builtin_fma(cj[i], cj[i], qsum);
+        }
+        joint_sig = jok && (qsum < __builtin_inf()) && (qsum > crow[2 + nt]);
+      }
+      uint32_t unc_bits = 0, cor_bits = 0;
+      decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
+      if (!conv) {
+        unc_bits = 0;
+        cor_bits = 0;
+      }
+      const size_t cell = (size_t)(prm.out_base + lsim) * prm.n_grid + g;
+#pragma unroll
+      for (int t = 0; t < MAX_T_WAVE; ++t)
+        if ((uint32_t)t < nt) {
+          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
+          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
+        }
+      prm.conv[cell] = conv ? 1 : 0;
+      prm.boundary[cell] = (uint8_t)bh;
+      prm.joint[cell] = joint_sig ? 1 : 0;
+      if (prm.pinned) prm.pinned[cell] = (uint16_t)(conv ? pinned : 0u);
+      if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1449-1451
+      if (prm.stat && g == 0u) {
+#pragma unroll
+        for (int t = 0; t < MAX_T_WAVE; ++t)
+          if ((uint32_t)t < nt) prm.stat[(size_t)(prm.out_base + lsim) * nt + t] = tsq[t];
+      }
+    }
+    lmg_sync();
+  }
+}
+
+}  // namespace
+}  // namespace mcp

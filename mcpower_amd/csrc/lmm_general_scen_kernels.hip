@@ -1,4 +1,4 @@
-// lmm_general_kernels.hip -- instantiations of the general mixed-model kernel (plain data path); the kernel itself lives in
+// lmm_general_scen_kernels.hip -- instantiations of the general mixed-model kernel (general / scenario data path); the kernel itself lives in
 // lmm_general_impl.hpp.  Split over two translation units so that both data-path flavours compile in parallel.
 #include "lmm_general_impl.hpp"
 
@@ -6,30 +6,16 @@
 
 namespace mcp {
 
-// LDS bytes of one replicate
-size_t lmg_lds_bytes(const SimParams& prm) {
-  const size_t W = prm.lmg_W, L0 = prm.lmg_levels[0], q0 = prm.lmg_q[0], d = prm.lmg_n_theta;
-  size_t dbl = L0 * q0 * q0 + 2 * L0 * q0 * W + L0 + 2 * W * W + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8) +
-               LMG_MAX_NZ + LMG_MAX_THETA;
-  size_t u32 = LMG_MAX_NZ;
-  const size_t n_pad = ((size_t)prm.max_n + 3u) & ~(size_t)3u;
-  size_t nlev = 0;
-  for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) nlev += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
-  size_t flt = (size_t)prm.P * n_pad + L0 + L0 * LMG_MAX_SLOPES + nlev + 4 * (prm.P + 1) * GW;
-  return dbl * 8 + ((u32 + 1) & ~(size_t)1) * 4 + flt * 4 + 64;
-}
-
-
-hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st) {
+hipError_t launch_lmm_general_scen(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st) {
   const dim3 block(GW), grid(n_sims);
 #define LG(PP, QQ)                                                                                                     \
   if (P == PP && q0 == QQ) {                                                                                           \
     if (lds > 48 * 1024) {                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)lmm_general_kernel<PP, QQ, false>,                                  \
+      hipError_t e = hipFuncSetAttribute((const void*)lmm_general_kernel<PP, QQ, true>,                                  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
       if (e != hipSuccess) return e;                                                                                   \
     }                                                                                                                  \
-    hipLaunchKernelGGL((lmm_general_kernel<PP, QQ, false>), grid, block, lds, st, d_prm);                                 \
+    hipLaunchKernelGGL((lmm_general_kernel<PP, QQ, true>), grid, block, lds, st, d_prm);                                 \
     return hipGetLastError();                                                                                          \
   }
   LG(2, 1) LG(2, 2) LG(3, 1) LG(3, 2) LG(3, 3) LG(4, 1) LG(4, 2) LG(4, 3) LG(5, 1) LG(5, 2) LG(5, 3) LG(6, 1) LG(6, 2) LG(6, 3)

@@ -181,6 +181,9 @@ struct SimParams {
   uint32_t _pad_lmg;
   double lmg_tau[LMG_MAX_TERMS];     // sqrt(max(tau^2, 0)) per term
   double lmg_chol[LMG_MAX_TERMS][9]; // row-major lower chol(diag(tau) R diag(tau)) per term: the slope draws
+  double lmg_tau_sq[LMG_MAX_TERMS];  // spec tau^2 per term (the ICC jitter of the general path starts from it)
+  double lmg_slope_sd[LMG_MAX_TERMS][LMG_MAX_SLOPES];  // sqrt(slope variance)
+  double lmg_recorr[LMG_MAX_TERMS][9];                 // re_correlation_matrix(), row-major q x q
   double lmg_theta_truth[LMG_MAX_THETA];
   uint16_t* pinned;                  // [n_sims_total][n_grid] pinned-component bits (spec.rs:566-573) or null
 

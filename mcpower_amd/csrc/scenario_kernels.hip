@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void scenario_design_kernel(const SimParams* _
   uint32_t vt[MAX_K];
   uint32_t rd = prm.resid_spec_dist;
   double tau_sq = prm.tau_squared;
+  double extra_tau_sq[LMG_MAX_TERMS] = {0.0, prm.lmg_tau_sq[1], prm.lmg_tau_sq[2]};
   bool ok = true;
   for (uint32_t j = 0; j < K; ++j) vt[j] = prm.var_types[j];
   if (prm.scen_optimistic) {
@@ -72,9 +73,18 @@ __global__ __launch_bounds__(256) void scenario_design_kernel(const SimParams* _
       const double jit = (double)rng.next_normal() * prm.lme_icc_noise_sd;
       tau_sq = tau_sq + jit;
       tau_sq = tau_sq > 0.0 ? tau_sq : 0.0;
+      // extra groupings: one independent jitter each, after the primary's, in declaration order (:1077-1092)
+      for (uint32_t t = 1; prm.lmg_active && t < prm.lmg_n_terms; ++t) {
+        const double jg = (double)rng.next_normal() * prm.lme_icc_noise_sd;
+        const double v = prm.lmg_tau_sq[t] + jg;
+        extra_tau_sq[t] = v > 0.0 ? v : 0.0;
+      }
     }
   }
-  if (prm.scen_tau_sq) prm.scen_tau_sq[lsim] = tau_sq;
+  if (prm.scen_tau_sq) {
+    prm.scen_tau_sq[lsim] = tau_sq;
+    for (uint32_t t = 1; prm.lmg_active && t < prm.lmg_n_terms; ++t) prm.scen_tau_sq[(size_t)t * prm.scen_stride + lsim] = extra_tau_sq[t];
+  }
   uint32_t meta = (rd & 7u) << 28;
   for (uint32_t j = 0; j < K; ++j) meta |= (vt[j] & 15u) << (4u * j);
   if (!ok) meta |= 0x80000000u;  // EngineError::CorrelationNotPSD for this replicate

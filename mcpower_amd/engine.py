@@ -30,7 +30,7 @@ def build(force: bool = False) -> str:
     """Compile the HIP library for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "clean"], check=True, capture_output=True)
-    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
     return LIB_PATH
