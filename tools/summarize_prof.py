@@ -12,7 +12,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+ks = sorted(glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # newest run first
 if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{prefix}_{tag}_kernel_stats.csv"))
 bj = os.path.join(src, "bench_under_profiler.json")
@@ -20,7 +20,7 @@ if os.path.exists(bj):
     shutil.copy(bj, os.path.join(dst, f"{prefix}_{tag}_bench_under_profiler.json"))
 rows = []
 for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)[:1]:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
         for r in csv.DictReader(open(f)):
