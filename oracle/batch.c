@@ -32,6 +32,10 @@ void mcpo_set_error(const char* fmt, ...) {
 int mcpo_glm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
                  const double* crit, uint32_t crit_stride, mcpo_red_cache* cache, uint8_t* unc, uint8_t* cor,
                  uint8_t* conv, uint8_t* overall, uint8_t* fx, double* stat_row);
+int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
+                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
+                  uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* overall, double* tau_hat, double* stat_row,
+                  uint64_t* pinned);
 int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
                  uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* fx, double* stat_row, uint64_t* pinned);
@@ -242,6 +246,13 @@ static void* worker(void* arg) {
     uint8_t* fx = spec->n_factors ? R->factor_excluded + cell0 * spec->n_factors : NULL;
     if (spec->estimator == MCP_EST_OLS) {
       rc = ols_arm(jb, ws, s);
+      if (rc) { jb->rc = rc; break; }
+    } else if (spec->estimator == MCP_EST_GLM && spec->cluster.present) { /* GLMM branch, batch.rs:1575-1830 */
+      rc = mcpo_glmm_arm(spec, ws, jb->max_n, jb->ns, n_ns, jb->crit, cs, R->uncorrected + cell0 * nt,
+                         R->corrected + cell0 * nt, R->converged + cell0, R->boundary_hit + cell0,
+                         R->joint_unc + cell0, R->joint_cor + cell0, R->overall ? R->overall + cell0 : NULL,
+                         R->tau_squared_hat + cell0, R->stat_capture ? R->stat_capture + (size_t)s * nt : NULL,
+                         R->pinned_components + cell0);
       if (rc) { jb->rc = rc; break; }
     } else if (spec->estimator == MCP_EST_GLM) {
       rc = mcpo_glm_arm(spec, ws, jb->max_n, jb->ns, n_ns, jb->crit, cs, &jb->cache, R->uncorrected + cell0 * nt,

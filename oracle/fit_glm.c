@@ -60,7 +60,7 @@ static int glm_family_of(const mcp_spec* spec) {
 }
 
 /* mean, IRLS weight, working response and deviance contribution of one observation */
-static void fam_eval(int fam, double eta, double yi, double* w_out, double* z_out, double* dev_out) {
+void mcpo_fam_eval(int fam, double eta, double yi, double* w_out, double* z_out, double* dev_out) {
   if (fam == FAM_LOGIT) {
     double pr = sigmoid_stable(eta);
     double w = pr * (1.0 - pr);
@@ -101,7 +101,7 @@ static void irls_pass(int fam, const float* x, const float* y, uint32_t n, uint3
     double eta = 0.0;
     for (uint32_t c = 0; c < p; ++c) eta += (double)x[(size_t)c * ld + i] * beta[c];
     double w, z, di;
-    fam_eval(fam, eta, (double)y[i], &w, &z, &di);
+    mcpo_fam_eval(fam, eta, (double)y[i], &w, &z, &di);
     d += di;
     for (uint32_t a = 0; a < p; ++a) {
       double wxa = w * (double)x[(size_t)a * ld + i];

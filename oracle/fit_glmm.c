@@ -1,0 +1,411 @@
+/*
+ * oracle/fit_glmm.c -- CPU ORACLE (test infrastructure): generalised linear mixed model with a random
+ * intercept by the Laplace approximation (the clustered-GLM branch of the Glm arm, batch.rs:1575-1830).
+ *
+ * The reference hands these fits to glmm 0.1.2 `loop_advanced::fit_on` (family Binomial{logit, probit} /
+ * Poisson{log}, nagq = 1 = Laplace, Wald SE mode "rx"; mixed_workspace.rs:11-30, configs/config.json
+ * "estimation"), which is not in the tree.  Readable around the call: the start is the DGP truth
+ * [beta | theta] (beta unconditionally, theta = truth / carried theta-hat / blind THETA0; batch.rs:1650-1690),
+ * families fix the dispersion at 1, the outputs are predictor-indexed Wald z^2, the joint Wald chi2 against
+ * chi2_ppf(1 - alpha, k), boundary_hit, pinned_components and tau-hat^2 = D-hat[0][0] (:1723-1775).
+ *
+ * Algorithm (lme4's glmer with nAGQ = 1; Bates et al. 2015, section 5 carried to GLMMs as in lme4's
+ * `glmer` vignette): with b = theta u, u ~ N(0, I), the Laplace deviance is
+ *   d(theta, beta) = sum_i devres_i(mu_i(u~)) + |u~|^2 + log|theta^2 Z'W Z + I|,
+ * u~ the conditional modes from penalised IRLS (Fisher scoring on u with beta fixed).  A random intercept
+ * decouples the clusters: each mode is a scalar,  u <- theta sum_i w_i (z_i - x_i'beta) / (theta^2 sum_i w_i + 1).
+ * (theta, beta) are minimised jointly by the bounded Nelder-Mead simplex the general LMM oracle uses.
+ * Wald SE mode "rx": Var(beta-hat) = (RX'RX)^-1 with RX'RX = X'WX - sum_c theta^2 (X_c'w_c)(X_c'w_c)' /
+ * (theta^2 sum w_c + 1) at the optimum (lme4: vcov(., use.hessian = FALSE)).
+ *
+ * PARITY STATUS: beta-hat and tau-hat^2 pinned to lme4 1.1.38 glmer (Laplace) on the reference's bytes
+ * (validation/data/glmm_intercept.golden.rds; GLMM_TOL of tolerances.R:186-200: 1e-4 rel / 1e-3 abs on beta).
+ * The golden z is glmer's Hessian-based z, a different SE convention from the engine's "rx" default, so it
+ * is compared at the few-percent level only.  Optimiser, convergence rules, boundary classification:
+ * **parity unpinned**.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle_internal.h"
+
+#define GLMM_MAX_DIM (MCPO_MAX_P + 1)
+#define GLMM_MAX_EVAL 8000
+#define GLMM_THETA_MAX 32.0
+#define GLMM_THETA_ZERO 1e-6
+#define GLMM_PIRLS_ITERS 40
+#define GLMM_NEAR_ZERO 1e-30
+
+typedef struct glmm_model {
+  int fam;
+  uint32_t n, ld, p, ncl;
+  const float *x, *y;
+  uint32_t* start;  /* ncl + 1 */
+  uint32_t* rows;   /* n, grouped by cluster in row order */
+  double* eta0;     /* n */
+  double* u;        /* ncl: modes of the last evaluation */
+  double* sw;       /* ncl: sum of IRLS weights at the mode */
+} glmm_model;
+
+static void glmm_free(glmm_model* m) {
+  free(m->start); free(m->rows); free(m->eta0); free(m->u); free(m->sw);
+  memset(m, 0, sizeof *m);
+}
+
+static int glmm_build(glmm_model* m, int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld,
+                      uint32_t p, uint32_t ncl) {
+  memset(m, 0, sizeof *m);
+  m->fam = fam; m->n = n; m->ld = ld; m->p = p; m->ncl = ncl; m->x = x; m->y = y;
+  m->start = (uint32_t*)calloc(ncl + 2, sizeof(uint32_t));
+  m->rows = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+  m->eta0 = (double*)malloc(sizeof(double) * (n ? n : 1));
+  m->u = (double*)calloc(ncl ? ncl : 1, sizeof(double));
+  m->sw = (double*)calloc(ncl ? ncl : 1, sizeof(double));
+  if (!m->start || !m->rows || !m->eta0 || !m->u || !m->sw) { glmm_free(m); return MCP_ERR_DEVICE; }
+  for (uint32_t i = 0; i < n; ++i) {
+    if (ids[i] >= ncl) { glmm_free(m); return MCP_ERR_INVALID_SPEC; }
+    m->start[ids[i] + 1] += 1;
+  }
+  for (uint32_t c = 0; c < ncl; ++c) m->start[c + 1] += m->start[c];
+  uint32_t* fill = (uint32_t*)calloc(ncl ? ncl : 1, sizeof(uint32_t));
+  for (uint32_t i = 0; i < n; ++i) { uint32_t c = ids[i]; m->rows[m->start[c] + fill[c]++] = i; }
+  free(fill);
+  return MCP_OK;
+}
+
+/* Laplace deviance at par = (theta, beta_0..beta_{p-1}); leaves the modes and weight sums in m */
+static double glmm_deviance(glmm_model* m, const double* par) {
+  const double theta = par[0];
+  const double* beta = par + 1;
+  const uint32_t p = m->p;
+  for (uint32_t i = 0; i < m->n; ++i) {
+    double e = 0.0;
+    for (uint32_t c = 0; c < p; ++c) e += (c == 0 ? 1.0 : (double)m->x[(size_t)c * m->ld + i]) * beta[c];
+    m->eta0[i] = e;
+  }
+  double total = 0.0;
+  for (uint32_t c = 0; c < m->ncl; ++c) {
+    const uint32_t lo = m->start[c], hi = m->start[c + 1];
+    if (lo == hi) { m->u[c] = 0.0; m->sw[c] = 0.0; continue; }
+    double u = 0.0, pd_prev = INFINITY, sw = 0.0, dev = 0.0;
+    for (int it = 0; it < GLMM_PIRLS_ITERS; ++it) {
+      double swz = 0.0;
+      sw = 0.0; dev = 0.0;
+      for (uint32_t k = lo; k < hi; ++k) {
+        uint32_t i = m->rows[k];
+        double w, z, d;
+        mcpo_fam_eval(m->fam, m->eta0[i] + theta * u, (double)m->y[i], &w, &z, &d);
+        sw += w; swz += w * (z - m->eta0[i]); dev += d;
+      }
+      double pd = dev + u * u;
+      if (it > 0 && fabs(pd - pd_prev) <= 1e-13 * (fabs(pd) + 1.0)) break;
+      double un = theta * swz / (theta * theta * sw + 1.0);
+      if (it > 0 && pd > pd_prev) un = 0.5 * (u + un);  /* a Fisher step that overshot: damp it */
+      pd_prev = pd;
+      if (un == u) break;
+      u = un;
+    }
+    m->u[c] = u; m->sw[c] = sw;
+    total += dev + u * u + log(theta * theta * sw + 1.0);
+  }
+  return isfinite(total) ? total : INFINITY;
+}
+
+static double glmm_f(glmm_model* m, double* par, uint32_t* n_eval) {
+  if (par[0] < 0.0) par[0] = 0.0;
+  if (par[0] > GLMM_THETA_MAX) par[0] = GLMM_THETA_MAX;
+  for (uint32_t k = 1; k <= m->p; ++k) par[k] = par[k] < -50.0 ? -50.0 : (par[k] > 50.0 ? 50.0 : par[k]);
+  ++*n_eval;
+  return glmm_deviance(m, par);
+}
+
+static double glmm_nelder_mead(glmm_model* m, double* x0, double step, double ftol, double xtol, uint32_t* n_eval) {
+  const uint32_t d = m->p + 1;
+  double sx[GLMM_MAX_DIM + 1][GLMM_MAX_DIM], fv[GLMM_MAX_DIM + 1];
+  memcpy(sx[0], x0, sizeof(double) * d);
+  fv[0] = glmm_f(m, sx[0], n_eval);
+  for (uint32_t i = 0; i < d; ++i) {
+    memcpy(sx[i + 1], x0, sizeof(double) * d);
+    sx[i + 1][i] += step;
+    fv[i + 1] = glmm_f(m, sx[i + 1], n_eval);
+  }
+  while (*n_eval < GLMM_MAX_EVAL) {
+    uint32_t lo = 0, hi = 0, nh;
+    for (uint32_t i = 1; i <= d; ++i) { if (fv[i] < fv[lo]) lo = i; if (fv[i] > fv[hi]) hi = i; }
+    nh = lo;
+    for (uint32_t i = 0; i <= d; ++i) if (i != hi && fv[i] > fv[nh]) nh = i;
+    double size = 0.0;
+    for (uint32_t i = 0; i <= d; ++i)
+      for (uint32_t k = 0; k < d; ++k) size = fmax(size, fabs(sx[i][k] - sx[lo][k]));
+    if (isfinite(fv[hi]) && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
+    double cen[GLMM_MAX_DIM], xr[GLMM_MAX_DIM], xe[GLMM_MAX_DIM];
+    for (uint32_t k = 0; k < d; ++k) {
+      double s = 0.0;
+      for (uint32_t i = 0; i <= d; ++i) if (i != hi) s += sx[i][k];
+      cen[k] = s / (double)d;
+      xr[k] = cen[k] + (cen[k] - sx[hi][k]);
+    }
+    double fr = glmm_f(m, xr, n_eval);
+    if (fr < fv[lo]) {
+      for (uint32_t k = 0; k < d; ++k) xe[k] = cen[k] + 2.0 * (xr[k] - cen[k]);
+      double fe = glmm_f(m, xe, n_eval);
+      if (fe < fr) { memcpy(sx[hi], xe, sizeof(double) * d); fv[hi] = fe; }
+      else { memcpy(sx[hi], xr, sizeof(double) * d); fv[hi] = fr; }
+    } else if (fr < fv[nh]) {
+      memcpy(sx[hi], xr, sizeof(double) * d); fv[hi] = fr;
+    } else {
+      int outside = fr < fv[hi];
+      for (uint32_t k = 0; k < d; ++k) xe[k] = cen[k] + 0.5 * ((outside ? xr[k] : sx[hi][k]) - cen[k]);
+      double fc = glmm_f(m, xe, n_eval);
+      if (fc < (outside ? fr : fv[hi])) { memcpy(sx[hi], xe, sizeof(double) * d); fv[hi] = fc; }
+      else {
+        for (uint32_t i = 0; i <= d; ++i) {
+          if (i == lo) continue;
+          for (uint32_t k = 0; k < d; ++k) sx[i][k] = sx[lo][k] + 0.5 * (sx[i][k] - sx[lo][k]);
+          fv[i] = glmm_f(m, sx[i], n_eval);
+        }
+      }
+    }
+  }
+  uint32_t lo = 0;
+  for (uint32_t i = 1; i <= d; ++i) if (fv[i] < fv[lo]) lo = i;
+  memcpy(x0, sx[lo], sizeof(double) * d);
+  return fv[lo];
+}
+
+/* fit from the start (theta0, beta0); fills f (beta, lower Cholesky factor of RX'RX, sigma_sq = 1) */
+static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, mcpo_gen_fit* f) {
+  const uint32_t p = m->p, d = p + 1;
+  double par[GLMM_MAX_DIM];
+  par[0] = theta0;
+  for (uint32_t c = 0; c < p; ++c) par[1 + c] = beta0 ? beta0[c] : 0.0;
+  memset(f, 0, sizeof *f);
+  uint32_t n_eval = 0;
+  double best = glmm_nelder_mead(m, par, 0.25, 1e-9, 1e-6, &n_eval);
+  for (int restart = 0; restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
+    double prev = best;
+    best = glmm_nelder_mead(m, par, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, &n_eval);
+    if (!(prev - best > 1e-8)) break;
+  }
+  double cur = glmm_f(m, par, &n_eval);
+  if (par[0] != 0.0 && par[0] <= 1e-4) { /* snap onto the boundary when that costs no deviance */
+    double keep = par[0];
+    par[0] = 0.0;
+    double f0 = glmm_f(m, par, &n_eval);
+    if (f0 <= cur + 1e-8) cur = f0; else par[0] = keep;
+  }
+  cur = glmm_f(m, par, &n_eval); /* modes and weight sums of the final point */
+  f->n_eval = n_eval; f->n_theta = 1; f->p = p; f->theta[0] = par[0]; f->dev = cur; f->sigma_sq = 1.0;
+  memcpy(f->beta, par + 1, sizeof(double) * p);
+  /* RX'RX = X'WX - sum_c theta^2 a_c a_c' / (theta^2 sw_c + 1), a_c = X_c' w_c */
+  double A[MCPO_MAX_P * MCPO_MAX_P];
+  memset(A, 0, sizeof A);
+  const double theta = par[0];
+  int ok = isfinite(cur) && n_eval < GLMM_MAX_EVAL;
+  for (uint32_t c = 0; c < m->ncl && ok; ++c) {
+    double a[MCPO_MAX_P];
+    memset(a, 0, sizeof a);
+    for (uint32_t k = m->start[c]; k < m->start[c + 1]; ++k) {
+      uint32_t i = m->rows[k];
+      double w, z, dv;
+      mcpo_fam_eval(m->fam, m->eta0[i] + theta * m->u[c], (double)m->y[i], &w, &z, &dv);
+      for (uint32_t r = 0; r < p; ++r) {
+        double xr = r == 0 ? 1.0 : (double)m->x[(size_t)r * m->ld + i];
+        a[r] += w * xr;
+        for (uint32_t s = 0; s <= r; ++s) A[r * p + s] += w * xr * (s == 0 ? 1.0 : (double)m->x[(size_t)s * m->ld + i]);
+      }
+    }
+    double den = theta * theta * m->sw[c] + 1.0;
+    for (uint32_t r = 0; r < p; ++r)
+      for (uint32_t s = 0; s <= r; ++s) A[r * p + s] -= theta * theta * a[r] * a[s] / den;
+  }
+  memset(f->L, 0, sizeof f->L);
+  for (uint32_t j = 0; j < p && ok; ++j) {
+    double dd = A[j * p + j];
+    for (uint32_t t = 0; t < j; ++t) dd -= f->L[j * p + t] * f->L[j * p + t];
+    if (!(dd > 0.0) || !isfinite(dd)) { ok = 0; break; }
+    f->L[j * p + j] = sqrt(dd);
+    for (uint32_t i = j + 1; i < p; ++i) {
+      double v = A[i * p + j];
+      for (uint32_t t = 0; t < j; ++t) v -= f->L[i * p + t] * f->L[j * p + t];
+      f->L[i * p + j] = v / f->L[j * p + j];
+    }
+  }
+  f->converged = ok;
+  f->pinned = (ok && par[0] < GLMM_THETA_ZERO) ? 1u : 0u;
+  f->at_upper = par[0] > GLMM_THETA_MAX - 1e-3;
+  f->boundary_hit = !ok ? 0 : (f->at_upper ? 2 : (f->pinned ? 1 : 0));
+  if (f->at_upper) f->converged = 0;
+  (void)d;
+  return MCP_OK;
+}
+
+int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld, uint32_t p,
+                      uint32_t ncl, double theta0, const double* beta0, mcpo_gen_fit* f) {
+  if (p > MCPO_MAX_P) return MCP_ERR_UNSUPPORTED;
+  glmm_model m;
+  int rc = glmm_build(&m, fam, x, y, ids, n, ld, p, ncl);
+  if (rc) return rc;
+  rc = glmm_fit_model(&m, theta0, beta0, f);
+  glmm_free(&m);
+  return rc;
+}
+
+/* fit provided bytes (introspect::fit_provided_data twin, clustered-GLM arm) */
+int mcpo_glmm_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
+                  uint32_t p, uint32_t n_clusters, double theta_start, const double* beta_start, double* beta, double* se,
+                  double* z_sq, double* theta_hat, double* tau_sq, uint8_t* converged, uint8_t* boundary_hit,
+                  uint32_t* n_eval) {
+  mcpo_gen_fit f;
+  int rc = mcpo_glmm_fit_ids(family, x, y, cluster_ids, n, ld, p, n_clusters, theta_start > 0.0 ? theta_start : 1.0,
+                             beta_start, &f);
+  if (rc) return rc;
+  *converged = (uint8_t)f.converged; *boundary_hit = f.boundary_hit; *theta_hat = f.theta[0];
+  *tau_sq = f.theta[0] * f.theta[0]; *n_eval = f.n_eval;
+  for (uint32_t j = 0; j < p; ++j) {
+    double u[MCPO_MAX_P], nq = 0.0;
+    for (uint32_t i = 0; i < p; ++i) {
+      double acc = i == j ? 1.0 : 0.0;
+      for (uint32_t t = 0; t < i; ++t) acc -= f.L[i * p + t] * u[t];
+      u[i] = f.converged ? acc / f.L[i * p + i] : NAN;
+      nq += u[i] * u[i];
+    }
+    beta[j] = f.converged ? f.beta[j] : NAN;
+    se[j] = f.converged ? sqrt(nq) : NAN;
+    z_sq[j] = (f.converged && nq > GLMM_NEAR_ZERO) ? f.beta[j] * f.beta[j] / nq : NAN;
+  }
+  return MCP_OK;
+}
+
+/* Wald variance of c'beta from the lower factor of RX'RX (dispersion fixed at 1) */
+static double glmm_var(const mcpo_gen_fit* f, uint32_t p, const double* c) {
+  double u[MCPO_MAX_P], nq = 0.0;
+  for (uint32_t i = 0; i < p; ++i) {
+    double acc = c[i];
+    for (uint32_t t = 0; t < i; ++t) acc -= f->L[i * p + t] * u[t];
+    u[i] = acc / f->L[i * p + i];
+    nq += u[i] * u[i];
+  }
+  return nq;
+}
+
+/* joint Wald chi2 of the kept targets: b_T' [Cov_TT]^-1 b_T */
+static double glmm_joint(const mcpo_gen_fit* f, uint32_t p, const uint32_t* targets, uint32_t k) {
+  if (k == 0) return NAN;
+  double U[MCPO_MAX_P][MCPO_MAX_P], cov[MCPO_MAX_P * MCPO_MAX_P], Lc[MCPO_MAX_P * MCPO_MAX_P], cj[MCPO_MAX_P];
+  for (uint32_t a = 0; a < k; ++a)
+    for (uint32_t i = 0; i < p; ++i) {
+      double acc = i == targets[a] ? 1.0 : 0.0;
+      for (uint32_t t = 0; t < i; ++t) acc -= f->L[i * p + t] * U[a][t];
+      U[a][i] = acc / f->L[i * p + i];
+    }
+  for (uint32_t a = 0; a < k; ++a)
+    for (uint32_t b = 0; b <= a; ++b) {
+      double s = 0.0;
+      for (uint32_t i = 0; i < p; ++i) s += U[a][i] * U[b][i];
+      cov[a * k + b] = s;
+    }
+  memset(Lc, 0, sizeof Lc);
+  for (uint32_t j = 0; j < k; ++j) {
+    double dd = cov[j * k + j];
+    for (uint32_t t = 0; t < j; ++t) dd -= Lc[j * k + t] * Lc[j * k + t];
+    if (!(dd > 0.0)) return NAN;
+    Lc[j * k + j] = sqrt(dd);
+    for (uint32_t i = j + 1; i < k; ++i) {
+      double v = cov[i * k + j];
+      for (uint32_t t = 0; t < j; ++t) v -= Lc[i * k + t] * Lc[j * k + t];
+      Lc[i * k + j] = v / Lc[j * k + j];
+    }
+  }
+  double q = 0.0;
+  for (uint32_t i = 0; i < k; ++i) {
+    double v = f->beta[targets[i]];
+    for (uint32_t t = 0; t < i; ++t) v -= Lc[i * k + t] * cj[t];
+    cj[i] = v / Lc[i * k + i];
+    q += cj[i] * cj[i];
+  }
+  return q;
+}
+
+/* clustered-GLM branch of the Glm arm (batch.rs:1575-1830): random intercept only.  No factor exclusion on clustered
+ * specs (:1583); test_formula fits the kept columns; theta start = carried theta-hat / truth / blind, floored at 0.01
+ * when given (:1650-1690); beta start = the truth, unconditionally; joint crit = chi2_ppf(1 - alpha, k) (:1757-1762). */
+int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
+                  const double* crit, uint32_t crit_stride, uint8_t* unc, uint8_t* cor, uint8_t* conv, uint8_t* bh,
+                  uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* overall, double* tau_hat, double* stat_row,
+                  uint64_t* pinned) {
+  const mcp_cluster* cl = &spec->cluster;
+  if (!cl->present || cl->slopes.n_slopes || cl->n_extra_groupings) return MCP_ERR_UNSUPPORTED;
+  if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS || spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;
+  if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
+  const int fam = spec->outcome_kind == MCP_OUTCOME_COUNT ? 2 : (spec->link == MCP_LINK_PROBIT ? 1 : 0);
+  const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
+  const uint32_t nt = spec->n_target_indices;
+  const uint32_t cv = cl->sizing_value ? cl->sizing_value : 1;
+  const int fixed_clusters = cl->sizing == MCP_CLUSTER_FIXED_CLUSTERS;
+  const int test_reduces = spec->n_fit_columns && spec->n_fit_columns < p;
+  uint32_t* ids = (uint32_t*)malloc(sizeof(uint32_t) * max_n);
+  float* xr = NULL;
+  for (uint32_t i = 0; i < max_n; ++i) ids[i] = mcpo_cluster_of_row(cl, i);
+  uint32_t kept[MCPO_MAX_P];
+  int32_t remap[MCPO_MAX_P];
+  uint32_t p_fit = p;
+  const float* xfit = ws->x;
+  double beta0[MCPO_MAX_P];
+  if (!test_reduces) {
+    for (uint32_t c = 0; c < p; ++c) { remap[c] = (int32_t)c; beta0[c] = spec->effect_sizes[c]; }
+  } else {
+    uint8_t none[16] = {0};
+    p_fit = mcpo_build_exclusion_remap(spec, none, kept, remap);
+    if (p_fit == 0 || kept[0] != 0) { free(ids); return MCP_ERR_UNSUPPORTED; }
+    xr = (float*)malloc(sizeof(float) * (size_t)max_n * p);
+    for (uint32_t rj = 0; rj < p_fit; ++rj) {
+      memcpy(xr + (size_t)rj * max_n, ws->x + (size_t)kept[rj] * max_n, sizeof(float) * max_n);
+      beta0[rj] = spec->effect_sizes[kept[rj]];
+    }
+    xfit = xr;
+  }
+  int has_prev = 0, rc = MCP_OK;
+  double carry = 0.0;
+  for (uint32_t g = 0; g < n_ns && rc == MCP_OK; ++g) {
+    const uint32_t n = ns[g];
+    const uint32_t ncl = fixed_clusters ? cv : (n + cv - 1) / cv;
+    double th0 = has_prev ? carry : (spec->scenario.truth_start ? sqrt(fmax(cl->tau_squared, 0.0)) : 1.0);
+    if ((has_prev || spec->scenario.truth_start) && th0 < 0.01) th0 = 0.01;
+    mcpo_gen_fit f;
+    rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, &f);
+    if (rc) break;
+    if (f.converged) { carry = f.theta[0]; has_prev = 1; }
+    const double* crow = crit + (size_t)g * crit_stride;
+    conv[g] = (uint8_t)f.converged;
+    bh[g] = f.boundary_hit;
+    if (pinned) pinned[g] = f.converged ? f.pinned : 0;
+    if (tau_hat) tau_hat[g] = f.converged ? f.theta[0] * f.theta[0] : NAN;
+    if (overall) overall[g] = 0;
+    double tsq[MCPO_MAX_P * 2];
+    uint32_t fit_targets[MCPO_MAX_P * 2];
+    memset(unc + (size_t)g * nt, 0, nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+      tsq[t] = NAN;
+      fit_targets[t] = (uint32_t)remap[spec->target_indices[t]];  /* a test target is always in the test design */
+      if (f.converged) {
+        double c[MCPO_MAX_P] = {0};
+        c[fit_targets[t]] = 1.0;
+        double var = glmm_var(&f, p_fit, c), b = f.beta[fit_targets[t]];
+        if (var > GLMM_NEAR_ZERO && isfinite(var)) tsq[t] = b * b / var;
+        if (!isnan(tsq[t]) && tsq[t] > crow[0]) unc[(size_t)g * nt + t] = 1;
+      }
+    }
+    if (g == 0 && stat_row) memcpy(stat_row, tsq, sizeof(double) * nt);
+    if (f.converged) mcpo_apply_correction(spec->correction_method, tsq, nt, crow[0], crow + 1, cor + (size_t)g * nt);
+    else memset(cor + (size_t)g * nt, 0, nt);
+    double joint_crit = nt == 0 ? INFINITY : mcpo_chi2_ppf(1.0 - spec->alpha, (double)nt);
+    double jq = (f.converged && nt) ? glmm_joint(&f, p_fit, fit_targets, nt) : NAN;
+    uint8_t js = (f.converged && isfinite(jq) && jq > joint_crit) ? 1 : 0;
+    joint_unc[g] = js;
+    joint_cor[g] = js;
+  }
+  free(ids);
+  free(xr);
+  return rc;
+}

@@ -98,6 +98,12 @@ int mcpo_lmm_general_fit(const float* x, const float* y, uint32_t n, uint32_t ld
                          double* theta_hat, double* sigma_sq, double* vars_out, uint8_t* converged,
                          uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval);
 
+/* ---- random-intercept GLMM (Laplace) on provided bytes (fit_glmm.c); family 0 logit, 1 probit, 2 Poisson ---- */
+int mcpo_glmm_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
+                  uint32_t p, uint32_t n_clusters, double theta_start, const double* beta_start, double* beta, double* se,
+                  double* z_sq, double* theta_hat, double* tau_sq, uint8_t* converged, uint8_t* boundary_hit,
+                  uint32_t* n_eval);
+
 /* ---- OLS fit on provided bytes (glmm fit_suff_stats_t_sq, inferred from
  *      batch.rs:958-1142, posthoc.rs:62-99, introspect.rs:280-284) ----------- */
 int mcpo_ols_fit(const float* x_colmajor, const float* y, uint32_t n_rows, uint32_t ld, uint32_t p,

@@ -284,6 +284,29 @@ def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, s
                 converged=bool(conv.value), boundary_hit=conv.value and bh.value, pinned=pinned.value, n_eval=ne.value)
 
 
+def glmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, family: str = "logit", theta_start: float = 0.0,
+             beta_start=None):
+    """Random-intercept GLMM (Laplace, Wald SE mode "rx") on provided bytes."""
+    n, p = design.shape
+    x = np.ascontiguousarray(design.T, dtype=np.float32)
+    y = np.ascontiguousarray(outcome, dtype=np.float32)
+    ids = np.ascontiguousarray(cluster_ids, dtype=np.uint32)
+    ncl = int(ids.max()) + 1
+    beta, se, zsq = (np.zeros(p) for _ in range(3))
+    th, t2 = C.c_double(), C.c_double()
+    conv, bh, ne = C.c_uint8(), C.c_uint8(), C.c_uint32()
+    pd = C.POINTER(C.c_double)
+    b0 = None if beta_start is None else np.ascontiguousarray(beta_start, dtype=np.float64)
+    rc = lib().mcpo_glmm_fit(C.c_int(GLM_FAMILIES[family]), x.ctypes.data_as(C.POINTER(C.c_float)),
+                             y.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                             C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), C.c_uint32(ncl), C.c_double(theta_start),
+                             None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd), se.ctypes.data_as(pd),
+                             zsq.ctypes.data_as(pd), C.byref(th), C.byref(t2), C.byref(conv), C.byref(bh), C.byref(ne))
+    _check(rc)
+    return dict(beta=beta, se=se, z_sq=zsq, theta=th.value, tau_sq=t2.value, converged=bool(conv.value),
+                boundary_hit=bh.value, n_eval=ne.value)
+
+
 def lmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, theta_start: float = 0.0):
     """Random-intercept REML on provided bytes: design (n, p), outcome (n,), 0-based cluster ids (n,)."""
     n, p = design.shape

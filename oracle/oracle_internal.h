@@ -59,6 +59,11 @@ uint32_t mcpo_truth_theta(const mcp_cluster* c, int include_slopes, double* thet
 int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                const mcpo_re_term* terms, uint32_t n_terms, const double* theta_start, mcpo_gen_fit* f);
 
+/* GLM family kernel shared by fit_glm.c and fit_glmm.c: IRLS weight, working response, deviance contribution */
+void mcpo_fam_eval(int fam, double eta, double yi, double* w_out, double* z_out, double* dev_out);
+int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld, uint32_t p,
+                      uint32_t ncl, double theta0, const double* beta0, mcpo_gen_fit* f);
+
 /* OLS sufficient statistics + fit (fit_ols.c) */
 typedef struct mcpo_olsfit_t {
   uint32_t p;

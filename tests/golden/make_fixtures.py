@@ -198,8 +198,10 @@ def lower_case(spec: dict, columns):
     if "cluster" in spec and spec["cluster"] is not None:
         cl = spec["cluster"]
         icc = float(one(cl["ICC"]))
+        # family-aware latent-scale variance (ports/py/mcpower/model.py:1737-1758): logit carries pi^2 / 3
+        tau_sq = icc / (1.0 - icc) * (math.pi ** 2 / 3.0 if family == "logit" else 1.0)
         out["cluster"] = dict(n_clusters=int(one(cl["n_clusters"])), cluster_size=int(one(cl["cluster_size"])),
-                              icc=icc, tau_squared=icc / (1.0 - icc))
+                              icc=icc, tau_squared=tau_sq)
     return out
 
 
@@ -250,7 +252,7 @@ def make_cases():
 
 MIXED_CASES = ("lmm_crossed_a", "lmm_crossed_b", "lmm_nested_a", "lmm_nested_b", "lmm_crossed_nested_a", "lmm_slope_a",
                "lmm_slope_b", "lmm_multislope", "lmm_slope_crossed", "lmm_slope_crossed_extra_slopes",
-               "lmm_slope_nested_extra_slopes")
+               "lmm_slope_nested_extra_slopes", "glmm_intercept")
 
 
 def _one(v):
@@ -287,7 +289,7 @@ def make_mixed_cases():
             rel = {"Crossed": {"n_clusters": cnt}} if _one(e["kind"]) == "crossed" else {"NestedWithin": {"n_per_parent": cnt}}
             extras.append(dict(relation=rel, tau_squared=float(_one(e["tau_squared"])), slopes=_slope_list(e.get("slopes"))))
         low["cluster"]["extra_groupings"] = extras
-        low["lmer_re"] = _one(sp["lmer_re"])
+        low["lmer_re"] = _one(sp.get("lmer_re") or sp.get("glmer_re"))
         design = np.asarray(d["design"], dtype=np.float64)
         outcome = np.asarray(d["outcome"], dtype=np.float64)
         assert np.array_equal(design.astype(np.float32).astype(np.float64), design), name

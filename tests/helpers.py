@@ -42,12 +42,12 @@ def case_names(family=None):
 
 
 def mixed_case_names():
-    return sorted(json.load(open(os.path.join(GOLDEN, "mixed", "cases.json"))))
+    return sorted(n for n in json.load(open(os.path.join(GOLDEN, "mixed", "cases.json"))) if n.startswith("lmm_"))
 
 
 def load_case(name):
     """-> (SimulationSpec, base_seed, arrays dict, lowered-json dict)."""
-    z = np.load(os.path.join(GOLDEN, "mixed" if name.startswith("lmm_") else "", f"{name}.npz"))
+    z = np.load(os.path.join(GOLDEN, "mixed" if name.startswith(("lmm_", "glmm_")) else "", f"{name}.npz"))
     low = json.loads(str(z["spec_json"]))
     k = low["n_non_factor"]
     p = 1 + k + low["n_factor_dummies"] + len(low["interactions"])

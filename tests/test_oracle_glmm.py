@@ -1,0 +1,70 @@
+"""Oracle: clustered GLM = GLMM with a random intercept (Laplace), the clustered branch of the Glm arm
+(batch.rs:1575-1830).  Pinned to the reference's captured dataset `glmm_intercept.rds` (bit-exact data, with the
+family-aware latent variance tau^2 = ICC / (1 - ICC) * pi^2 / 3 of the ports) and to lme4's glmer on those bytes
+(`glmm_intercept.golden.rds`) inside the reference's own GLMM_TOL (tolerances.R:186-200)."""
+import numpy as np
+import pytest
+
+from helpers import BASE_SEED, load_case
+
+
+def test_glmm_dataset_is_reproduced_bit_exact(oracle):
+    spec, base_seed, a, low = load_case("glmm_intercept")
+    x, y, ids, _ = oracle.generate_sim_data_ids(spec, base_seed, 0, low["n"])
+    assert np.array_equal(ids, a["cluster_ids"]) and np.array_equal(x, a["design"]) and np.array_equal(y, a["outcome"])
+
+
+@pytest.mark.parametrize("start", ["blind", "truth"])
+def test_laplace_fit_matches_glmer_within_the_reference_gate(start, oracle):
+    spec, _, a, low = load_case("glmm_intercept")
+    kw = {} if start == "blind" else dict(theta_start=spec.cluster.tau_squared ** 0.5, beta_start=spec.effect_sizes)
+    r = oracle.glmm_fit(a["design"], a["outcome"], a["cluster_ids"], family="logit", **kw)
+    assert r["converged"] and r["boundary_hit"] == 0
+    # GLMM_TOL: beta_rel 1e-4 with an absolute floor of 1e-3 (glmer's own convergence tolerance)
+    assert np.all(np.abs(r["beta"] - a["golden_beta"]) <= np.maximum(1e-4 * np.abs(a["golden_beta"]), 1e-3))
+    assert abs(r["tau_sq"] - a["golden_vars"][0]) <= 2e-3 * a["golden_vars"][0]
+    # glmer reports Hessian-based z, the engine's default SE convention is "rx" (conditional on theta-hat): few percent apart
+    z = r["beta"] / r["se"]
+    assert np.all(np.abs(z / a["golden_z"] - 1.0) < 0.03)
+
+
+def test_this_optimum_is_below_glmers_on_an_independent_objective(oracle):
+    """The Laplace deviance restated with scipy (bounded scalar search per cluster) is lower at the oracle's
+    optimum than at glmer's reported one: the 4e-4 gap in beta is glmer stopping early, not a different objective."""
+    from scipy.optimize import minimize_scalar
+    from scipy.special import expit
+    spec, _, a, low = load_case("glmm_intercept")
+    x, y, ids = a["design"].astype(float), a["outcome"].astype(float), a["cluster_ids"]
+
+    def laplace(theta, beta):
+        eta0, tot = x @ beta, 0.0
+        for c in range(ids.max() + 1):
+            m = ids == c
+            e0, yc = eta0[m], y[m]
+            f = lambda u: -2.0 * np.sum(yc * np.log(expit(e0 + theta * u)) + (1 - yc) * np.log(1 - expit(e0 + theta * u))) + u * u
+            r = minimize_scalar(f, bounds=(-10, 10), method="bounded", options={"xatol": 1e-12})
+            mu = expit(e0 + theta * r.x)
+            tot += r.fun + np.log(theta * theta * (mu * (1 - mu)).sum() + 1.0)
+        return tot
+    r = oracle.glmm_fit(a["design"], a["outcome"], a["cluster_ids"], family="logit")
+    assert laplace(r["theta"], r["beta"]) < laplace(a["golden_vars"][0] ** 0.5, a["golden_beta"])
+
+
+def test_glmm_arm_run_batch(oracle):
+    """Decisions of run_batch equal refits of the same bytes; tau-hat^2 is reported on converged fits only; the grid
+    carries theta-hat; a test_formula subset fits the kept columns."""
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.target_indices = [1]
+    spec.scenario.truth_start = True
+    r = oracle.run_batch(spec, [300, 600], 24, BASE_SEED, n_threads=8)
+    assert r.converged.mean() > 0.9 and np.array_equal(r.joint_unc, r.joint_cor)
+    assert np.isnan(r.tau_squared_hat[r.converged == 0]).all() and np.isfinite(r.tau_squared_hat[r.converged == 1]).all()
+    crit = oracle.build_crit_table(spec, [300, 600])
+    for sim in range(4):
+        x, y, ids, _ = oracle.generate_sim_data_ids(spec, BASE_SEED, sim, 600)
+        f = oracle.glmm_fit(x[:300], y[:300], ids[:300], family="logit", theta_start=spec.cluster.tau_squared ** 0.5,
+                            beta_start=spec.effect_sizes)
+        if f["converged"] and r.converged[sim, 0]:
+            assert bool(f["z_sq"][1] > crit[0, 0]) == bool(r.uncorrected[sim, 0, 0])
+            assert abs(f["tau_sq"] - r.tau_squared_hat[sim, 0]) < 1e-9
+    assert r.uncorrected[:, 1, 0].mean() > 0.9          # beta 0.5 at n = 600: se ~ 0.11
