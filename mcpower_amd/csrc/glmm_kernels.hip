@@ -1,0 +1,520 @@
+// glmm_kernels.hip -- gfx950 kernel of the clustered GLM: a GLMM with a random intercept, fitted by the Laplace
+// approximation (the clustered branch of the Glm arm, crates/engine-core/src/batch.rs:1575-1830).
+//
+// The reference hands the fit to glmm 0.1.2 (`fit_on`, family Binomial{logit, probit} / Poisson{log}, nagq = 1,
+// Wald SE mode "rx"), out of tree; this is lme4's glmer(nAGQ = 1) objective
+//   d(theta, beta) = sum_i devres_i(mu_i(u~)) + |u~|^2 + sum_c log(theta^2 sum_{i in c} w_i + 1)
+// with the conditional modes u~ from per-cluster Fisher scoring, minimised jointly over (theta, beta) by the bounded
+// Nelder-Mead simplex -- the algorithm, constants and control flow of oracle/fit_glmm.c.
+//
+// ONE WAVEFRONT PER REPLICATE, design resident in LDS.  One evaluation has two phases of opposite shape:
+//   A. lane = row:      eta0_i = x_i' beta                                   (n x p MACs, written to LDS)
+//   B. lane = cluster:  the scalar Fisher-scoring loop for u_c over the cluster's rows (a random intercept decouples
+//                       the clusters), its deviance term, weight sum and log-determinant term;
+// the cluster terms are then summed in cluster order by every lane, so the objective -- and with it every branch of
+// the simplex -- is wave-uniform.  The Wald covariance ("rx": (X'WX - sum_c theta^2 a_c a_c' / (theta^2 sw_c + 1))^-1,
+// a_c = X_c' w_c) is formed once at the optimum.
+#include <hip/hip_runtime.h>
+#include "mcp_device.hpp"
+#include "mcp_params.hpp"
+#include "mcp_rows.hpp"
+#include "mcp_decide.hpp"
+#include "mcp_glm_family.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mcp {
+namespace {
+
+constexpr int QW = 64;
+constexpr uint32_t GLMM_MAX_EVAL = 8000;
+constexpr double GLMM_THETA_MAX = 32.0;
+constexpr double GLMM_THETA_ZERO = 1e-6;
+constexpr int GLMM_PIRLS_ITERS = 40;
+constexpr double GLMM_NEAR_ZERO = 1e-30;
+constexpr int GLMM_ROW = 10;  // simplex row stride (d = P + 1 <= 9)
+
+typedef __attribute__((address_space(3))) double gdd;
+typedef __attribute__((address_space(3))) float gdf;
+
+struct GlmmLds {
+  gdd *eta0, *tcl, *ucl, *swcl, *simplex, *fv, *tail;
+  gdf *design, *cluster_u;
+  float* st;
+};
+
+__device__ __forceinline__ void gq_sync() { __syncthreads(); }
+
+__device__ __forceinline__ double gq_wave_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < QW; m <<= 1) v += __shfl_xor(v, m, QW);
+  return v;
+}
+
+// Laplace deviance at par = (theta, beta); leaves the modes and weight sums of every cluster in LDS
+template <int P>
+__device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
+                                         uint32_t ncl, uint32_t n_pad) {
+  const uint32_t fam = prm.glm_family;
+  const double theta = par[0];
+  double beta[P];
+#pragma unroll
+  for (int c = 0; c < P; ++c) beta[c] = par[1 + c];
+  for (uint32_t i = lane; i < n; i += QW) {
+    double e = beta[0];
+#pragma unroll
+    for (int c = 1; c < P; ++c) e += (double)m.design[(size_t)(c - 1) * n_pad + i] * beta[c];
+    m.eta0[i] = e;
+  }
+  gq_sync();
+  const uint32_t cv = prm.cluster_v;
+  for (uint32_t c = lane; c < ncl; c += QW) {
+    const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
+    const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
+    const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
+    double u = 0.0, pd_prev = __builtin_inf(), sw = 0.0, dev = 0.0;
+    if (first < last) {
+      for (int it = 0; it < GLMM_PIRLS_ITERS; ++it) {
+        double swz = 0.0;
+        sw = 0.0;
+        dev = 0.0;
+        for (uint32_t i = first; i < last; i += step) {
+          const double e0 = m.eta0[i];
+          double w, wz, d;
+          fam_eval(fam, e0 + theta * u, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, d);
+          sw += w;
+          swz += wz - w * e0;  // w (z - eta0)
+          dev += d;
+        }
+        const double pd = dev + u * u;
+        if (it > 0 && __builtin_fabs(pd - pd_prev) <= 1e-13 * (__builtin_fabs(pd) + 1.0)) break;
+        double un = theta * swz / (theta * theta * sw + 1.0);
+        if (it > 0 && pd > pd_prev) un = 0.5 * (u + un);
+        pd_prev = pd;
+        if (un == u) break;
+        u = un;
+      }
+      m.tcl[c] = dev + u * u + log(theta * theta * sw + 1.0);
+    } else {
+      m.tcl[c] = 0.0;
+    }
+    m.ucl[c] = u;
+    m.swcl[c] = sw;
+  }
+  gq_sync();
+  double total = 0.0;
+  for (uint32_t c = 0; c < ncl; ++c) total += m.tcl[c];
+  gq_sync();
+  return (total < __builtin_inf() && total > -__builtin_inf()) ? total : __builtin_inf();
+}
+
+template <int P>
+__device__ __forceinline__ double glmm_f(const SimParams& prm, const GlmmLds& m, gdd* x, uint32_t lane, uint32_t n, uint32_t ncl,
+                                         uint32_t n_pad, uint32_t& n_eval) {
+  if (lane <= (uint32_t)P) {
+    double v = x[lane];
+    if (lane == 0u) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+    else v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
+    x[lane] = v;
+  }
+  gq_sync();
+  ++n_eval;
+  return glmm_eval<P>(prm, m, x, lane, n, ncl, n_pad);
+}
+
+// one Nelder-Mead run from simplex row 0 with initial edge `step`; the best point ends in row 0
+template <int P>
+__device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const GlmmLds m, double step, double ftol, double xtol,
+                                                uint32_t lane, uint32_t n, uint32_t ncl, uint32_t n_pad, uint32_t& n_eval) {
+  constexpr uint32_t d = P + 1;
+  gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe
+  gdd* fv = m.fv;
+  gdd* cen = sx + (size_t)(d + 1u) * GLMM_ROW;
+  gdd* xr = cen + GLMM_ROW;
+  gdd* xe = xr + GLMM_ROW;
+  const double inf = __builtin_inf();
+  const double f0 = glmm_f<P>(prm, m, sx, lane, n, ncl, n_pad, n_eval);
+  if (lane == 0u) fv[0] = f0;
+  for (uint32_t i = 0; i < d; ++i) {
+    gdd* v = sx + (size_t)(i + 1u) * GLMM_ROW;
+    if (lane < d) v[lane] = sx[lane] + (lane == i ? step : 0.0);
+    gq_sync();
+    const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, n_eval);
+    if (lane == 0u) fv[i + 1u] = fi;
+  }
+  gq_sync();
+  while (n_eval < GLMM_MAX_EVAL) {
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t i = 1; i <= d; ++i) {
+      if (fv[i] < fv[lo]) lo = i;
+      if (fv[i] > fv[hi]) hi = i;
+    }
+    uint32_t nh = lo;
+    for (uint32_t i = 0; i <= d; ++i)
+      if (i != hi && fv[i] > fv[nh]) nh = i;
+    double size = 0.0;
+    for (uint32_t i = 0; i <= d; ++i)
+      for (uint32_t k = 0; k < d; ++k) {
+        const double dd = __builtin_fabs(sx[(size_t)i * GLMM_ROW + k] - sx[(size_t)lo * GLMM_ROW + k]);
+        size = dd > size ? dd : size;
+      }
+    if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
+    const double flo = fv[lo], fhi = fv[hi], fnh = fv[nh];
+    gq_sync();
+    if (lane < d) {
+      double s = 0.0;
+      for (uint32_t i = 0; i <= d; ++i)
+        if (i != hi) s += sx[(size_t)i * GLMM_ROW + lane];
+      const double c = s / (double)d;
+      cen[lane] = c;
+      xr[lane] = c + (c - sx[(size_t)hi * GLMM_ROW + lane]);
+    }
+    gq_sync();
+    const double fr = glmm_f<P>(prm, m, xr, lane, n, ncl, n_pad, n_eval);
+    gdd* worst = sx + (size_t)hi * GLMM_ROW;
+    if (fr < flo) {
+      if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
+      gq_sync();
+      const double fe = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, n_eval);
+      if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
+      if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
+    } else if (fr < fnh) {
+      if (lane < d) worst[lane] = xr[lane];
+      if (lane == 0u) fv[hi] = fr;
+    } else {
+      const bool outside = fr < fhi;
+      if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
+      gq_sync();
+      const double fc = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, n_eval);
+      if (fc < (outside ? fr : fhi)) {
+        if (lane < d) worst[lane] = xe[lane];
+        if (lane == 0u) fv[hi] = fc;
+      } else {
+        for (uint32_t i = 0; i <= d; ++i) {
+          if (i == lo) continue;
+          gdd* v = sx + (size_t)i * GLMM_ROW;
+          if (lane < d) v[lane] = sx[(size_t)lo * GLMM_ROW + lane] + 0.5 * (v[lane] - sx[(size_t)lo * GLMM_ROW + lane]);
+          gq_sync();
+          const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, n_eval);
+          if (lane == 0u) fv[i] = fi;
+          gq_sync();
+        }
+      }
+    }
+    gq_sync();
+  }
+  uint32_t lo = 0;
+  for (uint32_t i = 1; i <= d; ++i)
+    if (fv[i] < fv[lo]) lo = i;
+  const double best = fv[lo];
+  gq_sync();
+  double keep = 0.0;
+  if (lane < d) keep = sx[(size_t)lo * GLMM_ROW + lane];
+  gq_sync();
+  if (lane < d) sx[lane] = keep;
+  gq_sync();
+  return best;
+}
+
+template <int P>
+__global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ double lds_q[];
+  const SimParams& prm = *pp;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lsim = blockIdx.x;
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
+  const uint32_t ncl_max = prm.n_clusters_max, ncl_pad = (ncl_max + 1u) & ~1u;
+  const uint32_t cv = prm.cluster_v;
+  constexpr uint32_t d = P + 1;
+  GlmmLds m;
+  {
+    gdd* q = (gdd*)lds_q;
+    m.eta0 = q; q += n_pad;
+    m.tcl = q; q += ncl_pad;
+    m.ucl = q; q += ncl_pad;
+    m.swcl = q; q += ncl_pad;
+    m.simplex = q; q += (size_t)(d + 4u) * GLMM_ROW;
+    m.fv = q; q += d + 1u + (d & 1u ? 0u : 1u);
+    m.tail = q; q += 8 + 64 + 64 + 64 + 8 + 8;
+    gdf* f = (gdf*)q;
+    m.design = f; f += (size_t)P * n_pad;
+    m.cluster_u = f; f += ncl_pad;
+    m.st = (float*)f + lane;
+  }
+  // ---- cluster random intercepts (data_gen.rs:146-161), then the rows: the effect sits inside the link ----
+  for (uint32_t c = lane; c < ncl_max; c += QW) {
+    const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
+    m.cluster_u[c] = (float)((double)z * prm.tau);
+  }
+  gq_sync();
+  RowCtx<P> cx;
+  row_ctx_init<P, true>(prm, cx);
+  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += QW) {
+    stage_group<P, QW, 1, false>(prm, k0, k1, ctr, m.st, 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t rr = 4u * ctr + r;
+      if (rr < max_n) {
+        const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
+        float x[P], y;
+        build_row<P, true, QW, 1, false>(prm, cx, k0, k1, m.st, r, rr, x, y, (double)m.cluster_u[cid < ncl_max ? cid : 0u], nullptr);
+#pragma unroll
+        for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
+        m.design[(size_t)(P - 1) * n_pad + rr] = y;
+      }
+    }
+  }
+  gq_sync();
+
+  bool has_prev = false;
+  double carry = 0.0;
+  const uint32_t nt = prm.n_tests;
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n = prm.ns[g];
+    const uint32_t ncl = prm.cluster_fixed_clusters ? cv : (n + cv - 1u) / cv;
+    gdd* x0 = m.simplex;
+    if (lane <= (uint32_t)P) {
+      double v;
+      if (lane == 0u) {
+        v = has_prev ? carry : (prm.truth_start ? prm.tau : 1.0);  // carried theta-hat / truth / blind THETA0
+        if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;
+      } else {
+        v = prm.beta[lane - 1u];                                    // beta starts at the truth, unconditionally
+      }
+      x0[lane] = v;
+    }
+    gq_sync();
+    uint32_t n_eval = 0;
+    double best = glmm_nelder_mead<P>(prm, m, 0.25, 1e-9, 1e-6, lane, n, ncl, n_pad, n_eval);
+    for (int restart = 0; restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
+      const double prev = best;
+      best = glmm_nelder_mead<P>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, n_eval);
+      if (!(prev - best > 1e-8)) break;
+    }
+    double cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, n_eval);
+    {
+      const double keep = x0[0];
+      if (keep != 0.0 && keep <= 1e-4) {  // snap onto the boundary when that costs no deviance
+        gq_sync();
+        if (lane == 0u) x0[0] = 0.0;
+        gq_sync();
+        const double f0 = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, n_eval);
+        if (f0 <= cur + 1e-8) cur = f0;
+        else {
+          gq_sync();
+          if (lane == 0u) x0[0] = keep;
+          gq_sync();
+        }
+      }
+    }
+    cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, n_eval);  // modes and weight sums of the final point
+    const double theta = x0[0];
+    bool ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
+    // ---- RX'RX at the optimum: lane = cluster accumulates X_c'W X_c and a_c = X_c'w_c, wave sums the Schur terms ----
+    double A[P * (P + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = 0.0;
+    for (uint32_t c = lane; c < ncl; c += QW) {
+      const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
+      const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
+      const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
+      double a[P], loc[P * (P + 1) / 2];
+#pragma unroll
+      for (int i = 0; i < P; ++i) a[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < P * (P + 1) / 2; ++i) loc[i] = 0.0;
+      const double uc = m.ucl[c];
+      for (uint32_t i = first; i < last; i += step) {
+        double w, wz, dv;
+        fam_eval(prm.glm_family, m.eta0[i] + theta * uc, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
+        double xd[P];
+        xd[0] = 1.0;
+#pragma unroll
+        for (int r = 1; r < P; ++r) xd[r] = (double)m.design[(size_t)(r - 1) * n_pad + i];
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+          a[r] += w * xd[r];
+#pragma unroll
+          for (int s = 0; s <= r; ++s) loc[idx++] += w * xd[r] * xd[s];
+        }
+      }
+      const double den = theta * theta * m.swcl[c] + 1.0;
+      int idx = 0;
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+#pragma unroll
+        for (int s = 0; s <= r; ++s) {
+          A[idx] += loc[idx] - theta * theta * a[r] * a[s] / den;
+          ++idx;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]);
+    double Lx[P][P];
+    {
+      int idx = 0;
+      double Af[P][P];
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+#pragma unroll
+        for (int s = 0; s <= r; ++s) Af[r][s] = A[idx++];
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        double dd = Af[j][j];
+#pragma unroll
+        for (int t = 0; t < j; ++t) dd -= Lx[j][t] * Lx[j][t];
+        ok = ok && (dd > 0.0) && (dd < __builtin_inf());
+        Lx[j][j] = __builtin_sqrt(dd);
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+          double v = Af[i][j];
+#pragma unroll
+          for (int t = 0; t < j; ++t) v -= Lx[i][t] * Lx[j][t];
+          Lx[i][j] = v / Lx[j][j];
+        }
+      }
+    }
+    bool conv = ok;
+    const bool at_upper = theta > GLMM_THETA_MAX - 1e-3;
+    const uint32_t pinned = (conv && theta < GLMM_THETA_ZERO) ? 1u : 0u;
+    const uint32_t bh = !conv ? 0u : (at_upper ? 2u : pinned);
+    if (at_upper) conv = false;
+    if (conv) {
+      carry = theta;
+      has_prev = true;
+    }
+    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions ----
+    double beta[P];
+#pragma unroll
+    for (int c = 0; c < P; ++c) beta[c] = x0[1 + c];
+    const double* crow = prm.crit + (size_t)g * prm.crit_stride;
+    double tsq[MAX_T_WAVE];
+    double U[MAX_T_WAVE][P];
+#pragma unroll
+    for (int t = 0; t < MAX_T_WAVE; ++t) {
+      tsq[t] = __builtin_nan("");
+#pragma unroll
+      for (int i = 0; i < P; ++i) U[t][i] = 0.0;
+      if ((uint32_t)t < nt && conv) {
+        const double* c = prm.contrast + t * MAX_P;
+        double est = 0.0, nq = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          est = __builtin_fma(c[i], beta[i], est);
+          double acc = c[i];
+#pragma unroll
+          for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i][q], U[t][q], acc);
+          U[t][i] = acc / Lx[i][i];
+          nq = __builtin_fma(U[t][i], U[t][i], nq);
+        }
+        if (nq > GLMM_NEAR_ZERO && nq < __builtin_inf()) tsq[t] = est * est / nq;
+      }
+    }
+    bool joint_sig = false;
+    if (conv && nt != 0u) {
+      double Lc[MAX_T_WAVE][MAX_T_WAVE], cj[MAX_T_WAVE];
+      bool jok = true;
+      double qsum = 0.0;
+#pragma unroll
+      for (int j = 0; j < MAX_T_WAVE; ++j) {
+        if ((uint32_t)j < nt) {
+          double dd = 0.0;
+#pragma unroll
+          for (int i = 0; i < P; ++i) dd = __builtin_fma(U[j][i], U[j][i], dd);
+#pragma unroll
+          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j][t], Lc[j][t], dd);
+          jok = jok && (dd > 0.0);
+          Lc[j][j] = __builtin_sqrt(dd);
+#pragma unroll
+          for (int i2 = j + 1; i2 < MAX_T_WAVE; ++i2) {
+            if ((uint32_t)i2 < nt) {
+              double vv = 0.0;
+#pragma unroll
+              for (int i = 0; i < P; ++i) vv = __builtin_fma(U[i2][i], U[j][i], vv);
+#pragma unroll
+              for (int t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2][t], Lc[j][t], vv);
+              Lc[i2][j] = vv / Lc[j][j];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAX_T_WAVE; ++i) {
+        if ((uint32_t)i < nt) {
+          const double* c = prm.contrast + i * MAX_P;
+          double vv = 0.0;
+#pragma unroll
+          for (int q = 0; q < P; ++q) vv = __builtin_fma(c[q], beta[q], vv);
+#pragma unroll
+          for (int t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i][t], cj[t], vv);
+          cj[i] = vv / Lc[i][i];
+          qsum = __builtin_fma(cj[i], cj[i], qsum);
+        }
+      }
+      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > prm.joint_crit_k[nt]);
+    }
+    uint32_t unc_bits = 0, cor_bits = 0;
+    decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
+    if (!conv) {
+      unc_bits = 0;
+      cor_bits = 0;
+    }
+    if (lane == 0u) {
+      const size_t cell = (size_t)(prm.out_base + lsim) * prm.n_grid + g;
+#pragma unroll
+      for (int t = 0; t < MAX_T_WAVE; ++t)
+        if ((uint32_t)t < nt) {
+          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
+          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
+        }
+      prm.conv[cell] = conv ? 1 : 0;
+      prm.boundary[cell] = (uint8_t)bh;
+      prm.joint[cell] = joint_sig ? 1 : 0;
+      if (prm.pinned) prm.pinned[cell] = (uint16_t)pinned;
+      if (prm.tau_hat) prm.tau_hat[cell] = conv ? theta * theta : __builtin_nan("");
+      if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1750-1753
+      if (prm.stat && g == 0u) {
+#pragma unroll
+        for (int t = 0; t < MAX_T_WAVE; ++t)
+          if ((uint32_t)t < nt) prm.stat[(size_t)(prm.out_base + lsim) * nt + t] = tsq[t];
+      }
+    }
+    gq_sync();
+  }
+}
+
+}  // namespace
+
+size_t glmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max) {
+  const size_t n_pad = ((size_t)max_n + 3u) & ~(size_t)3u;
+  const size_t ncl_pad = ((size_t)ncl_max + 1u) & ~(size_t)1u;
+  const size_t d = (size_t)P + 1;
+  const size_t dbl = n_pad + 3 * ncl_pad + (d + 4) * GLMM_ROW + d + 2 + (8 + 64 + 64 + 64 + 8 + 8);
+  const size_t flt = (size_t)P * n_pad + ncl_pad + (size_t)4 * (P + 1) * QW;
+  return dbl * 8 + flt * 4 + 64;
+}
+
+hipError_t launch_glmm(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, hipStream_t st) {
+  const size_t lds = glmm_lds_bytes(P, max_n, ncl_max);
+  const dim3 block(QW), grid(n_sims);
+#define GQ(PP)                                                                                                         \
+  case PP: {                                                                                                           \
+    if (lds > 48 * 1024) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)glmm_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return e;                                                                                   \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((glmm_kernel<PP>), grid, block, lds, st, d_prm);                                                \
+  } break;
+  switch (P) {
+    GQ(2) GQ(3) GQ(4) GQ(5) GQ(6) GQ(7) GQ(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef GQ
+  return hipGetLastError();
+}
+
+}  // namespace mcp

@@ -39,6 +39,8 @@ hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32
                           bool reduced, bool scen, hipStream_t st);
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 size_t lmm_rec_fields(int P, uint32_t ncl_max);
+hipError_t launch_glmm(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, hipStream_t st);
+size_t glmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 hipError_t launch_lmm_general_scen(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 size_t lmg_lds_bytes(const SimParams& prm);
@@ -69,7 +71,7 @@ struct Arena {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Buf slots[29];
+  Buf slots[30];
   Buf pinned[2];  // host staging: [0] the upload blob, [1] the counters coming back
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
@@ -132,7 +134,7 @@ struct Ticket {
 thread_local Ticket g_tickets[MAX_IN_FLIGHT];
 thread_local hipStream_t g_upload_stream = nullptr;  // a batch in flight uploads its tables beside the running kernel
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS, S_PINNED };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS, S_PINNED, S_TAU_HAT };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts, Arena* extra = nullptr) {
   int n = 0;
@@ -267,7 +269,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   const bool reduced = prm.red_active && !glm;             // reduced-design OLS kernel, flags folded afterwards
   // RED variants of the wave-per-replicate kernels; their general-path (scenario) variants build on them
   // (probit / Poisson run on the superset kernel as well: only the logit kernels are family-specialised)
-  const bool glm_reduced = (prm.red_active || prm.scen_active || (!mle && prm.glm_family != 0u)) && glm;
+  const bool glm_reduced = (prm.red_active || prm.scen_active || (!mle && prm.glm_family != 0u)) && glm && !prm.glmm_active;
   if (reduced && (flags & MCP_PIPELINE_STAGED))
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds or more than 8 design columns / tests");
   const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
@@ -280,11 +282,17 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   mcp::counter_layout(spec, &layout);
   out->layout = layout;
   out->n_sims = n_sims; out->n_sample_sizes = n_ns; out->n_targets = nt; out->n_factors = spec->n_factors;
-  out->n_posthoc_contrasts = npc; out->n_variance_components = spec->estimator == MCP_EST_MLE ? 1u : 0u;
+  out->n_posthoc_contrasts = npc;
+  out->n_variance_components = (spec->estimator == MCP_EST_MLE || (spec->estimator == MCP_EST_GLM && spec->cluster.present)) ? 1u : 0u;
   out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
   const bool lmg = mle && prm.lmg_active;  // random slopes / extra groupings: the general mixed-model kernel
+  const bool glmm = prm.glmm_active != 0u;  // clustered GLM: random-intercept GLMM kernel (writes flags like the Mle arm)
+  if (glmm && mcp::glmm_lds_bytes((int)P, prm.max_n, prm.n_clusters_max) > 158u * 1024u) {
+    mcp_free_result(out);
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: clustered GLM design does not fit one wave's LDS budget");
+  }
   if (lmg && mcp::lmg_lds_bytes(prm) > 158u * 1024u) {
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the random-effect structure does not fit one wave's LDS budget");
@@ -293,7 +301,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: LMM design + cluster sums do not fit one wave's LDS budget");
   }
-  if (glm && !mle && mcp::glm_lds_bytes((int)P, prm.max_n) > 150u * 1024u) {
+  if (glm && !mle && !glmm && mcp::glm_lds_bytes((int)P, prm.max_n) > 150u * 1024u) {
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: GLM design (n x p f32) does not fit one wave's LDS budget");
   }
@@ -383,8 +391,10 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   uint32_t* d_lmm_flags = nullptr;
   const uint32_t lmm_stride = (chunk + 63u) & ~63u;
   uint16_t* d_pinned = nullptr;
-  if (lmg) DEV_TRY(ar.get(S_PINNED, (cells + 1) * sizeof(uint16_t), (void**)&d_pinned));
-  if (mle) {
+  double* d_tau_hat = nullptr;
+  if (lmg || glmm) DEV_TRY(ar.get(S_PINNED, (cells + 1) * sizeof(uint16_t), (void**)&d_pinned));
+  if (glmm) DEV_TRY(ar.get(S_TAU_HAT, (cells + 1) * sizeof(double), (void**)&d_tau_hat));
+  if (mle || glmm) {
     DEV_TRY(ar.get(S_BOUNDARY, cells + 1, (void**)&d_bh));
     DEV_TRY(ar.get(S_JOINT, cells + 1, (void**)&d_joint));
   }
@@ -464,6 +474,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   prm.ctr_excl_sparse = layout.excl_sparse; prm.ctr_excl_sep = layout.excl_sep;
   prm.lmm_rec = d_lmm_rec; prm.lmm_rec_flags = d_lmm_flags; prm.lmm_rec_stride = lmm_stride;
   prm.pinned = d_pinned;
+  prm.tau_hat = d_tau_hat;
   prm.tile = d_tile;
   prm.tile_sims = chunk;
   prm.scen_L = d_scen_L;
@@ -498,7 +509,8 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (lmg && scen) DEV_TRY(mcp::launch_lmm_general_scen((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
+      if (glmm) DEV_TRY(mcp::launch_glmm((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, st));
+      else if (lmg && scen) DEV_TRY(mcp::launch_lmm_general_scen((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (lmg) DEV_TRY(mcp::launch_lmm_general((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));
       else DEV_TRY(mcp::launch_glm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, spec->n_factors > 0, glm_reduced, scen, prm.glm_family == 0u, st));
@@ -571,12 +583,13 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
       out->overall = host_alloc<uint8_t>(cells);
       DEV_TRY(hipMemcpyAsync(out->overall, d_ov, cells, hipMemcpyDeviceToHost, st));
     }
-    if (mle) {
+    if (mle || glmm) {
       DEV_TRY(hipMemcpyAsync(out->boundary_hit, d_bh, cells, hipMemcpyDeviceToHost, st));
       DEV_TRY(hipMemcpyAsync(out->joint_unc, d_joint, cells, hipMemcpyDeviceToHost, st));
       DEV_TRY(hipMemcpyAsync(out->joint_cor, d_joint, cells, hipMemcpyDeviceToHost, st));
     }
-    if (lmg) {  // pinned-component bits travel as u16 and are widened below
+    if (glmm) DEV_TRY(hipMemcpyAsync(out->tau_squared_hat, d_tau_hat, cells * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (lmg || glmm) {  // pinned-component bits travel as u16 and are widened below
       h_pinned.resize(cells);
       DEV_TRY(hipMemcpyAsync(h_pinned.data(), d_pinned, cells * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
     }
@@ -595,9 +608,9 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   }
   DEV_TRY(hipStreamSynchronize(st));
   std::memcpy(out->counters, h_ctr, (size_t)n_ctr * sizeof(uint64_t));
-  if (mle && per_sim)  // pinned_components: bit k = diagonal variance component k pinned at 0 (spec.rs:566-573)
+  if ((mle || glmm) && per_sim)  // pinned_components: bit k = diagonal variance component k pinned at 0 (spec.rs:566-573)
     for (size_t i = 0; i < cells; ++i)
-      out->pinned_components[i] = lmg ? (uint64_t)h_pinned[i] : (out->boundary_hit[i] == 1 ? 1ull : 0ull);
+      out->pinned_components[i] = (lmg || glmm) ? (uint64_t)h_pinned[i] : (out->boundary_hit[i] == 1 ? 1ull : 0ull);
 #undef DEV_TRY
   rc = finish_timing(ar, ev_begin, ev_end, launched, ev_per_chunk, glm, reduced, staged, out);
   if (rc) mcp_free_result(out);

@@ -244,9 +244,14 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       return unsupported("Count outcomes under a non-log link");
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
-  if (spec->cluster.present && spec->estimator == MCP_EST_GLM) return unsupported("clustered GLM (GLMM: Laplace / AGQ fits)");
+  const bool glmm = spec->cluster.present && spec->estimator == MCP_EST_GLM;  // batch.rs:1575-1830
+  if (glmm) {
+    if (lmm_general) return unsupported("clustered GLM with random slopes / extra groupings (random intercept only)");
+    if (spec->n_fit_columns) return unsupported("clustered GLM together with a test_formula column subset");
+    if (spec->n_between_var_indices) return unsupported("clustered GLM together with cluster-level predictors");
+  }
   if (lmm_general) {
-    if (spec->estimator != MCP_EST_MLE) return unsupported("random slopes / extra groupings outside the Mle estimator");
+    if (spec->estimator != MCP_EST_MLE) return unsupported("random slopes / extra groupings outside the Mle estimator (clustered GLM: random intercept only)");
     if (spec->n_fit_columns) return unsupported("random slopes / extra groupings together with a test_formula column subset");
     if (spec->n_between_var_indices) return unsupported("random slopes / extra groupings together with cluster-level predictors");
     if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");
@@ -706,6 +711,12 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   // intercept of a row's cluster is re-drawn per row on the reduced-design kernel
   const bool ols_cluster = spec->cluster.present && spec->estimator == MCP_EST_OLS;
   prm.red_active = (npc > 0 || test_reduces || any_excl_possible || wide || ols_cluster) ? 1u : 0u;
+  if (glmm) {
+    prm.glmm_active = 1;
+    prm.red_active = 0;  // no factor exclusion on clustered specs (batch.rs:1583)
+    if (prm.scen_active) return unsupported("clustered GLM on the general (scenario / upload) data path");
+    if (prm.lme_re_dist != 0u || prm.lme_icc_noise_sd > 0.0) return unsupported("clustered GLM with scenario random-effect knobs");
+  }
   if (prm.lmg_active && prm.red_active)
     return unsupported("random slopes / extra groupings together with a factor that can be excluded per replicate (sparse levels or sampled proportions)");
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))

@@ -1,0 +1,81 @@
+"""Device vs oracle on the clustered GLM (random-intercept GLMM, Laplace): same objective, same simplex, the
+family kernel differs in the last bits (short exp / log1p on the device, glibc in the oracle), so decisions agree
+replicate by replicate up to a rare borderline case and statistics to ~1e-6."""
+import numpy as np
+import pytest
+
+from helpers import BASE_SEED, load_case
+from mcpower_amd import spec as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(dev, ora, n_sims, stat_dev=None, stat_ora=None, slack=1):
+    same = ((dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+            & (dev.boundary_hit == ora.boundary_hit).all(axis=1) & (dev.joint_unc == ora.joint_unc).all(axis=1)
+            & (dev.pinned_components == ora.pinned_components).all(axis=1))
+    assert same.sum() >= n_sims - slack, np.flatnonzero(~same)
+    both = (dev.converged == 1) & (ora.converged == 1)
+    assert np.allclose(dev.tau_squared_hat[both], ora.tau_squared_hat[both], rtol=1e-4, atol=1e-7)
+    assert np.isnan(dev.tau_squared_hat[dev.converged == 0]).all()
+    if stat_dev is not None:
+        ok = both[:, 0] & same
+        assert np.allclose(stat_dev[ok], stat_ora[ok], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("truth", [True, False])
+def test_glmm_logit_matches_oracle(truth, engine, oracle):
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.scenario.truth_start = truth
+    dev, stat = engine.run_batch_st_capture(spec, [300, 600], 64, BASE_SEED)
+    ora = oracle.run_batch(spec, [300, 600], 64, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.95 and dev.shape.n_variance_components == 1
+    _compare(dev, ora, 64, stat, ora.stat_capture)
+
+
+@pytest.mark.parametrize("family", ["probit", "poisson"])
+def test_glmm_probit_and_poisson_match_oracle(family, engine, oracle):
+    spec, _, a, low = load_case("glmm_intercept")
+    if family == "probit":
+        spec.link = S.LinkKind.Probit
+        spec.effect_sizes = [-0.52, 0.30]
+        spec.cluster.tau_squared = 0.25
+    else:
+        spec.outcome_kind = S.OutcomeKind.Count
+        spec.effect_sizes = [0.7, 0.15]
+        spec.cluster.tau_squared = 0.10
+    spec.scenario.truth_start = True
+    dev = engine.run_batch(spec, [600], 48, BASE_SEED)
+    ora = oracle.run_batch(spec, [600], 48, BASE_SEED, n_threads=8)
+    assert dev.converged.mean() > 0.9
+    _compare(dev, ora, 48)
+
+
+def test_glmm_two_predictors_fixed_size_clusters_counters_and_shards(engine, oracle):
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.n_non_factor = 2
+    spec.correlation = [1.0, 0.3, 0.3, 1.0]
+    spec.var_types, spec.var_params = [S.Distribution.Normal] * 2, [0.0, 0.0]
+    spec.effect_sizes = [-0.85, 0.5, 0.3]
+    spec.target_indices = [1, 2]
+    spec.cluster = S.ClusterSpec(sizing=("FixedSize", 15), tau_squared=0.6)
+    spec.correction_method = S.CorrectionMethod.Holm
+    spec.scenario.truth_start = True
+    dev = engine.run_batch(spec, [300, 450], 48, BASE_SEED)
+    ora = oracle.run_batch(spec, [300, 450], 48, BASE_SEED, n_threads=8)
+    _compare(dev, ora, 48)
+    assert np.array_equal(dev.corrected[dev.converged.all(axis=1)].shape, ora.corrected[ora.converged.all(axis=1)].shape)
+    red = engine.run_batch(spec, [300, 450], 48, BASE_SEED, per_sim=False)
+    assert np.array_equal(red.counters, dev.counters)
+    left = engine.run_batch(spec, [300, 450], 30, BASE_SEED, per_sim=False)
+    right = engine.run_batch(spec, [300, 450], 18, BASE_SEED, per_sim=False, sim_offset=30)
+    assert np.array_equal(left.counters + right.counters, dev.counters)
+
+
+def test_glmm_refuses_what_it_cannot_do(engine):
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.cluster.slopes = [{"column": 0, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": []}]
+    spec.cluster_slope_design_cols = [1]
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, [600], 4, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "random intercept only" in str(e.value)
