@@ -170,6 +170,13 @@ def preset(name: str) -> S.ScenarioPerturbations:
     raise KeyError(name)
 
 
+def spec_glmm() -> S.SimulationSpec:
+    """Reference case glmm_intercept (validation/formulas.R:1092-1100): logit, y ~ x1 + (1 | g), 30 clusters x 20."""
+    spec = load_case("glmm_intercept")[0]
+    spec.scenario.truth_start = True
+    return spec
+
+
 def spec_lmm_slope() -> S.SimulationSpec:
     """Reference case lmm_slope_a (validation/formulas.R:461-469): y ~ x1 + (1 + x1 | g), 24 clusters x 20."""
     spec = load_case("lmm_slope_a")[0]

@@ -382,3 +382,38 @@ def test_find_power_mixed_contract_device_equals_oracle(engine, oracle):
     for t in range(2):
         assert abs(d["power_uncorrected"][0][t] - o["power_uncorrected"][0][t]) <= 1.0 / 200 + 1e-12
     assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 1.0 / 200 + 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# clustered binary outcome: the Glm estimator with a ClusterSpec is a random-intercept GLMM
+# ---------------------------------------------------------------------------------------------
+def _glmm_contract():
+    c = _contract()
+    c["generation"]["cluster"] = {"sizing": {"FixedClusters": {"n_clusters": 20}},
+                                  "tau_squared": 0.25 * math.pi ** 2 / 3.0, "slopes": [], "extra_groupings": []}
+    c["estimator"] = "glm"
+    c["outcome"]["kind"] = "binary"
+    c["outcome"]["intercept"] = math.log(0.3 / 0.7)
+    c["outcome"]["coefficients"] = [0.0, 0.50, 0.30]
+    c["test"]["targets"] = [{"kind": "marginal", "term": 1}, {"kind": "marginal", "term": 2}]
+    return c
+
+
+def test_find_power_clustered_glm_on_the_oracle(oracle):
+    r = _engine.find_power(_pack(_glmm_contract()), 400, 40, 2137, None, _runner=_oracle_runner(oracle))
+    sc = r["scenarios"]["optimistic"] if "scenarios" in r else r
+    assert sc["n_sims"] == 40 and 0.5 < sc["power_uncorrected"][0][0] <= 1.0 and sc["convergence_rate"][0] > 0.9
+    ex = sc["estimator_extras"]
+    assert ex["estimator"] == "glm" and 0.2 < ex["tau_squared_hat_mean"] < 2.0   # truth: 0.25 * pi^2 / 3 = 0.82
+
+
+@pytest.mark.gpu
+def test_find_power_clustered_glm_device_equals_oracle(engine, oracle):
+    blob = _pack(_glmm_contract())
+    dev = _engine.find_power(blob, 400, 200, 2137, None)
+    ora = _engine.find_power(blob, 400, 200, 2137, None, _runner=_oracle_runner(oracle))
+    d = dev["scenarios"]["optimistic"] if "scenarios" in dev else dev
+    o = ora["scenarios"]["optimistic"] if "scenarios" in ora else ora
+    for t in range(2):
+        assert abs(d["power_uncorrected"][0][t] - o["power_uncorrected"][0][t]) <= 1.0 / 200 + 1e-12
+    assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 1.0 / 200 + 1e-12
