@@ -139,6 +139,10 @@ def validate_contract(c: dict) -> None:
     test_design = c.get("design_test") or c["design_generation"]
     test_terms = _terms(test_design)
 
+    # 25 nagq backstop (engine-contract/src/error.rs:67-73): odd, 1..=25
+    nagq = int(c.get("nagq", 1))
+    if nagq < 1 or nagq > 25 or nagq % 2 == 0:
+        raise ContractError(f"nagq must be odd and in 1..=25; got {nagq}")
     # 01 coefficient length
     if len(outcome["coefficients"]) != len(gen_terms):
         raise ContractError(f"coefficients.len ({len(outcome['coefficients'])}) must equal "
@@ -360,6 +364,13 @@ def report_targets_and_contrasts(c: dict):
 def contract_to_simulation_spec(c: dict) -> S.SimulationSpec:
     """`contract_to_simulation_spec` (contract_adapter.rs:74-230)."""
     validate_contract(c)
+    # wald_se / nagq only steer the clustered-GLM estimator (estimator.rs:58-66).  The device fits it by the Laplace
+    # approximation with the "rx" Wald SE -- the contract's defaults; the opt-in modes are refused, not approximated.
+    if c.get("estimator") == "glm" and c["generation"].get("cluster") is not None:
+        if int(c.get("nagq", 1)) != 1:
+            raise S.EngineError(S.Status.Unsupported, "unsupported on the device path: adaptive Gauss-Hermite quadrature (nagq > 1) for a clustered GLM")
+        if str(c.get("wald_se", "rx")) != "rx":
+            raise S.EngineError(S.Status.Unsupported, "unsupported on the device path: Wald SE mode 'hessian' for a clustered GLM")
     cols = _Columns(c)
     gen = c["generation"]
     gen_terms = _terms(c["design_generation"])

@@ -417,3 +417,21 @@ def test_find_power_clustered_glm_device_equals_oracle(engine, oracle):
     for t in range(2):
         assert abs(d["power_uncorrected"][0][t] - o["power_uncorrected"][0][t]) <= 1.0 / 200 + 1e-12
     assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 1.0 / 200 + 1e-12
+
+
+def test_clustered_glm_opt_in_modes_are_refused_not_approximated():
+    c = _glmm_contract()
+    c["nagq"] = 7
+    with pytest.raises(S.EngineError) as e:
+        K.contract_to_simulation_spec(c)
+    assert e.value.status == S.Status.Unsupported and "nagq" in str(e.value)
+    c = _glmm_contract()
+    c["wald_se"] = "hessian"
+    with pytest.raises(S.EngineError) as e:
+        K.contract_to_simulation_spec(c)
+    assert e.value.status == S.Status.Unsupported and "hessian" in str(e.value)
+    c = _glmm_contract()
+    c["nagq"] = 4
+    with pytest.raises(K.ContractError) as e:
+        K.contract_to_simulation_spec(c)
+    assert "nagq must be odd" in str(e.value)
