@@ -262,7 +262,10 @@ def validate_contract(c: dict) -> None:
         raise ContractError("estimator Glm requires outcome.kind == Binary or Count")
     if outcome.get("link") is not None and okind != S.OutcomeKind.Binary:
         raise ContractError("outcome.link == Some(Probit) requires outcome.kind == Binary")
-    if c["scenario"].get("lme") is not None and est != S.EstimatorSpec.Mle:
+    # invariant 13 (validate.rs:458-474): the random-effect knobs need an estimator that draws random effects --
+    # Mle, or Glm on clustered data (the GLMM); the message keeps the variant's wording
+    if (c["scenario"].get("lme") is not None and est != S.EstimatorSpec.Mle
+            and not (est == S.EstimatorSpec.Glm and gen.get("cluster") is not None)):
         raise ContractError("scenario.lme requires estimator == Mle")
 
     # 14/15

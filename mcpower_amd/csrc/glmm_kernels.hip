@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
+#include "mcp_scenario.hpp"
 #include "mcp_rows.hpp"
 #include "mcp_decide.hpp"
 #include "mcp_glm_family.hpp"
@@ -216,7 +217,9 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
   return best;
 }
 
-template <int P>
+// SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
+// random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
+template <int P, bool SCEN>
 __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_q[];
   const SimParams& prm = *pp;
@@ -245,22 +248,33 @@ __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ 
     m.st = (float*)f + lane;
   }
   // ---- cluster random intercepts (data_gen.rs:146-161), then the rows: the effect sits inside the link ----
+  double tau_rep = prm.tau;
+  if (SCEN && prm.scen_tau_sq) {
+    const double t2 = prm.scen_tau_sq[lsim];
+    tau_rep = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
+  }
   for (uint32_t c = lane; c < ncl_max; c += QW) {
-    const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
-    m.cluster_u[c] = (float)((double)z * prm.tau);
+    if (SCEN) {
+      m.cluster_u[c] = (float)(draw_cluster_effect(prm, k0, k1, c) * tau_rep);
+    } else {
+      const float z = norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)c)));
+      m.cluster_u[c] = (float)((double)z * prm.tau);
+    }
   }
   gq_sync();
   RowCtx<P> cx;
   row_ctx_init<P, true>(prm, cx);
+  ScenLane<P> sl;
+  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
   for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += QW) {
-    stage_group<P, QW, 1, false>(prm, k0, k1, ctr, m.st, 0u);
+    stage_group<P, QW, 1, SCEN>(prm, k0, k1, ctr, m.st, SCEN ? sl.meta : 0u);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint32_t rr = 4u * ctr + r;
       if (rr < max_n) {
         const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
         float x[P], y;
-        build_row<P, true, QW, 1, false>(prm, cx, k0, k1, m.st, r, rr, x, y, (double)m.cluster_u[cid < ncl_max ? cid : 0u], nullptr);
+        build_row<P, true, QW, 1, SCEN>(prm, cx, k0, k1, m.st, r, rr, x, y, (double)m.cluster_u[cid < ncl_max ? cid : 0u], &sl);
 #pragma unroll
         for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
         m.design[(size_t)(P - 1) * n_pad + rr] = y;
@@ -498,16 +512,19 @@ size_t glmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max) {
   return dbl * 8 + flt * 4 + 64;
 }
 
-hipError_t launch_glmm(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, hipStream_t st) {
+hipError_t launch_glmm(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool scen,
+                       hipStream_t st) {
   const size_t lds = glmm_lds_bytes(P, max_n, ncl_max);
   const dim3 block(QW), grid(n_sims);
 #define GQ(PP)                                                                                                         \
   case PP: {                                                                                                           \
     if (lds > 48 * 1024) {                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void*)glmm_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipError_t e = hipFuncSetAttribute(scen ? (const void*)glmm_kernel<PP, true> : (const void*)glmm_kernel<PP, false>, \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
       if (e != hipSuccess) return e;                                                                                   \
     }                                                                                                                  \
-    hipLaunchKernelGGL((glmm_kernel<PP>), grid, block, lds, st, d_prm);                                                \
+    if (scen) hipLaunchKernelGGL((glmm_kernel<PP, true>), grid, block, lds, st, d_prm);                                \
+    else hipLaunchKernelGGL((glmm_kernel<PP, false>), grid, block, lds, st, d_prm);                                    \
   } break;
   switch (P) {
     GQ(2) GQ(3) GQ(4) GQ(5) GQ(6) GQ(7) GQ(8)

@@ -39,7 +39,7 @@ hipError_t launch_lmm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32
                           bool reduced, bool scen, hipStream_t st);
 size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 size_t lmm_rec_fields(int P, uint32_t ncl_max);
-hipError_t launch_glmm(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, hipStream_t st);
+hipError_t launch_glmm(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool scen, hipStream_t st);
 size_t glmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 hipError_t launch_lmm_general_scen(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
@@ -509,7 +509,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (glmm) DEV_TRY(mcp::launch_glmm((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, st));
+      if (glmm) DEV_TRY(mcp::launch_glmm((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, scen, st));
       else if (lmg && scen) DEV_TRY(mcp::launch_lmm_general_scen((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (lmg) DEV_TRY(mcp::launch_lmm_general((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));

@@ -295,7 +295,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     general = true;
   }
   if (general && K > 6) return unsupported("general data-generating path with more than 6 continuous predictors");
-  if (spec->scenario.has_lme && spec->estimator != MCP_EST_MLE) {
+  if (spec->scenario.has_lme && spec->estimator != MCP_EST_MLE &&
+      !(spec->estimator == MCP_EST_GLM && spec->cluster.present)) {  // validate.rs:458-474: Mle or clustered Glm
     err = "invalid spec: scenario.lme requires estimator == Mle";
     return MCP_ERR_INVALID_SPEC;
   }
@@ -714,8 +715,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (glmm) {
     prm.glmm_active = 1;
     prm.red_active = 0;  // no factor exclusion on clustered specs (batch.rs:1583)
-    if (prm.scen_active) return unsupported("clustered GLM on the general (scenario / upload) data path");
-    if (prm.lme_re_dist != 0u || prm.lme_icc_noise_sd > 0.0) return unsupported("clustered GLM with scenario random-effect knobs");
+    if (spec->upload_normal_rows || spec->n_bootstrap_frame_map) return unsupported("clustered GLM together with uploaded data");
   }
   if (prm.lmg_active && prm.red_active)
     return unsupported("random slopes / extra groupings together with a factor that can be excluded per replicate (sparse levels or sampled proportions)");

@@ -79,3 +79,18 @@ def test_glmm_refuses_what_it_cannot_do(engine):
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(spec, [600], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "random intercept only" in str(e.value)
+
+
+@pytest.mark.parametrize("preset_name", ["realistic", "doomer"])
+def test_glmm_under_scenario_presets(preset_name, engine, oracle):
+    """General data path for the clustered GLM: non-normal marginals, per-study effects on the link scale, heavy-tailed
+    cluster effects and the per-replicate ICC jitter."""
+    from helpers import preset
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.scenario = preset(preset_name)
+    spec.scenario.lme = S.LmeScenarioPerturbations(random_effect_dist=S.ResidualDist.HighKurtosis, random_effect_df=6.0,
+                                                   icc_noise_sd=0.15)
+    dev = engine.run_batch(spec, [600], 96, BASE_SEED)
+    ora = oracle.run_batch(spec, [600], 96, BASE_SEED, n_threads=8)
+    assert dev.converged.mean() > 0.9
+    _compare(dev, ora, 96, slack=2)
