@@ -114,9 +114,13 @@ def factor_preflight_warnings(spec: S.SimulationSpec, n: int) -> List[str]:
 
 
 def aggregate_batch(batch: S.BatchResult, target_indices: Sequence[int], contrast_pairs: Sequence[Tuple[int, int]],
-                    estimator: S.EstimatorSpec, posthoc_blocks: Sequence[Tuple[int, int]] = ()) -> List[dict]:
+                    estimator: S.EstimatorSpec, posthoc_blocks: Sequence[Tuple[int, int]] = (),
+                    report_overall: bool = False) -> List[dict]:
     """`aggregate_batch` (aggregation.rs:62-291): one PowerResult-shaped dict per sample size.
-    `posthoc_blocks` = [(n_levels, n_contrasts), ...] (`ResultShape::posthoc_blocks`)."""
+    `posthoc_blocks` = [(n_levels, n_contrasts), ...] (`ResultShape::posthoc_blocks`); `report_overall` is only
+    consulted for counters-only results (a per-sim result carries the `overall` tensor itself)."""
+    if batch.uncorrected is None:  # counters-only result (10^7-replicate or sharded runs): same numbers from the pooled counts
+        return _aggregate_counters(batch, target_indices, contrast_pairs, estimator, posthoc_blocks, report_overall)
     sh = batch.shape
     n_sims, n_ss, n_targets, n_factors = sh.n_sims, sh.n_sample_sizes, sh.n_targets, sh.n_factors
     total_contrasts = sum(w for _, w in posthoc_blocks)
@@ -189,6 +193,89 @@ def aggregate_batch(batch: S.BatchResult, target_indices: Sequence[int], contras
             grid_warnings=[], posthoc=posthoc, factor_exclusion_counts=excl_sparse,
             factor_separation_counts=excl_sep))
     return out
+
+
+def _aggregate_counters(batch: S.BatchResult, target_indices, contrast_pairs, estimator: S.EstimatorSpec,
+                        posthoc_blocks, report_overall: bool) -> List[dict]:
+    """`aggregate_batch` from the additive counter block alone -- what `merge_power_results` (merge.rs:26-70) pools
+    across workers: every count, rate, Wilson interval and histogram of the per-sim path.  Not recoverable from
+    counts: the per-sim `boundary_hit` list (left empty), per-component pin rates beyond the first component and the
+    mean tau-hat^2 of a clustered GLM (NaN)."""
+    sh, lay, ctr = batch.shape, batch.layout, batch.counters
+    n_ss, n_targets, n_factors = sh.n_sample_sizes, sh.n_targets, sh.n_factors
+    total_contrasts = sum(w for _, w in posthoc_blocks)
+    out = []
+    for ss in range(n_ss):
+        row = ctr[ss]
+        n_sims = int(row[lay["n_sims"]])
+
+        def block(name, width):
+            return [int(v) for v in row[lay[name]:lay[name] + width]]
+
+        k_unc, k_cor = block("k_unc", n_targets), block("k_cor", n_targets)
+        conv_count = int(row[lay["converged"]])
+        b1, b2 = int(row[lay["boundary_1"]]), int(row[lay["boundary_2"]])
+        singular_rate = b1 / conv_count if conv_count > 0 else 0.0
+        if estimator == S.EstimatorSpec.Ols:
+            extras = {"estimator": "ols"}
+        elif estimator == S.EstimatorSpec.Glm:
+            extras = {"estimator": "glm", "baseline_prob_realized": math.nan, "singular_fit_rate": singular_rate,
+                      "tau_squared_hat_mean": math.nan}
+        else:
+            comp = [singular_rate] + [math.nan] * max(sh.n_variance_components - 1, 0)
+            extras = {"estimator": "mle", "tau_estimate": math.nan, "boundary_hits": b1 + b2,
+                      "joint_uncorrected_rate": _rate(int(row[lay["joint_unc"]]), n_sims),
+                      "joint_corrected_rate": _rate(int(row[lay["joint_cor"]]), n_sims),
+                      "singular_fit_rate": singular_rate, "boundary_rate_per_component": comp[:sh.n_variance_components]}
+        posthoc, offset = [], 0
+        for n_levels, w in posthoc_blocks:
+            ku = [int(v) for v in row[lay["posthoc_unc"] + offset:lay["posthoc_unc"] + offset + w]]
+            kc = [int(v) for v in row[lay["posthoc_cor"] + offset:lay["posthoc_cor"] + offset + w]]
+            posthoc.append(dict(n_levels=int(n_levels), power_uncorrected=[_rate(k, n_sims) for k in ku],
+                                power_corrected=[_rate(k, n_sims) for k in kc],
+                                ci_uncorrected=[wilson_ci(k, n_sims) for k in ku],
+                                ci_corrected=[wilson_ci(k, n_sims) for k in kc],
+                                success_counts_uncorrected=ku, success_counts_corrected=kc))
+            offset += w
+        overall_rate = overall_ci = None
+        overall_count = 0
+        if report_overall:
+            overall_count = int(row[lay["overall"]])
+            overall_rate, overall_ci = _rate(overall_count, n_sims), wilson_ci(overall_count, n_sims)
+        n_joint = n_targets + total_contrasts
+        out.append(dict(
+            n=0, n_sims=n_sims, target_indices=[int(i) for i in target_indices],
+            contrast_pairs=[(int(a), int(b)) for a, b in contrast_pairs],
+            power_uncorrected=[_rate(k, n_sims) for k in k_unc], power_corrected=[_rate(k, n_sims) for k in k_cor],
+            ci_uncorrected=[wilson_ci(k, n_sims) for k in k_unc], ci_corrected=[wilson_ci(k, n_sims) for k in k_cor],
+            convergence_rate=1.0 if n_sims == 0 else conv_count / n_sims, boundary_hit=[], estimator_extras=extras,
+            overall_significant_rate=overall_rate, success_counts_uncorrected=k_unc, success_counts_corrected=k_cor,
+            convergence_count=conv_count, overall_significant_count=overall_count, overall_significant_ci=overall_ci,
+            success_count_histogram_uncorrected=block("hist_unc", n_joint + 1),
+            success_count_histogram_corrected=block("hist_cor", n_joint + 1), grid_warnings=[], posthoc=posthoc,
+            factor_exclusion_counts=block("excl_sparse", n_factors), factor_separation_counts=block("excl_sep", n_factors)))
+    return out
+
+
+def sharded_runner(rank: int, world: int, group=None, run_batch=None):
+    """Runner for `find_power` / `find_sample_size` when one process drives one GPU: this rank simulates its
+    contiguous slice of the replicates (same base seed, so the union is the single-device run), one all-reduce pools
+    the counters, and every rank aggregates the same pooled block -- identical results on all ranks.
+    Usage: `find_power(blob, n, n_sims, seed, _runner=sharded_runner(rank, world))` on every rank."""
+    def run(spec, sample_sizes, n_sims, base_seed, sink):
+        from . import dist as mdist
+        if run_batch is None:
+            from . import engine
+            call = lambda cnt, off: engine.run_batch(spec, sample_sizes, cnt, base_seed, sink, per_sim=False, sim_offset=off)
+        else:
+            call = lambda cnt, off: run_batch(spec, sample_sizes, cnt, base_seed, off)
+        off, cnt = mdist.shard_range(int(n_sims), rank, world)
+        local = call(cnt, off)
+        local.uncorrected = None  # a runner handing back per-sim tensors of its shard must not be mistaken for the whole
+        local.counters = mdist.allreduce_counters(local.counters, group)
+        local.shape.n_sims = int(n_sims)
+        return local
+    return run
 
 
 def _estimator_extras(estimator: S.EstimatorSpec, batch: S.BatchResult, ss: int) -> dict:
@@ -362,7 +449,7 @@ def find_power(contracts_bytes: bytes, sample_size: int, n_sims: int, base_seed:
                 raise OrchestratorError("Cancelled", f"cancelled at scenario {idx}, n=Some({sample_size})") from e
             raise
         aggs = aggregate_batch(batch, sc["report_target_indices"], sc["report_contrast_pairs"], spec.estimator,
-                               _posthoc_blocks(spec))
+                               _posthoc_blocks(spec), report_overall=bool(spec.report_overall))
         assert len(aggs) == 1
         pr = aggs[0]
         pr["n"] = sample_size
@@ -818,7 +905,7 @@ def find_sample_size(contracts_bytes: bytes, target_power: float, lo: int, hi: i
                 raise OrchestratorError("Cancelled", f"cancelled at scenario {idx}, n=None") from e
             raise
         aggs = aggregate_batch(batch, sc["report_target_indices"], sc["report_contrast_pairs"], spec.estimator,
-                               _posthoc_blocks(spec))
+                               _posthoc_blocks(spec), report_overall=bool(spec.report_overall))
         for pr, n in zip(aggs, grid):
             pr["n"] = int(n)
         d = derive_sample_size_outputs(aggs, grid, float(target_power), atom)
