@@ -55,12 +55,21 @@ __device__ __forceinline__ double gq_wave_sum(double v) {
 // Laplace deviance at par = (theta, beta); leaves the modes and weight sums of every cluster in LDS
 template <int P>
 __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
-                                         uint32_t ncl, uint32_t n_pad) {
+                                         uint32_t ncl, uint32_t n_pad, uint32_t keep) {
   const uint32_t fam = prm.glm_family;
   const double theta = par[0];
+  // par = (theta, coefficients of the fitted columns in column order); a column outside a test_formula subset has
+  // coefficient 0 (batch.rs:1588-1640 fits the gathered kept columns: the same sums plus exact zeros)
   double beta[P];
+  {
+    uint32_t k = 1;
 #pragma unroll
-  for (int c = 0; c < P; ++c) beta[c] = par[1 + c];
+    for (int c = 0; c < P; ++c) {
+      const bool kept = (keep >> c) & 1u;
+      beta[c] = kept ? par[k] : 0.0;
+      k += kept ? 1u : 0u;
+    }
+  }
   for (uint32_t i = lane; i < n; i += QW) {
     double e = beta[0];
 #pragma unroll
@@ -111,8 +120,8 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
 
 template <int P>
 __device__ __forceinline__ double glmm_f(const SimParams& prm, const GlmmLds& m, gdd* x, uint32_t lane, uint32_t n, uint32_t ncl,
-                                         uint32_t n_pad, uint32_t& n_eval) {
-  if (lane <= (uint32_t)P) {
+                                         uint32_t n_pad, uint32_t keep, uint32_t& n_eval) {
+  if (lane <= (uint32_t)__popc(keep)) {
     double v = x[lane];
     if (lane == 0u) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
     else v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
@@ -120,27 +129,28 @@ __device__ __forceinline__ double glmm_f(const SimParams& prm, const GlmmLds& m,
   }
   gq_sync();
   ++n_eval;
-  return glmm_eval<P>(prm, m, x, lane, n, ncl, n_pad);
+  return glmm_eval<P>(prm, m, x, lane, n, ncl, n_pad, keep);
 }
 
 // one Nelder-Mead run from simplex row 0 with initial edge `step`; the best point ends in row 0
 template <int P>
 __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const GlmmLds m, double step, double ftol, double xtol,
-                                                uint32_t lane, uint32_t n, uint32_t ncl, uint32_t n_pad, uint32_t& n_eval) {
-  constexpr uint32_t d = P + 1;
+                                                uint32_t lane, uint32_t n, uint32_t ncl, uint32_t n_pad, uint32_t keep,
+                                                uint32_t& n_eval) {
+  const uint32_t d = 1u + (uint32_t)__popc(keep);
   gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe
   gdd* fv = m.fv;
   gdd* cen = sx + (size_t)(d + 1u) * GLMM_ROW;
   gdd* xr = cen + GLMM_ROW;
   gdd* xe = xr + GLMM_ROW;
   const double inf = __builtin_inf();
-  const double f0 = glmm_f<P>(prm, m, sx, lane, n, ncl, n_pad, n_eval);
+  const double f0 = glmm_f<P>(prm, m, sx, lane, n, ncl, n_pad, keep, n_eval);
   if (lane == 0u) fv[0] = f0;
   for (uint32_t i = 0; i < d; ++i) {
     gdd* v = sx + (size_t)(i + 1u) * GLMM_ROW;
     if (lane < d) v[lane] = sx[lane] + (lane == i ? step : 0.0);
     gq_sync();
-    const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, n_eval);
+    const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
     if (lane == 0u) fv[i + 1u] = fi;
   }
   gq_sync();
@@ -171,12 +181,12 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
       xr[lane] = c + (c - sx[(size_t)hi * GLMM_ROW + lane]);
     }
     gq_sync();
-    const double fr = glmm_f<P>(prm, m, xr, lane, n, ncl, n_pad, n_eval);
+    const double fr = glmm_f<P>(prm, m, xr, lane, n, ncl, n_pad, keep, n_eval);
     gdd* worst = sx + (size_t)hi * GLMM_ROW;
     if (fr < flo) {
       if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
       gq_sync();
-      const double fe = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, n_eval);
+      const double fe = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
       if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
       if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
     } else if (fr < fnh) {
@@ -186,7 +196,7 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
       const bool outside = fr < fhi;
       if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
       gq_sync();
-      const double fc = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, n_eval);
+      const double fc = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
       if (fc < (outside ? fr : fhi)) {
         if (lane < d) worst[lane] = xe[lane];
         if (lane == 0u) fv[hi] = fc;
@@ -196,7 +206,7 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
           gdd* v = sx + (size_t)i * GLMM_ROW;
           if (lane < d) v[lane] = sx[(size_t)lo * GLMM_ROW + lane] + 0.5 * (v[lane] - sx[(size_t)lo * GLMM_ROW + lane]);
           gq_sync();
-          const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, n_eval);
+          const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
           if (lane == 0u) fv[i] = fi;
           gq_sync();
         }
@@ -209,10 +219,10 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
     if (fv[i] < fv[lo]) lo = i;
   const double best = fv[lo];
   gq_sync();
-  double keep = 0.0;
-  if (lane < d) keep = sx[(size_t)lo * GLMM_ROW + lane];
+  double best_k = 0.0;
+  if (lane < d) best_k = sx[(size_t)lo * GLMM_ROW + lane];
   gq_sync();
-  if (lane < d) sx[lane] = keep;
+  if (lane < d) sx[lane] = best_k;
   gq_sync();
   return best;
 }
@@ -286,45 +296,45 @@ __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ 
   bool has_prev = false;
   double carry = 0.0;
   const uint32_t nt = prm.n_tests;
+  // fitted columns: all of them, or the test_formula subset (no factor exclusion on clustered specs, batch.rs:1583)
+  const uint32_t keep = prm.glmm_keep;
   for (uint32_t g = 0; g < prm.n_grid; ++g) {
     const uint32_t n = prm.ns[g];
     const uint32_t ncl = prm.cluster_fixed_clusters ? cv : (n + cv - 1u) / cv;
     gdd* x0 = m.simplex;
-    if (lane <= (uint32_t)P) {
-      double v;
-      if (lane == 0u) {
-        v = has_prev ? carry : (prm.truth_start ? prm.tau : 1.0);  // carried theta-hat / truth / blind THETA0
-        if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;
-      } else {
-        v = prm.beta[lane - 1u];                                    // beta starts at the truth, unconditionally
-      }
-      x0[lane] = v;
+    if (lane == 0u) {
+      double v = has_prev ? carry : (prm.truth_start ? prm.tau : 1.0);  // carried theta-hat / truth / blind THETA0
+      if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;
+      x0[0] = v;
+      uint32_t k = 1;
+      for (uint32_t c = 0; c < (uint32_t)P; ++c)
+        if ((keep >> c) & 1u) x0[k++] = prm.beta[c];                      // beta starts at the truth, unconditionally
     }
     gq_sync();
     uint32_t n_eval = 0;
-    double best = glmm_nelder_mead<P>(prm, m, 0.25, 1e-9, 1e-6, lane, n, ncl, n_pad, n_eval);
+    double best = glmm_nelder_mead<P>(prm, m, 0.25, 1e-9, 1e-6, lane, n, ncl, n_pad, keep, n_eval);
     for (int restart = 0; restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
       const double prev = best;
-      best = glmm_nelder_mead<P>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, n_eval);
+      best = glmm_nelder_mead<P>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
       if (!(prev - best > 1e-8)) break;
     }
-    double cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, n_eval);
+    double cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
     {
-      const double keep = x0[0];
-      if (keep != 0.0 && keep <= 1e-4) {  // snap onto the boundary when that costs no deviance
+      const double th_keep = x0[0];
+      if (th_keep != 0.0 && th_keep <= 1e-4) {  // snap onto the boundary when that costs no deviance
         gq_sync();
         if (lane == 0u) x0[0] = 0.0;
         gq_sync();
-        const double f0 = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, n_eval);
+        const double f0 = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
         if (f0 <= cur + 1e-8) cur = f0;
         else {
           gq_sync();
-          if (lane == 0u) x0[0] = keep;
+          if (lane == 0u) x0[0] = th_keep;
           gq_sync();
         }
       }
     }
-    cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, n_eval);  // modes and weight sums of the final point
+    cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);  // modes and weight sums of the final point
     const double theta = x0[0];
     bool ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
     // ---- RX'RX at the optimum: lane = cluster accumulates X_c'W X_c and a_c = X_c'w_c, wave sums the Schur terms ----
@@ -375,7 +385,10 @@ __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ 
 #pragma unroll
       for (int r = 0; r < P; ++r)
 #pragma unroll
-        for (int s = 0; s <= r; ++s) Af[r][s] = A[idx++];
+        for (int s = 0; s <= r; ++s) {  // a dropped column is an identity row / column: the kept block factors as the gathered system
+          const double v = A[idx++];
+          Af[r][s] = (((keep >> r) & 1u) && ((keep >> s) & 1u)) ? v : (r == s ? 1.0 : 0.0);
+        }
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         double dd = Af[j][j];
@@ -403,8 +416,15 @@ __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ 
     }
     // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions ----
     double beta[P];
+    {
+      uint32_t k = 1;
 #pragma unroll
-    for (int c = 0; c < P; ++c) beta[c] = x0[1 + c];
+      for (int c = 0; c < P; ++c) {
+        const bool kept = (keep >> c) & 1u;
+        beta[c] = kept ? x0[k] : 0.0;
+        k += kept ? 1u : 0u;
+      }
+    }
     const double* crow = prm.crit + (size_t)g * prm.crit_stride;
     double tsq[MAX_T_WAVE];
     double U[MAX_T_WAVE][P];

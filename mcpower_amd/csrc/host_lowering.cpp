@@ -247,7 +247,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   const bool glmm = spec->cluster.present && spec->estimator == MCP_EST_GLM;  // batch.rs:1575-1830
   if (glmm) {
     if (lmm_general) return unsupported("clustered GLM with random slopes / extra groupings (random intercept only)");
-    if (spec->n_fit_columns) return unsupported("clustered GLM together with a test_formula column subset");
     if (spec->n_between_var_indices) return unsupported("clustered GLM together with cluster-level predictors");
   }
   if (lmm_general) {
@@ -714,6 +713,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   prm.red_active = (npc > 0 || test_reduces || any_excl_possible || wide || ols_cluster) ? 1u : 0u;
   if (glmm) {
     prm.glmm_active = 1;
+    prm.glmm_keep = prm.keep_mask[0];  // every column, or the test_formula subset (flag combination 0: nothing excluded)
+    if (!(prm.glmm_keep & 1u)) return unsupported("intercept-free test_formula fit of a clustered GLM");
     prm.red_active = 0;  // no factor exclusion on clustered specs (batch.rs:1583)
     if (spec->upload_normal_rows || spec->n_bootstrap_frame_map) return unsupported("clustered GLM together with uploaded data");
   }

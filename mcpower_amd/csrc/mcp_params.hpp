@@ -188,7 +188,7 @@ struct SimParams {
   uint16_t* pinned;                  // [n_sims_total][n_grid] pinned-component bits (spec.rs:566-573) or null
   double* tau_hat;                   // [n_sims_total][n_grid] tau-hat^2 of a clustered-GLM fit (spec.rs:589-593) or null
   uint32_t glmm_active;              // Glm estimator + cluster: the random-intercept GLMM kernel
-  uint32_t _pad_glmm;
+  uint32_t glmm_keep;                // fitted columns of the clustered GLM: all, or the test_formula subset
 
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;

@@ -94,3 +94,19 @@ def test_glmm_under_scenario_presets(preset_name, engine, oracle):
     ora = oracle.run_batch(spec, [600], 96, BASE_SEED, n_threads=8)
     assert dev.converged.mean() > 0.9
     _compare(dev, ora, 96, slack=2)
+
+
+def test_glmm_test_formula_fits_the_kept_columns(engine, oracle):
+    """batch.rs `test_formula_reduced_fit_glmm_recovers_marginal_coefficient`: generate with x1 + x2, fit x1 only."""
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.n_non_factor = 2
+    spec.correlation = [1.0, 0.0, 0.0, 1.0]
+    spec.var_types, spec.var_params = [S.Distribution.Normal] * 2, [0.0, 0.0]
+    spec.effect_sizes = [-0.85, 0.5, 0.4]
+    spec.fit_columns = [0, 1]
+    spec.target_indices = [1]
+    spec.scenario.truth_start = True
+    dev, stat = engine.run_batch_st_capture(spec, [300, 600], 48, BASE_SEED)
+    ora = oracle.run_batch(spec, [300, 600], 48, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.9
+    _compare(dev, ora, 48, stat, ora.stat_capture)
