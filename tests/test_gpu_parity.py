@@ -584,3 +584,46 @@ def test_poisson_large_rate_and_factor_exclusion(engine, oracle):
     d, y = engine.generate_design(spec, 200, 2, seed, 5)
     xo, yo, _ = oracle.generate_sim_data(spec, seed, 6, 200)
     assert np.array_equal(y[1], yo) and yo.mean() > 25
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes of the iterative estimators: size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_c3_logistic_properties(engine, oracle):
+    """configs[2]: logistic IRLS n = 500, p = 4, 10^5 replicates -- determinism, shard union, counter checksums, the
+    oracle's first replicates, and the null-effect target (x3 = 0) rejecting at alpha."""
+    from helpers import spec_c3
+    spec, n = spec_c3(), 100_000
+    a = engine.run_batch(spec, [500], n, BASE_SEED, per_sim=False)
+    b = engine.run_batch(spec, [500], n, BASE_SEED, per_sim=False)
+    assert np.array_equal(a.counters, b.counters)
+    parts = [engine.run_batch(spec, [500], n // 4, BASE_SEED, per_sim=False, sim_offset=o * (n // 4)) for o in range(4)]
+    assert np.array_equal(sum(p.counters for p in parts), a.counters)
+    nt = spec.n_targets
+    assert a.counter("n_sims")[0, 0] == n and a.counter("hist_unc", nt + 1)[0].sum() == n
+    hist = a.counter("hist_unc", nt + 1)[0].astype(np.float64)
+    assert a.counter("k_unc", nt)[0].sum() == (hist * np.arange(nt + 1)).sum()
+    assert a.counter("converged")[0, 0] >= 0.999 * n
+    head = engine.run_batch(spec, [500], 2000, BASE_SEED)
+    o = oracle.run_batch(spec, [500], 2000, BASE_SEED, n_threads=8)
+    assert np.array_equal(head.uncorrected, o.uncorrected) and np.array_equal(head.converged, o.converged)
+    null_rate = a.counter("k_unc", nt)[0, 2] / n                       # x3 carries no effect
+    assert abs(null_rate - 0.05) < 5 * np.sqrt(0.05 * 0.95 / n) + 0.002  # Wald z on a logit fit: within 0.2 pp of alpha
+
+
+def test_full_size_c4_lmm_properties(engine, oracle):
+    """configs[3]: random-intercept REML, 30 clusters x 20, 10^4 replicates -- same properties plus joint <= marginal logic."""
+    from helpers import spec_c4
+    spec, n = spec_c4(), 10_000
+    a = engine.run_batch(spec, [600], n, BASE_SEED)
+    b = engine.run_batch(spec, [600], n, BASE_SEED, per_sim=False)
+    assert np.array_equal(a.counters, b.counters)
+    parts = [engine.run_batch(spec, [600], n // 2, BASE_SEED, per_sim=False, sim_offset=o * (n // 2)) for o in range(2)]
+    assert np.array_equal(parts[0].counters + parts[1].counters, a.counters)
+    assert a.counter("n_sims")[0, 0] == n and a.converged.mean() > 0.999
+    assert np.array_equal(a.joint_unc, a.joint_cor)                                  # batch.rs:1453-1477
+    assert (a.pinned_components == (a.boundary_hit == 1)).all()
+    head = oracle.run_batch(spec, [600], 1000, BASE_SEED, n_threads=8)
+    assert np.array_equal(a.uncorrected[:1000], head.uncorrected) and np.array_equal(a.boundary_hit[:1000], head.boundary_hit)
+    # Wald power of x1 = 0.15 with se = 1 / sqrt(n) on standardised within-cluster variation: ~0.95
+    assert 0.93 < a.uncorrected[:, 0, 0].mean() < 0.97
