@@ -37,7 +37,10 @@ WORKLOADS = {
     # name: (spec factory, n, ops per fit for the fused kernel, staged bytes read per fit)
     "c2a": ("spec_c2a", 200, 3.76e4, 4 * 200 * 5),   # x1,x2,x3,x1:x2,y stored: 5 f32 columns
     "c2b": ("spec_c2b", 200, 5.26e4, 4 * 200 * 6),   # 5 predictors + y: the 4800 B of BASELINE.md
-    "k4": ("spec_k4", 200, 4.3e4, 4 * 200 * 5),      # tuning aid: 4 plain predictors (p=5, no interaction)
+    "k4": ("spec_k4", 200, 4.3e4, 4 * 200 * 5),
+    # the reference bench's widest case (throughput.rs:274-277, :512-517): k = 15, P = 16, n = 200 --
+    # 800 Philox calls + 3 200 inverse CDFs + 2 x 200 x 152 f64 MAC: ~1.4e5 ops
+    "ols_wide": ("spec_ols_wide", 200, 1.4e5, 4 * 200 * 16),      # tuning aid: 4 plain predictors (p=5, no interaction)
     # C3: logistic IRLS n=500 p=4: 2000 draws + ~5 passes x 500 rows x (exp, log1p, 2 div, 18 fma) ~ 5.0e5 ops
     "c3": ("spec_c3", 500, 5.0e5, 4 * 500 * 4),
     # C4: random-intercept REML, 30 x 20: 1800 draws + 30 RE draws + one 600-row pass + ~28 objective evaluations
@@ -199,7 +202,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
             "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
-                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
+                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": "1 all-reduce(sum) of counters per step"},
@@ -210,7 +213,7 @@ def main():
         if not staged:
             fits_per_launch *= len(ns)  # a replicate on a grid is len(ns) prefix fits (throughput.rs:1111-1113)
             ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "valu", "kernel": (f"ols_sim_kernel<{spec.n_predictors},fused>" if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
+            out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
                                "traffic": (pmc_traffic(args.workload, f"ols_sim_kernel<{spec.n_predictors}, 0,")
                                            if (is_ols and not is_c5 and S == 1_000_000) else None),
@@ -219,7 +222,7 @@ def main():
                                "note": "fused generate+fit: no design bytes touch HBM; bound is VALU/integer issue "
                                        "(SURVEY.md 8d); HBM-equivalent rate in hbm_equiv_gbs",
                                "hbm_equiv_gbs": bytes_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e9}
-        if not staged and is_ols and not is_c5:
+        if not staged and is_ols and not is_c5 and spec.n_predictors <= 8:  # the staged pipeline serves the register-resident kernels
             # the HBM-bound kernel of the path: staged fit over a resident design tile (measured outside the timed region)
             rs = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, staged=True)
             rs = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, staged=True)

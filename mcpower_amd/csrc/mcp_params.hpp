@@ -10,11 +10,11 @@
 
 namespace mcp {
 
-constexpr int MAX_P = 12;        // design columns incl. intercept handled by the register-resident OLS kernels
+constexpr int MAX_P = 16;        // design columns incl. intercept handled by the register-resident OLS kernels
 constexpr int MAX_P_WAVE = 8;    // ... by the wave-per-replicate GLM kernels (Mle: 6)
-constexpr int MAX_K = 11;        // continuous predictors
+constexpr int MAX_K = 15;        // continuous predictors
 constexpr int MAX_GRID = 64;     // sample-size grid points per call
-constexpr int MAX_T = 12;        // tests per fit (marginal targets + contrast pairs)
+constexpr int MAX_T = 16;        // tests per fit (marginal targets + contrast pairs)
 constexpr int MAX_T_WAVE = 8;    // ... in the GLM / LMM kernels (no contrast pairs there, targets <= P - 1)
 constexpr int MAX_FACTORS = 4;
 constexpr int MAX_LEVELS = 16;   // sum of levels over all factors

@@ -40,6 +40,10 @@ template <> struct PendMask<9> { typedef unsigned long long type; };
 template <> struct PendMask<10> { typedef unsigned long long type; };
 template <> struct PendMask<11> { typedef unsigned long long type; };
 template <> struct PendMask<12> { typedef unsigned long long type; };
+template <> struct PendMask<13> { typedef unsigned long long type; };
+template <> struct PendMask<14> { typedef unsigned long long type; };
+template <> struct PendMask<15> { typedef unsigned long long type; };
+template <> struct PendMask<16> { typedef unsigned long long type; };  // 16 slots x 4 rows: the last size one u64 holds
 __device__ __forceinline__ uint32_t pend_ctz(uint32_t m) { return (uint32_t)__builtin_ctz(m); }
 __device__ __forceinline__ uint32_t pend_ctz(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }
 

@@ -476,7 +476,7 @@ hipError_t launch_ols_fit_provided(int P, const float* design, const float* outc
 #define LFP(PP) \
   case PP: hipLaunchKernelGGL((ols_fit_provided_kernel<PP>), grid, block, 0, st, design, outcome, n_fits, n, beta, se, tsq, rss, sst, conv); break;
   switch (P) {
-    LFP(2) LFP(3) LFP(4) LFP(5) LFP(6) LFP(7) LFP(8) LFP(9) LFP(10) LFP(11) LFP(12)
+    LFP(2) LFP(3) LFP(4) LFP(5) LFP(6) LFP(7) LFP(8) LFP(9) LFP(10) LFP(11) LFP(12) LFP(13) LFP(14) LFP(15) LFP(16)
     default: return hipErrorInvalidValue;
   }
 #undef LFP

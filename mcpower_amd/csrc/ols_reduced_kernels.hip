@@ -357,7 +357,7 @@ hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims,
     else hipLaunchKernelGGL((design_capture_kernel<PP, false>), grid, block, lds, st, d_prm);                    \
   } break;
   switch (P) {
-    LC(2) LC(3) LC(4) LC(5) LC(6) LC(7) LC(8) LC(9) LC(10) LC(11) LC(12)
+    LC(2) LC(3) LC(4) LC(5) LC(6) LC(7) LC(8) LC(9) LC(10) LC(11) LC(12) LC(13) LC(14) LC(15) LC(16)
     default: return hipErrorInvalidValue;
   }
 #undef LC
@@ -373,7 +373,7 @@ static hipError_t launch_reduced_f(int P, const SimParams* d_prm, uint32_t n_sim
     hipLaunchKernelGGL((ols_reduced_kernel<PP, FLAVOR>), grid, block, lds, st, d_prm);                           \
   } break;
   switch (P) {
-    LR(2) LR(3) LR(4) LR(5) LR(6) LR(7) LR(8) LR(9) LR(10) LR(11) LR(12)
+    LR(2) LR(3) LR(4) LR(5) LR(6) LR(7) LR(8) LR(9) LR(10) LR(11) LR(12) LR(13) LR(14) LR(15) LR(16)
     default: return hipErrorInvalidValue;
   }
 #undef LR

@@ -170,6 +170,13 @@ def preset(name: str) -> S.ScenarioPerturbations:
     raise KeyError(name)
 
 
+def spec_ols_wide() -> S.SimulationSpec:
+    """`ols_wide` of the reference bench (throughput.rs:274-277): base_spec(15), x1 = x2 = 0.2."""
+    s = base_spec(15)
+    s.effect_sizes[1] = s.effect_sizes[2] = 0.2
+    return s
+
+
 def spec_glmm() -> S.SimulationSpec:
     """Reference case glmm_intercept (validation/formulas.R:1092-1100): logit, y ~ x1 + (1 | g), 30 clusters x 20."""
     spec = load_case("glmm_intercept")[0]

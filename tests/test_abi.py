@@ -91,7 +91,7 @@ def test_unsupported_fails_loudly_never_falls_back(engine):
         engine.run_batch(s, [100], 4, BASE_SEED)
     assert e.value.status == S.Status.InvalidSpec
     from helpers import base_spec
-    s = base_spec(12)  # 13 design columns: beyond the register-resident kernels
+    s = base_spec(16)  # 17 design columns: one more than the widest kernel carries
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(s, [100], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "design columns" in str(e.value)

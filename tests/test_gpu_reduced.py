@@ -364,6 +364,33 @@ def test_wide_ols_eleven_predictors(engine, oracle):
         assert np.allclose(f["t_sq"][s], fo["t_sq"], rtol=1e-9)
 
 
+def test_ols_wide_fifteen_predictors_like_the_reference_bench(engine, oracle):
+    """`ols_wide` of the reference's throughput bench (k = 15, P = 16: throughput.rs): the widest design one u64
+    of pending-tail bits and the reduced kernel's register file carry; 16 tests incl. a contrast pair."""
+    from helpers import base_spec
+    spec = base_spec(15)
+    c = np.eye(15)
+    c[0, 1] = c[1, 0] = 0.3
+    c[7, 14] = c[14, 7] = -0.25
+    spec.correlation = c.flatten().tolist()
+    spec.effect_sizes = [0.0] + [0.18, 0.18, 0.0, 0.1, -0.1, 0.0, 0.05, 0.2, 0.0, -0.15, 0.12, 0.0, 0.08, 0.0, 0.22]
+    spec.target_indices = list(range(1, 16))
+    spec.contrast_pairs = [(1, 2)]
+    spec.correction_method = S.CorrectionMethod.BenjaminiHochberg
+    spec.report_overall = True
+    g, o = _both(engine, oracle, spec, [40, 200, 500], 2000, 77)
+    _assert_reduced_equal(g, o)
+    assert g.shape.n_targets == 16
+    d, y = engine.generate_design(spec, 200, 2, 77, 0)
+    for s in range(2):
+        xo, yo, _ = oracle.generate_sim_data(spec, 77, s, 200)
+        assert np.array_equal(d[s].view(np.uint32), xo.view(np.uint32)) and np.array_equal(y[s], yo)
+    f = engine.fit_design(d, y)
+    for s in range(2):
+        fo = oracle.ols_fit(d[s], y[s])
+        assert np.allclose(f["beta"][s], fo["beta"], rtol=1e-10, atol=1e-13) and np.allclose(f["t_sq"][s], fo["t_sq"], rtol=1e-9)
+
+
 def test_wide_ols_factors_interactions_posthoc_and_exclusion(engine, oracle):
     spec = S.SimulationSpec(
         n_non_factor=3, n_factor_dummies=5, correlation=[1.0, 0.3, 0.0, 0.3, 1.0, 0.2, 0.0, 0.2, 1.0],
