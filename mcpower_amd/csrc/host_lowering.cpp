@@ -251,7 +251,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   }
   if (lmm_general) {
     if (spec->estimator != MCP_EST_MLE) return unsupported("random slopes / extra groupings outside the Mle estimator (clustered GLM: random intercept only)");
-    if (spec->n_fit_columns) return unsupported("random slopes / extra groupings together with a test_formula column subset");
     if (spec->n_between_var_indices) return unsupported("random slopes / extra groupings together with cluster-level predictors");
     if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");
     for (uint32_t t = 0; t <= spec->cluster.n_extra_groupings; ++t) {
@@ -718,8 +717,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     prm.red_active = 0;  // no factor exclusion on clustered specs (batch.rs:1583)
     if (spec->upload_normal_rows || spec->n_bootstrap_frame_map) return unsupported("clustered GLM together with uploaded data");
   }
-  if (prm.lmg_active && prm.red_active)
-    return unsupported("random slopes / extra groupings together with a factor that can be excluded per replicate (sparse levels or sampled proportions)");
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))
     return unsupported("intercept-free reduced fit under Glm / Mle");
   for (uint32_t k = 0; k <= (uint32_t)MAX_T; ++k)

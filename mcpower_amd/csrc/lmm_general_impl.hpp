@@ -305,6 +305,140 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, co
   return (dev < inf && dev > -inf) ? dev : inf;
 }
 
+
+// A reduced round (batch.rs:1343-1400): some design columns are out of the fit (sparse-factor exclusion, a test_formula
+// subset) and every grouping keeps its intercept only.  The fitted model's statistics are sub-blocks of the full
+// structure's: the intercept row of each primary strip, the intercept column of each extra-grouping level, the kept X
+// columns.  theta has one entry per grouping; a dropped X column is an identity row / column of the dense block.
+struct LmgRed {
+  uint32_t keep;   // kept design columns
+  uint32_t p_fit;  // their count
+};
+
+// view column (reduced rest | X | y) -> column of the full layout
+__device__ __forceinline__ uint32_t lmg_red_col(const SimParams& prm, uint32_t i, uint32_t Rr, uint32_t& term) {
+  term = 0u;
+  if (i >= Rr) return prm.lmg_R + (i - Rr);
+  uint32_t t = 1u, off = 0u;
+  while (t + 1u < prm.lmg_n_terms && i >= off + prm.lmg_levels[t]) { off += prm.lmg_levels[t]; ++t; }
+  term = t;
+  return prm.lmg_roff[t] + (i - off) * prm.lmg_q[t];
+}
+
+template <int Q0F>
+__device__ __noinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows,
+                                            const LmgRed red) {
+  const uint32_t Wf = prm.lmg_W, p = prm.P, L0 = prm.lmg_levels[0], nterms = prm.lmg_n_terms;
+  uint32_t Rr = 0;
+  for (uint32_t t = 1; t < nterms; ++t) Rr += prm.lmg_levels[t];
+  const uint32_t W = Rr + p + 1u, M = Rr + p;
+  const double inf = __builtin_inf();
+  auto theta_of = [&](uint32_t term) { return th[term]; };
+  auto dropped = [&](uint32_t i) { return i >= Rr && i < M && !((red.keep >> (i - Rr)) & 1u); };
+  // ---- S (lower triangle): theta_tj (theta_ti G) on the rest block + I, pass-through elsewhere, identity for dropped X ----
+  for (uint32_t i = 0; i < W; ++i) {
+    uint32_t ti;
+    const uint32_t fi = lmg_red_col(prm, i, Rr, ti);
+    const bool di = dropped(i);
+    for (uint32_t j = lane; j <= i; j += GW) {
+      uint32_t tj;
+      const uint32_t fj = lmg_red_col(prm, j, Rr, tj);
+      double acc;
+      if (di || dropped(j)) {
+        acc = i == j ? 1.0 : 0.0;
+      } else {
+        const double g = fi >= fj ? m.gww[(size_t)fi * Wf + fj] : m.gww[(size_t)fj * Wf + fi];
+        const double inner = i < Rr ? 0.0 + theta_of(ti) * g : g;
+        acc = j < Rr ? 0.0 + theta_of(tj) * inner : inner;
+        if (i == j && i < Rr) acc += 1.0;
+      }
+      m.S[(size_t)i * W + j] = acc;
+    }
+  }
+  lmg_sync();
+  // ---- primary blocks (scalars): lane = level ----
+  double logdet = 0.0, pd = 1.0;
+  uint32_t npd = 0;
+  bool ok = true;
+  const double t0 = th[0];
+  for (uint32_t c = lane; c < L0; c += GW) {
+    const double g = m.gzz[(size_t)c * Q0F * Q0F];
+    const double dd = 0.0 + t0 * g * t0 + 1.0;
+    ok = ok && (dd > 0.0);
+    const double lc = __builtin_sqrt(dd);
+    m.ld[c] = log(dd);
+    const ldd* row = m.gzw + (size_t)c * Q0F * Wf;  // intercept row of the level's strip
+    for (uint32_t j = 0; j < W; ++j) {
+      uint32_t tj;
+      const uint32_t fj = lmg_red_col(prm, j, Rr, tj);
+      const double zw = j < Rr ? 0.0 + theta_of(tj) * row[fj] : row[fj];
+      const double tv = 0.0 + t0 * zw;
+      m.B[(size_t)c * W + j] = dropped(j) ? 0.0 : tv / lc;
+    }
+  }
+  ok = __ballot(!ok) == 0ull;
+  lmg_sync();
+  for (uint32_t c = 0; c < L0; ++c) logdet += m.ld[c];
+  for (uint32_t i = 0; i < W; ++i)
+    for (uint32_t j = lane; j <= i; j += GW) {
+      double sacc = m.S[(size_t)i * W + j];
+      for (uint32_t k = 0; k < L0; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
+      m.S[(size_t)i * W + j] = sacc;
+    }
+  lmg_sync();
+  // ---- dense Cholesky over [rest | X]; dropped columns are identities and stay out of the pivot products ----
+  for (uint32_t j = 0; j < M; ++j) {
+    double vv[2] = {0.0, 0.0};
+    uint32_t cntr = 0;
+    for (uint32_t i = j + lane; i < W; i += GW) {
+      double v = m.S[(size_t)i * W + j];
+      for (uint32_t k = 0; k < j; ++k) v -= m.S[(size_t)i * W + k] * m.S[(size_t)j * W + k];
+      vv[cntr++] = v;
+      if (i == j) m.misc[1] = v;
+    }
+    lmg_sync();
+    const double dj = m.misc[1];
+    ok = ok && (dj > 0.0) && (dj < inf);
+    const double ljj = __builtin_sqrt(dj);
+    if (!dropped(j)) {
+      pd *= dj;
+      if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; }
+    }
+    cntr = 0;
+    for (uint32_t i = j + lane; i < W; i += GW) {
+      m.S[(size_t)i * W + j] = i == j ? ljj : vv[cntr] / ljj;
+      ++cntr;
+    }
+    lmg_sync();
+  }
+  logdet += log(pd);
+  double pwrss = m.S[(size_t)M * W + M];
+  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[(size_t)M * W + k] * m.S[(size_t)M * W + k];
+  const double dfr = n_rows - (double)red.p_fit;
+  double lmin = inf, lmax = 0.0;
+  for (uint32_t a = 0; a < p; ++a) {
+    if (!((red.keep >> a) & 1u)) continue;
+    const double v = __builtin_fabs(m.S[(size_t)(Rr + a) * W + Rr + a]);
+    lmin = v < lmin ? v : lmin;
+    lmax = v > lmax ? v : lmax;
+  }
+  ok = ok && (pwrss > 0.0) && (dfr > 0.0) && (lmin / lmax >= 1e-12);
+  if (!ok) return inf;
+  const double dev = logdet + dfr * (1.0 + log(2.0 * 3.14159265358979323846 * pwrss / dfr));
+  if (lane == 0u) {
+    m.misc[0] = pwrss / dfr;
+    for (uint32_t a = 0; a < p; ++a)
+      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[(size_t)(Rr + a) * W + Rr + b] : 0.0;
+    for (int a = (int)p - 1; a >= 0; --a) {
+      double v = m.S[(size_t)M * W + Rr + (uint32_t)a];
+      for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[8u + k * 8u + (uint32_t)a] * m.tail[k];
+      m.tail[a] = v / m.tail[8u + (uint32_t)a * 8u + (uint32_t)a];
+    }
+  }
+  lmg_sync();
+  return (dev < inf && dev > -inf) ? dev : inf;
+}
+
 __device__ __forceinline__ bool lmg_is_diag(const SimParams& prm, uint32_t k) {
   for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) {
     uint32_t o = prm.lmg_theta_off[t];
@@ -317,43 +451,45 @@ __device__ __forceinline__ bool lmg_is_diag(const SimParams& prm, uint32_t k) {
   return false;
 }
 
+template <bool RED>
 __device__ __forceinline__ void lmg_clamp(const SimParams& prm, ldd* x, uint32_t lane) {
-  const uint32_t d = prm.lmg_n_theta;
+  const uint32_t d = RED ? prm.lmg_n_terms : prm.lmg_n_theta;
   if (lane < d) {
     double v = x[lane];
-    if (lmg_is_diag(prm, lane)) v = v < 0.0 ? 0.0 : (v > LMG_THETA_MAX ? LMG_THETA_MAX : v);
+    if (RED || lmg_is_diag(prm, lane)) v = v < 0.0 ? 0.0 : (v > LMG_THETA_MAX ? LMG_THETA_MAX : v);
     else v = v < -LMG_THETA_MAX ? -LMG_THETA_MAX : (v > LMG_THETA_MAX ? LMG_THETA_MAX : v);
     x[lane] = v;
   }
   lmg_sync();
 }
 
-template <int Q0>
+template <int Q0, bool RED>
 __device__ __forceinline__ double lmg_f(const SimParams& prm, const LmgLds& m, ldd* x, uint32_t lane, double n_rows,
-                                        uint32_t& n_eval) {
-  lmg_clamp(prm, x, lane);
+                                        const LmgRed& red, uint32_t& n_eval) {
+  lmg_clamp<RED>(prm, x, lane);
   ++n_eval;
+  if (RED) return lmg_eval_red<Q0>(prm, m, x, lane, n_rows, red);
   return lmg_eval<Q0>(prm, m, x, lane, n_rows);
 }
 
 // one Nelder-Mead run from x0 (simplex row 0) with initial edge `step`; the best point ends in row 0
-template <int Q0>
+template <int Q0, bool RED>
 __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLds m, double step, double ftol, double xtol,
-                                               uint32_t lane, double n_rows, uint32_t& n_eval) {
-  const uint32_t d = prm.lmg_n_theta;
+                                               uint32_t lane, double n_rows, const LmgRed red, uint32_t& n_eval) {
+  const uint32_t d = RED ? prm.lmg_n_terms : prm.lmg_n_theta;
   ldd* sx = m.simplex;            // (d + 4) rows of LMG_MAX_THETA: vertices 0..d, then centroid, xr, xe
   ldd* fv = m.fv;
   ldd* cen = sx + (size_t)(d + 1u) * LMG_MAX_THETA;
   ldd* xr = cen + LMG_MAX_THETA;
   ldd* xe = xr + LMG_MAX_THETA;
   const double inf = __builtin_inf();
-  double f0 = lmg_f<Q0>(prm, m, sx, lane, n_rows, n_eval);
+  double f0 = lmg_f<Q0, RED>(prm, m, sx, lane, n_rows, red, n_eval);
   if (lane == 0u) fv[0] = f0;
   for (uint32_t i = 0; i < d; ++i) {
     ldd* v = sx + (size_t)(i + 1u) * LMG_MAX_THETA;
-    if (lane < d) v[lane] = sx[lane] + (lane == i ? ((lmg_is_diag(prm, i) || sx[i] >= 0.0) ? step : -step) : 0.0);
+    if (lane < d) v[lane] = sx[lane] + (lane == i ? ((RED || lmg_is_diag(prm, i) || sx[i] >= 0.0) ? step : -step) : 0.0);
     lmg_sync();
-    const double fi = lmg_f<Q0>(prm, m, v, lane, n_rows, n_eval);
+    const double fi = lmg_f<Q0, RED>(prm, m, v, lane, n_rows, red, n_eval);
     if (lane == 0u) fv[i + 1u] = fi;
   }
   lmg_sync();
@@ -384,12 +520,12 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
       xr[lane] = c + (c - sx[(size_t)hi * LMG_MAX_THETA + lane]);
     }
     lmg_sync();
-    const double fr = lmg_f<Q0>(prm, m, xr, lane, n_rows, n_eval);
+    const double fr = lmg_f<Q0, RED>(prm, m, xr, lane, n_rows, red, n_eval);
     ldd* worst = sx + (size_t)hi * LMG_MAX_THETA;
     if (fr < flo) {
       if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
       lmg_sync();
-      const double fe = lmg_f<Q0>(prm, m, xe, lane, n_rows, n_eval);
+      const double fe = lmg_f<Q0, RED>(prm, m, xe, lane, n_rows, red, n_eval);
       if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
       if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
     } else if (fr < fnh) {
@@ -399,7 +535,7 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
       const bool outside = fr < fhi;
       if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
       lmg_sync();
-      const double fc = lmg_f<Q0>(prm, m, xe, lane, n_rows, n_eval);
+      const double fc = lmg_f<Q0, RED>(prm, m, xe, lane, n_rows, red, n_eval);
       if (fc < (outside ? fr : fhi)) {
         if (lane < d) worst[lane] = xe[lane];
         if (lane == 0u) fv[hi] = fc;
@@ -409,7 +545,7 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
           ldd* v = sx + (size_t)i * LMG_MAX_THETA;
           if (lane < d) v[lane] = sx[(size_t)lo * LMG_MAX_THETA + lane] + 0.5 * (v[lane] - sx[(size_t)lo * LMG_MAX_THETA + lane]);
           lmg_sync();
-          const double fi = lmg_f<Q0>(prm, m, v, lane, n_rows, n_eval);
+          const double fi = lmg_f<Q0, RED>(prm, m, v, lane, n_rows, red, n_eval);
           if (lane == 0u) fv[i] = fi;
           lmg_sync();
         }
@@ -647,54 +783,123 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
       lmg_sync();
     }
     prev_n = n;
-    // ---- minimise: truth start / carried theta-hat / blind start (batch.rs:1316-1332) ----
-    ldd* x0 = m.simplex;
-    if (lane < d) {
-      double v;
-      if (has_prev) v = m.carry[lane];  // theta-hat of the last converged grid point
-      else if (prm.truth_start) v = prm.lmg_theta_truth[lane];
-      else v = lmg_is_diag(prm, lane) ? 1.0 : 0.0;
-      if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;  // THETA_TRUTH_FLOOR on every component of a given start
-      x0[lane] = v;
-    }
-    lmg_sync();
-    uint32_t n_eval = 0;
-    const double n_rows = (double)n;
-    double best = lmg_nelder_mead<Q0>(prm, m, 0.25, 1e-9, 1e-6, lane, n_rows, n_eval);
-    for (int restart = 0; restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
-      const double prev = best;
-      best = lmg_nelder_mead<Q0>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, n_eval);
-      if (!(prev - best > 1e-8)) break;
-    }
-    // snap small diagonals onto the boundary when that costs no deviance
-    double cur = lmg_f<Q0>(prm, m, x0, lane, n_rows, n_eval);
-    for (uint32_t k = 0; k < d; ++k) {
-      const double keep = x0[k];
-      if (!lmg_is_diag(prm, k) || keep == 0.0 || keep > 1e-4) continue;
-      lmg_sync();
-      if (lane == 0u) x0[k] = 0.0;
-      lmg_sync();
-      const double f0 = lmg_f<Q0>(prm, m, x0, lane, n_rows, n_eval);
-      if (f0 <= cur + 1e-8) cur = f0;
-      else {
-        lmg_sync();
-        if (lane == 0u) x0[k] = keep;
-        lmg_sync();
+    // ---- which model this round fits: sparse-factor flags recounted from rows [0, n) (batch.rs:1236-1250), then the
+    //      kept columns of that flag combination (test_formula subsets included) ----
+    uint32_t flag_bits = 0;
+    const uint32_t full_mask = (1u << P) - 1u;
+    if (prm.red_active && prm.min_level_count) {
+#pragma unroll
+      for (int f = 0; f < MAX_FACTORS; ++f) {
+        if ((uint32_t)f < prm.n_factors) {
+          uint32_t mn = 0xffffffffu;
+          for (uint32_t l = 0; l < prm.f_levels[f]; ++l) {
+            uint32_t cnt = 0;
+            for (uint32_t i = lane; i < n; i += GW) {
+              uint32_t lv = 0;
+#pragma unroll
+              for (int c = 1; c < P; ++c)
+                if (prm.col_factor[c] == (uint32_t)f && m.design[(size_t)(c - 1) * n_pad + i] == 1.0f) lv = prm.col_level[c];
+              cnt += lv == l ? 1u : 0u;
+            }
+#pragma unroll
+            for (int mm = 1; mm < GW; mm <<= 1) cnt += __shfl_xor(cnt, mm, GW);
+            mn = cnt < mn ? cnt : mn;
+          }
+          if (mn < prm.min_level_count) flag_bits |= 1u << f;
+        }
       }
     }
-    const double fin = lmg_f<Q0>(prm, m, x0, lane, n_rows, n_eval);
-    bool conv = fin < __builtin_inf() && n_eval < LMG_MAX_EVAL;
-    uint32_t pinned = 0, comp = 0;
-    bool at_upper = false;
-    for (uint32_t k = 0; k < d; ++k) {
-      if (!lmg_is_diag(prm, k)) continue;
-      if (x0[k] < LMG_THETA_ZERO) pinned |= 1u << comp;
-      if (x0[k] > LMG_THETA_MAX - 1e-3) at_upper = true;
-      ++comp;
+    const uint32_t keep = prm.red_active ? prm.keep_mask[flag_bits] : full_mask;
+    const bool reduced_round = keep != full_mask;
+    LmgRed red;
+    red.keep = keep;
+    red.p_fit = (uint32_t)__popc(keep);
+    const double n_rows = (double)n;
+    ldd* x0 = m.simplex;
+    uint32_t n_eval = 0, pinned = 0;
+    bool conv = false, at_upper = false;
+    if (!reduced_round) {
+      // ---- minimise: truth start / carried theta-hat / blind start (batch.rs:1316-1332) ----
+      if (lane < d) {
+        double v;
+        if (has_prev) v = m.carry[lane];  // theta-hat of the last converged grid point
+        else if (prm.truth_start) v = prm.lmg_theta_truth[lane];
+        else v = lmg_is_diag(prm, lane) ? 1.0 : 0.0;
+        if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;  // THETA_TRUTH_FLOOR on every component of a given start
+        x0[lane] = v;
+      }
+      lmg_sync();
+      double best = lmg_nelder_mead<Q0, false>(prm, m, 0.25, 1e-9, 1e-6, lane, n_rows, red, n_eval);
+      for (int restart = 0; restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
+        const double prev = best;
+        best = lmg_nelder_mead<Q0, false>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, red, n_eval);
+        if (!(prev - best > 1e-8)) break;
+      }
+      // snap small diagonals onto the boundary when that costs no deviance
+      double cur = lmg_f<Q0, false>(prm, m, x0, lane, n_rows, red, n_eval);
+      for (uint32_t k = 0; k < d; ++k) {
+        const double kept_v = x0[k];
+        if (!lmg_is_diag(prm, k) || kept_v == 0.0 || kept_v > 1e-4) continue;
+        lmg_sync();
+        if (lane == 0u) x0[k] = 0.0;
+        lmg_sync();
+        const double f0 = lmg_f<Q0, false>(prm, m, x0, lane, n_rows, red, n_eval);
+        if (f0 <= cur + 1e-8) cur = f0;
+        else {
+          lmg_sync();
+          if (lane == 0u) x0[k] = kept_v;
+          lmg_sync();
+        }
+      }
+      const double fin = lmg_f<Q0, false>(prm, m, x0, lane, n_rows, red, n_eval);
+      conv = fin < __builtin_inf() && n_eval < LMG_MAX_EVAL;
+      uint32_t comp = 0;
+      for (uint32_t k = 0; k < d; ++k) {
+        if (!lmg_is_diag(prm, k)) continue;
+        if (x0[k] < LMG_THETA_ZERO) pinned |= 1u << comp;
+        if (x0[k] > LMG_THETA_MAX - 1e-3) at_upper = true;
+        ++comp;
+      }
+    } else {
+      // ---- reduced round (batch.rs:1343-1400): intercept-only groupings on the kept columns, started at the truth
+      //      taus (or blind); it neither reads nor feeds the theta carry (:1414-1428) ----
+      if (lane < nterms) {
+        double v = prm.truth_start ? prm.lmg_tau[lane] : 1.0;
+        if (prm.truth_start && v < 0.01) v = 0.01;
+        x0[lane] = v;
+      }
+      lmg_sync();
+      double best = lmg_nelder_mead<Q0, true>(prm, m, 0.25, 1e-9, 1e-6, lane, n_rows, red, n_eval);
+      for (int restart = 0; restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
+        const double prev = best;
+        best = lmg_nelder_mead<Q0, true>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, red, n_eval);
+        if (!(prev - best > 1e-8)) break;
+      }
+      double cur = lmg_f<Q0, true>(prm, m, x0, lane, n_rows, red, n_eval);
+      for (uint32_t k = 0; k < nterms; ++k) {
+        const double kept_v = x0[k];
+        if (kept_v == 0.0 || kept_v > 1e-4) continue;
+        lmg_sync();
+        if (lane == 0u) x0[k] = 0.0;
+        lmg_sync();
+        const double f0 = lmg_f<Q0, true>(prm, m, x0, lane, n_rows, red, n_eval);
+        if (f0 <= cur + 1e-8) cur = f0;
+        else {
+          lmg_sync();
+          if (lane == 0u) x0[k] = kept_v;
+          lmg_sync();
+        }
+      }
+      const double fin = lmg_f<Q0, true>(prm, m, x0, lane, n_rows, red, n_eval);
+      conv = fin < __builtin_inf() && n_eval < LMG_MAX_EVAL;
+      for (uint32_t k = 0; k < nterms; ++k) {
+        if (x0[k] < LMG_THETA_ZERO) pinned |= 1u << k;
+        if (x0[k] > LMG_THETA_MAX - 1e-3) at_upper = true;
+      }
     }
     const uint32_t bh = !conv ? 0u : (at_upper ? 2u : (pinned ? 1u : 0u));
     if (at_upper) conv = false;
-    if (conv) {  // grid-sequential warm start (batch.rs:1414-1428): a diverged theta-hat never replaces the carry
+    if (conv && !reduced_round) {  // grid-sequential warm start (batch.rs:1414-1428): a diverged theta-hat never replaces the carry
       if (lane < d) m.carry[lane] = x0[lane];
       has_prev = true;
     }
@@ -709,10 +914,15 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
       const double sigma_sq = m.misc[0];
       const double* crow = prm.crit + (size_t)g * prm.crit_stride;
       double tsq[MAX_T_WAVE];
+      uint32_t tkeep = 0;  // targets whose column is in the fitted model
+#pragma unroll
+      for (int t = 0; t < MAX_T_WAVE; ++t)
+        if ((uint32_t)t < nt && ((keep >> prm.test_pos[t]) & 1u)) tkeep |= 1u << t;
 #pragma unroll
       for (int t = 0; t < MAX_T_WAVE; ++t) {
         tsq[t] = __builtin_nan("");
-        if ((uint32_t)t < nt && conv) {
+        for (uint32_t i = 0; i < p; ++i) U[t * 8 + i] = 0.0;
+        if (((tkeep >> t) & 1u) && conv) {
           const double* c = prm.contrast + t * MAX_P;
           double est = 0.0, nq = 0.0;
           for (uint32_t i = 0; i < p; ++i) {
@@ -727,10 +937,14 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
         }
       }
       bool joint_sig = false;
-      if (conv && nt != 0u) {
+      if (conv && tkeep != 0u) {
         bool jok = true;
         double qsum = 0.0;
         for (uint32_t j = 0; j < nt; ++j) {
+          if (!((tkeep >> j) & 1u)) {  // untestable target: identity row, no contribution
+            for (uint32_t i2 = j; i2 < nt; ++i2) Lc[i2 * 8u + j] = i2 == j ? 1.0 : 0.0;
+            continue;
+          }
           double dd = 0.0;
           for (uint32_t i = 0; i < p; ++i) dd = __builtin_fma(U[j * 8u + i], U[j * 8u + i], dd);
           dd *= sigma_sq;
@@ -748,12 +962,14 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
         for (uint32_t i = 0; i < nt; ++i) {
           const double* c = prm.contrast + i * MAX_P;
           double vv = 0.0;
-          for (uint32_t q = 0; q < p; ++q) vv = __builtin_fma(c[q], beta[q], vv);
+          for (uint32_t q = 0; q < p; ++q) vv = __builtin_fma(((tkeep >> i) & 1u) ? c[q] : 0.0, beta[q], vv);
           for (uint32_t t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i * 8u + t], cj[t], vv);
           cj[i] = vv / Lc[i * 8u + i];
           qsum = __builtin_fma(cj[i], cj[i], qsum);
         }
-        joint_sig = jok && (qsum < __builtin_inf()) && (qsum > crow[2 + nt]);
+        // the table row holds chi2(n_targets); a reduced round tests its kept targets (batch.rs:1456-1468)
+        const double joint_crit = reduced_round ? prm.joint_crit_k[__popc(tkeep)] : crow[2 + nt];
+        joint_sig = jok && (qsum < __builtin_inf()) && (qsum > joint_crit);
       }
       uint32_t unc_bits = 0, cor_bits = 0;
       decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
@@ -772,6 +988,8 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
       prm.boundary[cell] = (uint8_t)bh;
       prm.joint[cell] = joint_sig ? 1 : 0;
       if (prm.pinned) prm.pinned[cell] = (uint16_t)(conv ? pinned : 0u);
+      if (prm.factor_excluded)
+        for (uint32_t f = 0; f < prm.n_factors; ++f) prm.factor_excluded[cell * prm.n_factors + f] = (uint8_t)((flag_bits >> f) & 1u);
       if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1449-1451
       if (prm.stat && g == 0u) {
 #pragma unroll
