@@ -679,6 +679,8 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   if (rc) return fail(rc, err);
   if (prm.between_mask)
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: design capture with cluster-level (between) predictors");
+  if (prm.lmg_active)  // the capture kernel draws the primary random intercept only
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: design capture with random slopes / extra groupings");
   if (n_sims == 0) return MCP_OK;
   hipStream_t st = nullptr;
   rc = ensure_device(&st, nullptr);

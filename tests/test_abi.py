@@ -118,3 +118,13 @@ def test_product_does_not_reference_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "mcpo_" not in txt and "libmcp_oracle" not in txt, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f
+
+
+def test_design_capture_refuses_structures_it_does_not_draw(engine):
+    """mcp_generate_design twins capture_sim0_data with the primary random intercept only: anything it would
+    silently leave out of the outcome is refused (host-side check, no device needed)."""
+    from helpers import load_case
+    spec = load_case("lmm_slope_a")[0]
+    with pytest.raises(S.EngineError) as e:
+        engine.generate_design(spec, 100, 1, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "design capture" in str(e.value)
