@@ -394,8 +394,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     }
     prm.n_seq_pre = prm.n_clusters_max * prm.re_draws_per_cluster;
     if (lmm_general) {
-      if (spec->upload_normal_rows || spec->n_bootstrap_frame_map)
-        return unsupported("random slopes / extra groupings together with uploaded data");
       const mcp_cluster& cl = spec->cluster;
       prm.lmg_active = 1;
       prm.lmg_n_terms = 1 + cl.n_extra_groupings;
@@ -715,7 +713,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     prm.glmm_keep = prm.keep_mask[0];  // every column, or the test_formula subset (flag combination 0: nothing excluded)
     if (!(prm.glmm_keep & 1u)) return unsupported("intercept-free test_formula fit of a clustered GLM");
     prm.red_active = 0;  // no factor exclusion on clustered specs (batch.rs:1583)
-    if (spec->upload_normal_rows || spec->n_bootstrap_frame_map) return unsupported("clustered GLM together with uploaded data");
   }
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))
     return unsupported("intercept-free reduced fit under Glm / Mle");

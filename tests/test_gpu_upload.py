@@ -78,3 +78,35 @@ def test_bootstrap_under_glm_and_scenario(engine, oracle):
     g = engine.run_batch(spec, [150], 2000, 13)
     o = oracle.run_batch(spec, [150], 2000, 13, n_threads=8)
     assert np.array_equal(g.uncorrected, o.uncorrected) and np.array_equal(g.converged, o.converged)
+
+
+def test_uploaded_frames_under_the_mixed_model_kernels(engine, oracle):
+    """NORTA marginals and strict bootstrap rows feed the general LMM and the clustered GLM through the same row
+    builder as every other estimator; the bootstrap uniform follows ALL random-effect draws on the sequential stream."""
+    from helpers import load_case
+    from test_oracle_upload import std_normal_quantile_table, nonlinear_frame
+    # random slope + crossed grouping, x1 from an uploaded (NORTA) column
+    spec = load_case("lmm_slope_crossed")[0]
+    table = [v * 1.0 for v in std_normal_quantile_table(120)]
+    spec.var_types = [S.Distribution.UploadedData]
+    spec.upload_normal, spec.upload_normal_shape = table, (120, 1)
+    spec.scenario.truth_start = True
+    dev = engine.run_batch(spec, [480], 32, 2137)
+    ora = oracle.run_batch(spec, [480], 32, 2137, n_threads=8)
+    same = (dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+    assert same.sum() >= 31 and dev.converged.mean() > 0.9
+    # clustered logistic on strict-bootstrap rows of a two-column frame
+    spec = load_case("glmm_intercept")[0]
+    frame = nonlinear_frame()
+    spec.n_non_factor = 2
+    spec.correlation = [1.0, 0.0, 0.0, 1.0]
+    spec.var_types, spec.var_params = [S.Distribution.UploadedData] * 2, [0.0, 0.0]
+    spec.upload_data, spec.upload_data_shape = [v for r in frame for v in r], (len(frame), 2)
+    spec.bootstrap_frame_map = [0, 1]
+    spec.effect_sizes = [-0.85, 0.5, 0.1]
+    spec.target_indices = [1, 2]
+    spec.scenario.truth_start = True
+    dev = engine.run_batch(spec, [600], 32, 2137)
+    ora = oracle.run_batch(spec, [600], 32, 2137, n_threads=8)
+    same = (dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+    assert same.sum() >= 31 and dev.converged.mean() > 0.9
