@@ -276,6 +276,7 @@ __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ 
   row_ctx_init<P, true>(prm, cx);
   ScenLane<P> sl;
   if (SCEN) scen_lane_load<P>(prm, lsim, sl);
+  const uint32_t bmask = prm.between_mask;
   for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += QW) {
     stage_group<P, QW, 1, SCEN>(prm, k0, k1, ctr, m.st, SCEN ? sl.meta : 0u);
 #pragma unroll
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ 
       if (rr < max_n) {
         const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
         float x[P], y;
-        build_row<P, true, QW, 1, SCEN>(prm, cx, k0, k1, m.st, r, rr, x, y, (double)m.cluster_u[cid < ncl_max ? cid : 0u], &sl);
+        const float e = build_x<P, true, QW, SCEN>(prm, cx, k0, k1, m.st, r, rr, x, &sl);
+        if (bmask == 0u) finish_row<P, 1, SCEN>(prm, cx, x, e, y, (double)m.cluster_u[cid < ncl_max ? cid : 0u], &sl);
+        else y = e;  // the outcome draw waits until the cluster-level columns are broadcast
 #pragma unroll
         for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
         m.design[(size_t)(P - 1) * n_pad + rr] = y;
@@ -292,6 +295,42 @@ __global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ 
     }
   }
   gq_sync();
+  if (bmask != 0u) {
+    // cluster-level predictors (data_gen.rs:606-636), as in lmm_kernels.hip: broadcast from the representative row,
+    // rebuild interactions and the outcome, rewrite the marked columns last
+    for (uint32_t rr = lane; rr < max_n; rr += QW) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cv : rr - (rr % cv);
+      float x[P];
+      x[0] = 1.0f;
+#pragma unroll
+      for (int c = 1; c < P; ++c) {
+        const uint32_t src = ((bmask >> c) & 1u) ? rep : rr;
+        x[c] = m.design[(size_t)(c - 1) * n_pad + src];
+      }
+      rebuild_interactions<P>(cx, x);
+      const float e = m.design[(size_t)(P - 1) * n_pad + rr];
+      const uint32_t cid = prm.cluster_fixed_clusters ? rr % cv : rr / cv;
+      float y;
+      finish_row<P, 1, SCEN>(prm, cx, x, e, y, (double)m.cluster_u[cid < ncl_max ? cid : 0u], &sl);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if (((bmask >> c) & 1u) == 0u && ((cx.inter_any >> c) & 1u)) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
+      m.design[(size_t)(P - 1) * n_pad + rr] = y;
+    }
+    gq_sync();
+    for (uint32_t rr = lane; rr < max_n; rr += QW) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cv : rr - (rr % cv);
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if ((bmask >> c) & 1u) {
+          const float v = m.design[(size_t)(c - 1) * n_pad + rep];
+          __builtin_amdgcn_wave_barrier();
+          m.design[(size_t)(c - 1) * n_pad + rr] = v;
+        }
+    }
+    gq_sync();
+  }
 
   bool has_prev = false;
   double carry = 0.0;

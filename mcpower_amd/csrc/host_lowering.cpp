@@ -247,11 +247,9 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   const bool glmm = spec->cluster.present && spec->estimator == MCP_EST_GLM;  // batch.rs:1575-1830
   if (glmm) {
     if (lmm_general) return unsupported("clustered GLM with random slopes / extra groupings (random intercept only)");
-    if (spec->n_between_var_indices) return unsupported("clustered GLM together with cluster-level predictors");
   }
   if (lmm_general) {
     if (spec->estimator != MCP_EST_MLE) return unsupported("random slopes / extra groupings outside the Mle estimator (clustered GLM: random intercept only)");
-    if (spec->n_between_var_indices) return unsupported("random slopes / extra groupings together with cluster-level predictors");
     if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");
     for (uint32_t t = 0; t <= spec->cluster.n_extra_groupings; ++t) {
       const mcp_re_slopes& sl = t == 0 ? spec->cluster.slopes : spec->cluster.extra[t - 1].slopes;
@@ -298,8 +296,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     err = "invalid spec: scenario.lme requires estimator == Mle";
     return MCP_ERR_INVALID_SPEC;
   }
-  if (spec->n_between_var_indices && spec->cluster.present && spec->estimator != MCP_EST_MLE)
-    return unsupported("cluster-level (between) predictors outside the Mle estimator");
+  if (spec->n_between_var_indices && spec->cluster.present && spec->estimator == MCP_EST_OLS)
+    return unsupported("cluster-level (between) predictors under the OLS estimator");
   for (uint32_t b = 0; b < spec->n_between_var_indices; ++b)
     if (spec->between_var_indices[b] == 0 || spec->between_var_indices[b] >= 1 + K + spec->n_factor_dummies) {
       err = "invalid spec: between_var_indices entry must name a continuous or dummy column";

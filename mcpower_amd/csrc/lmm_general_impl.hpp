@@ -694,6 +694,33 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
   row_ctx_init<P, true>(prm, cx);  // factor columns cost nothing here: generation is a sliver of this kernel
   ScenLane<P> sl;
   if (SCEN) scen_lane_load<P>(prm, lsim, sl);
+  // latent-scale random effect of a row in the reference's order: primary intercept, extras (intercept, slopes),
+  // primary slopes (data_gen.rs:812-842)
+  auto row_effect = [&](uint32_t rr, const float (&x)[P]) -> double {
+    const uint32_t cid = lmg_level_of_row(prm, 0u, rr);
+    double u_re = (double)m.u0[cid];
+    const ldf* ux = m.ux;
+    for (uint32_t t = 1; t < nterms; ++t) {
+      const uint32_t q = prm.lmg_q[t], lvl = lmg_level_of_row(prm, t, rr);
+      u_re += (double)ux[(size_t)lvl * q];
+      for (uint32_t s = 1; s < q; ++s) {
+        float xv = 0.0f;
+#pragma unroll
+        for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[t][s - 1u] ? x[c] : xv;
+        u_re += (double)ux[(size_t)lvl * q + s] * (double)xv;
+      }
+      ux += (size_t)prm.lmg_levels[t] * q;
+    }
+#pragma unroll
+    for (int s = 1; s < Q0; ++s) {
+      float xv = 0.0f;
+#pragma unroll
+      for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[0][s - 1] ? x[c] : xv;
+      u_re += (double)m.us[(size_t)cid * (Q0 - 1) + (s - 1)] * (double)xv;
+    }
+    return u_re;
+  };
+  const uint32_t bmask = prm.between_mask;
   for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += GW) {
     stage_group<P, GW, 0, SCEN>(prm, k0, k1, ctr, m.st, SCEN ? sl.meta : 0u);
 #pragma unroll
@@ -702,33 +729,49 @@ __global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __rest
       if (rr < max_n) {
         float x[P], y;
         const float e = build_x<P, true, GW, SCEN>(prm, cx, k0, k1, m.st, r, rr, x, &sl);
-        // latent-scale random effect in the reference's order: primary intercept, extras (intercept, slopes), primary slopes
-        const uint32_t cid = lmg_level_of_row(prm, 0u, rr);
-        double u_re = (double)m.u0[cid];
-        const ldf* ux = m.ux;
-        for (uint32_t t = 1; t < nterms; ++t) {
-          const uint32_t q = prm.lmg_q[t], lvl = lmg_level_of_row(prm, t, rr);
-          u_re += (double)ux[(size_t)lvl * q];
-          for (uint32_t s = 1; s < q; ++s) {
-            float xv = 0.0f;
-#pragma unroll
-            for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[t][s - 1u] ? x[c] : xv;
-            u_re += (double)ux[(size_t)lvl * q + s] * (double)xv;
-          }
-          ux += (size_t)prm.lmg_levels[t] * q;
-        }
-#pragma unroll
-        for (int s = 1; s < Q0; ++s) {
-          float xv = 0.0f;
-#pragma unroll
-          for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[0][s - 1] ? x[c] : xv;
-          u_re += (double)m.us[(size_t)cid * (Q0 - 1) + (s - 1)] * (double)xv;
-        }
-        finish_row<P, 0, SCEN>(prm, cx, x, e, y, u_re, &sl);
+        if (bmask == 0u) finish_row<P, 0, SCEN>(prm, cx, x, e, y, row_effect(rr, x), &sl);
+        else y = e;  // the residual waits in the outcome slot until the cluster-level columns are broadcast
 #pragma unroll
         for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
         m.design[(size_t)(P - 1) * n_pad + rr] = y;
       }
+    }
+  }
+  if (bmask != 0u) {
+    // cluster-level predictors (data_gen.rs:606-636): every row takes the marked columns from its primary cluster's
+    // representative row, then interactions, the random-effect contribution and the outcome follow from the
+    // broadcast values; the marked columns themselves are rewritten last (see lmm_kernels.hip)
+    lmg_sync();
+    const uint32_t cvb = prm.cluster_v;
+    for (uint32_t rr = lane; rr < max_n; rr += GW) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cvb : rr - (rr % cvb);
+      float x[P];
+      x[0] = 1.0f;
+#pragma unroll
+      for (int c = 1; c < P; ++c) {
+        const uint32_t src = ((bmask >> c) & 1u) ? rep : rr;
+        x[c] = m.design[(size_t)(c - 1) * n_pad + src];
+      }
+      rebuild_interactions<P>(cx, x);
+      const float e = m.design[(size_t)(P - 1) * n_pad + rr];
+      float y;
+      finish_row<P, 0, SCEN>(prm, cx, x, e, y, row_effect(rr, x), &sl);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if (((bmask >> c) & 1u) == 0u && ((cx.inter_any >> c) & 1u)) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
+      m.design[(size_t)(P - 1) * n_pad + rr] = y;
+    }
+    lmg_sync();
+    for (uint32_t rr = lane; rr < max_n; rr += GW) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cvb : rr - (rr % cvb);
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if ((bmask >> c) & 1u) {
+          const float v = m.design[(size_t)(c - 1) * n_pad + rep];
+          __builtin_amdgcn_wave_barrier();
+          m.design[(size_t)(c - 1) * n_pad + rr] = v;
+        }
     }
   }
   // ---- 3. sufficient statistics, zeroed once and grown over the grid ----

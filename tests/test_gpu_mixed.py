@@ -148,3 +148,33 @@ def test_general_lmm_under_scenario_presets(name, preset_name, engine, oracle):
             & (dev.boundary_hit == ora.boundary_hit).all(axis=1) & (dev.pinned_components == ora.pinned_components).all(axis=1))
     assert same.sum() >= 94, (name, preset_name, np.flatnonzero(~same))
     assert dev.converged.mean() > 0.85
+
+
+def test_cluster_level_predictors_under_general_lmm_and_clustered_glm(engine, oracle):
+    """A cluster-randomised design: treatment (x2) assigned per cluster, x1 varying within; a random slope on x1 and
+    the cross-level interaction x1:x2 (data_gen.rs:606-636 broadcast before interactions, effects and outcome)."""
+    from mcpower_amd import spec as S
+    spec = S.SimulationSpec(n_non_factor=2, correlation=[1.0, 0.0, 0.0, 1.0], var_types=[S.Distribution.Normal] * 2,
+                            var_params=[0.0, 0.0], interactions=[[1, 2]], effect_sizes=[0.0, 0.3, 0.4, 0.2],
+                            target_indices=[1, 2, 3], between_var_indices=[2], estimator=S.EstimatorSpec.Mle,
+                            cluster=S.ClusterSpec(sizing=("FixedClusters", 16), tau_squared=0.25,
+                                                  slopes=[{"column": 0, "variance": 0.1, "corr_with_intercept": 0.2,
+                                                           "corr_with": []}]),
+                            cluster_slope_design_cols=[1], max_failed_fraction=1.0,
+                            scenario=S.ScenarioPerturbations(name="optimistic", truth_start=True))
+    dev = engine.run_batch(spec, [160, 320], 48, BASE_SEED)
+    ora = oracle.run_batch(spec, [160, 320], 48, BASE_SEED, n_threads=8)
+    same = ((dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+            & (dev.pinned_components == ora.pinned_components).all(axis=1) & (dev.joint_unc == ora.joint_unc).all(axis=1))
+    assert same.sum() >= 47 and dev.converged.mean() > 0.9
+    # the same design with a binary outcome and a random intercept: clustered GLM
+    spec.estimator, spec.outcome_kind = S.EstimatorSpec.Glm, S.OutcomeKind.Binary
+    spec.cluster = S.ClusterSpec(sizing=("FixedSize", 20), tau_squared=0.6)
+    spec.cluster_slope_design_cols = []
+    spec.effect_sizes = [-0.4, 0.4, 0.5, 0.2]
+    dev = engine.run_batch(spec, [320], 48, BASE_SEED)
+    ora = oracle.run_batch(spec, [320], 48, BASE_SEED, n_threads=8)
+    same = (dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+    assert same.sum() >= 47 and dev.converged.mean() > 0.9
+    both = (dev.converged == 1) & (ora.converged == 1)
+    assert np.allclose(dev.tau_squared_hat[both], ora.tau_squared_hat[both], rtol=1e-4, atol=1e-7)
