@@ -50,6 +50,8 @@ WORKLOADS = {
     # clustered logistic (reference case glmm_intercept, formulas.R:1092-1100): 1 230 draws + ~300 evaluations of the
     # Laplace deviance, each ~6 Fisher-scoring sweeps over the 600 rows (exp, log1p, ~25 flops per row)
     "glmm": ("spec_glmm", 600, 4.5e7, 4 * 600 * 2),
+    # ... with a random slope (reference case glmm_slope, formulas.R): ~900 evaluations, 2 x 2 penalised systems per cluster
+    "glmm_slope": ("spec_glmm_slope", 600, 1.6e8, 4 * 600 * 2),
     "lmm_slope": ("spec_lmm_slope", 480, 2.6e5, 4 * 480 * 2),
     "lmm_crossed": ("spec_lmm_crossed", 480, 3.4e5, 4 * 480 * 3),
     # C5: C2b design on the grid N = 50..1000 (20 prefix fits per replicate on shared draws) under the three
@@ -132,7 +134,7 @@ def main():
     if args.workload.startswith("c5_"):
         spec.scenario = helpers.preset(args.workload[3:])
         ns = helpers.C5_GRID
-    S = args.sims_per_gpu or ({"c3": 100_000, "c4": 10_000, "lmm_slope": 10_000, "lmm_crossed": 10_000, "glmm": 10_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
+    S = args.sims_per_gpu or ({"c3": 100_000, "c4": 10_000, "lmm_slope": 10_000, "lmm_crossed": 10_000, "glmm": 10_000, "glmm_slope": 4_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
     staged = args.pipeline == "staged"
 
     def barrier():
@@ -201,19 +203,19 @@ def main():
             "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
-                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
+            "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM', 'glmm_slope': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
+                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'glmm_slope': 'logit, Laplace, (1 + x1 | g), 30 clusters x 20', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": "1 all-reduce(sum) of counters per step"},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),
         }
-        is_ols = args.workload not in ("c3", "c4", "lmm_slope", "lmm_crossed", "glmm")
+        is_ols = args.workload not in ("c3", "c4", "lmm_slope", "lmm_crossed", "glmm", "glmm_slope")
         is_c5 = args.workload.startswith("c5_")
         if not staged:
             fits_per_launch *= len(ns)  # a replicate on a grid is len(ns) prefix fits (throughput.rs:1111-1113)
             ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
+            out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"glmm_slopes_kernel<{spec.n_predictors},2>" if args.workload == "glmm_slope" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
                                "traffic": (pmc_traffic(args.workload, f"ols_sim_kernel<{spec.n_predictors}, 0,")
                                            if (is_ols and not is_c5 and S == 1_000_000) else None),
@@ -246,10 +248,11 @@ def main():
             # the CPU oracle ("port"): same spec, same seeds, on this host's cores, bounded sample
             from oracle import oracle
             cores = max(1, min(os.cpu_count() or 1, 16))
+            probe = 50_000 if is_ols else 2_000  # iterative fits run 1e2..1e4 per second: keep the probe in seconds
             t1 = time.perf_counter()
-            oracle.run_batch(spec, ns, 50_000, helpers.BASE_SEED, n_threads=cores)
-            rate = 50_000 / (time.perf_counter() - t1)
-            sample = int(min(max(rate * args.cpu_seconds, 50_000), 40_000_000))
+            oracle.run_batch(spec, ns, probe, helpers.BASE_SEED, n_threads=cores)
+            rate = probe / (time.perf_counter() - t1)
+            sample = int(min(max(rate * args.cpu_seconds, probe), 40_000_000))
             t1 = time.perf_counter()
             o = oracle.run_batch(spec, ns, sample, helpers.BASE_SEED, n_threads=cores)
             dt = time.perf_counter() - t1

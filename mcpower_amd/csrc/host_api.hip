@@ -41,6 +41,9 @@ size_t lmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 size_t lmm_rec_fields(int P, uint32_t ncl_max);
 hipError_t launch_glmm(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool scen, hipStream_t st);
 size_t glmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
+hipError_t launch_glmm_slopes(int P, int Q, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool scen,
+                              hipStream_t st);
+size_t glmm_slopes_lds_bytes(int P, int Q, uint32_t max_n, uint32_t ncl_max);
 hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 hipError_t launch_lmm_general_scen(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 size_t lmg_lds_bytes(const SimParams& prm);
@@ -289,7 +292,9 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
   const bool lmg = mle && prm.lmg_active;  // random slopes / extra groupings: the general mixed-model kernel
   const bool glmm = prm.glmm_active != 0u;  // clustered GLM: random-intercept GLMM kernel (writes flags like the Mle arm)
-  if (glmm && mcp::glmm_lds_bytes((int)P, prm.max_n, prm.n_clusters_max) > 158u * 1024u) {
+  const bool glmm_slopes = glmm && prm.lmg_active;  // ... with random slopes on the primary grouping (vector modes)
+  if (glmm && (glmm_slopes ? mcp::glmm_slopes_lds_bytes((int)P, (int)prm.lmg_q[0], prm.max_n, prm.n_clusters_max)
+                           : mcp::glmm_lds_bytes((int)P, prm.max_n, prm.n_clusters_max)) > 158u * 1024u) {
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: clustered GLM design does not fit one wave's LDS budget");
   }
@@ -509,7 +514,8 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (glmm) DEV_TRY(mcp::launch_glmm((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, scen, st));
+      if (glmm_slopes) DEV_TRY(mcp::launch_glmm_slopes((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, scen, st));
+      else if (glmm) DEV_TRY(mcp::launch_glmm((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, scen, st));
       else if (lmg && scen) DEV_TRY(mcp::launch_lmm_general_scen((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (lmg) DEV_TRY(mcp::launch_lmm_general((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (mle) DEV_TRY(mcp::launch_lmm_sim((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, spec->n_factors > 0, glm_reduced, scen, st));

@@ -327,7 +327,8 @@ static double glmm_joint(const mcpo_gen_fit* f, uint32_t p, const uint32_t* targ
   return q;
 }
 
-/* clustered-GLM branch of the Glm arm (batch.rs:1575-1830): random intercept only.  No factor exclusion on clustered
+/* clustered-GLM branch of the Glm arm (batch.rs:1575-1830): random intercept, optionally random slopes on the primary
+ * grouping (fit_glmm_slopes.c; theta is then the column-major vech of the lower template).  No factor exclusion on clustered
  * specs (:1583); test_formula fits the kept columns; theta start = carried theta-hat / truth / blind, floored at 0.01
  * when given (:1650-1690); beta start = the truth, unconditionally; joint crit = chi2_ppf(1 - alpha, k) (:1757-1762). */
 int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const uint32_t* ns, uint32_t n_ns,
@@ -335,7 +336,9 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
                   uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* overall, double* tau_hat, double* stat_row,
                   uint64_t* pinned) {
   const mcp_cluster* cl = &spec->cluster;
-  if (!cl->present || cl->slopes.n_slopes || cl->n_extra_groupings) return MCP_ERR_UNSUPPORTED;
+  if (!cl->present || cl->n_extra_groupings || cl->slopes.n_slopes > 2) return MCP_ERR_UNSUPPORTED;
+  const uint32_t q = 1 + cl->slopes.n_slopes, nth = q * (q + 1) / 2;
+  uint32_t slope_cols[2] = {0, 0};
   if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS || spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;
   if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
   const int fam = spec->outcome_kind == MCP_OUTCOME_COUNT ? 2 : (spec->link == MCP_LINK_PROBIT ? 1 : 0);
@@ -354,6 +357,7 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
   double beta0[MCPO_MAX_P];
   if (!test_reduces) {
     for (uint32_t c = 0; c < p; ++c) { remap[c] = (int32_t)c; beta0[c] = spec->effect_sizes[c]; }
+    for (uint32_t d = 0; d + 1 < q; ++d) slope_cols[d] = cl->slopes.design_cols[d];
   } else {
     uint8_t none[16] = {0};
     p_fit = mcpo_build_exclusion_remap(spec, none, kept, remap);
@@ -364,18 +368,30 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
       beta0[rj] = spec->effect_sizes[kept[rj]];
     }
     xfit = xr;
+    for (uint32_t d = 0; d + 1 < q; ++d) {  /* a random slope needs its column in the fitted design */
+      if (remap[cl->slopes.design_cols[d]] < 0) { free(ids); free(xr); return MCP_ERR_UNSUPPORTED; }
+      slope_cols[d] = (uint32_t)remap[cl->slopes.design_cols[d]];
+    }
   }
   int has_prev = 0, rc = MCP_OK;
-  double carry = 0.0;
+  double carry = 0.0, carry_v[6] = {0};
   for (uint32_t g = 0; g < n_ns && rc == MCP_OK; ++g) {
     const uint32_t n = ns[g];
     const uint32_t ncl = fixed_clusters ? cv : (n + cv - 1) / cv;
     double th0 = has_prev ? carry : (spec->scenario.truth_start ? sqrt(fmax(cl->tau_squared, 0.0)) : 1.0);
     if ((has_prev || spec->scenario.truth_start) && th0 < 0.01) th0 = 0.01;
     mcpo_gen_fit f;
-    rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, &f);
+    if (q == 1) {
+      rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, &f);
+    } else {
+      double tv[12];
+      const double* start = NULL;
+      if (has_prev) start = carry_v;
+      else if (spec->scenario.truth_start) { mcpo_truth_theta(cl, 1, tv); start = tv; }
+      rc = mcpo_glmm_slopes_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, q, slope_cols, start, beta0, &f);
+    }
     if (rc) break;
-    if (f.converged) { carry = f.theta[0]; has_prev = 1; }
+    if (f.converged) { carry = f.theta[0]; memcpy(carry_v, f.theta, sizeof(double) * nth); has_prev = 1; }
     const double* crow = crit + (size_t)g * crit_stride;
     conv[g] = (uint8_t)f.converged;
     bh[g] = f.boundary_hit;

@@ -307,6 +307,33 @@ def glmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, f
                 boundary_hit=bh.value, n_eval=ne.value)
 
 
+def glmm_slopes_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, slope_cols, family: str = "logit",
+                    theta_start=None, beta_start=None):
+    """GLMM with random slopes on the primary grouping (Laplace, "rx" SE) on provided bytes."""
+    n, p = design.shape
+    x = np.ascontiguousarray(design.T, dtype=np.float32)
+    y = np.ascontiguousarray(outcome, dtype=np.float32)
+    ids = np.ascontiguousarray(cluster_ids, dtype=np.uint32)
+    ncl, q = int(ids.max()) + 1, 1 + len(slope_cols)
+    cols = np.asarray(list(slope_cols) + [0, 0], dtype=np.uint32)
+    beta, se = np.zeros(p), np.zeros(p)
+    theta, vars_out = np.zeros(6), np.zeros((3, 3))
+    conv, bh, ne, pinned = C.c_uint8(), C.c_uint8(), C.c_uint32(), C.c_uint64()
+    pd = C.POINTER(C.c_double)
+    t0 = None if theta_start is None else np.ascontiguousarray(theta_start, dtype=np.float64)
+    b0 = None if beta_start is None else np.ascontiguousarray(beta_start, dtype=np.float64)
+    rc = lib().mcpo_glmm_slopes_fit(C.c_int(GLM_FAMILIES[family]), x.ctypes.data_as(C.POINTER(C.c_float)),
+                                    y.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                    C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), C.c_uint32(ncl), C.c_uint32(q),
+                                    cols.ctypes.data_as(C.POINTER(C.c_uint32)), None if t0 is None else t0.ctypes.data_as(pd),
+                                    None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
+                                    se.ctypes.data_as(pd), theta.ctypes.data_as(pd), vars_out.ctypes.data_as(pd),
+                                    C.byref(conv), C.byref(bh), C.byref(pinned), C.byref(ne))
+    _check(rc)
+    return dict(beta=beta, se=se, theta=theta[:q * (q + 1) // 2], cov=vars_out[:q, :q], converged=bool(conv.value),
+                boundary_hit=bh.value, pinned=pinned.value, n_eval=ne.value)
+
+
 def lmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, theta_start: float = 0.0):
     """Random-intercept REML on provided bytes: design (n, p), outcome (n,), 0-based cluster ids (n,)."""
     n, p = design.shape

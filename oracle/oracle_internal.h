@@ -64,6 +64,10 @@ void mcpo_fam_eval(int fam, double eta, double yi, double* w_out, double* z_out,
 int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld, uint32_t p,
                       uint32_t ncl, double theta0, const double* beta0, mcpo_gen_fit* f);
 
+int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld,
+                             uint32_t p, uint32_t ncl, uint32_t q, const uint32_t* slope_cols, const double* theta0,
+                             const double* beta0, mcpo_gen_fit* f);
+
 /* OLS sufficient statistics + fit (fit_ols.c) */
 typedef struct mcpo_olsfit_t {
   uint32_t p;

@@ -184,6 +184,13 @@ def spec_glmm() -> S.SimulationSpec:
     return spec
 
 
+def spec_glmm_slope() -> S.SimulationSpec:
+    """Reference case glmm_slope (validation/formulas.R:1103-1115): logit, y ~ x1 + (1 + x1 | g), 30 clusters x 20."""
+    spec = load_case("glmm_slope")[0]
+    spec.scenario.truth_start = True
+    return spec
+
+
 def spec_lmm_slope() -> S.SimulationSpec:
     """Reference case lmm_slope_a (validation/formulas.R:461-469): y ~ x1 + (1 + x1 | g), 24 clusters x 20."""
     spec = load_case("lmm_slope_a")[0]

@@ -74,11 +74,54 @@ def test_glmm_two_predictors_fixed_size_clusters_counters_and_shards(engine, ora
 
 def test_glmm_refuses_what_it_cannot_do(engine):
     spec, _, a, low = load_case("glmm_intercept")
-    spec.cluster.slopes = [{"column": 0, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": []}]
-    spec.cluster_slope_design_cols = [1]
+    spec.cluster.extra_groupings = [{"relation": {"Crossed": {"n_clusters": 8}}, "tau_squared": 0.2, "slopes": []}]
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(spec, [600], 4, BASE_SEED)
-    assert e.value.status == S.Status.Unsupported and "random intercept only" in str(e.value)
+    assert e.value.status == S.Status.Unsupported and "extra groupings" in str(e.value)
+
+
+# ---- random slopes on the primary grouping: glmm_slopes_kernels.hip vs oracle/fit_glmm_slopes.c ----
+
+@pytest.mark.parametrize("name,truth", [("glmm_slope", True), ("glmm_slope", False), ("glmm_multislope", True)])
+def test_glmm_slopes_match_oracle(name, truth, engine, oracle):
+    spec, _, a, low = load_case(name)
+    spec.scenario.truth_start = truth
+    n_sims = 32 if name == "glmm_slope" else 16
+    ns = [400, low["n"]]
+    dev, stat = engine.run_batch_st_capture(spec, ns, n_sims, BASE_SEED)
+    ora = oracle.run_batch(spec, ns, n_sims, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.85
+    _compare(dev, ora, n_sims, stat, ora.stat_capture, slack=2)
+
+
+def test_glmm_slopes_dataset_is_the_reference_capture(engine, oracle):
+    """sim 0 of the reference's glmm_slope seed: the device's decision equals a refit of the captured bytes."""
+    spec, base_seed, a, low = load_case("glmm_slope")
+    spec.scenario.truth_start = True
+    dev, stat = engine.run_batch_st_capture(spec, [low["n"]], 1, base_seed)
+    f = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], [1], family="logit",
+                               theta_start=oracle.truth_theta(spec), beta_start=spec.effect_sizes)
+    assert dev.converged[0, 0] == 1 and f["converged"]
+    assert np.isclose(stat[0, 0], (f["beta"][1] / f["se"][1]) ** 2, rtol=1e-5)
+    assert np.isclose(dev.tau_squared_hat[0, 0], f["theta"][0] ** 2, rtol=1e-4)
+    assert dev.pinned_components[0, 0] == f["pinned"]
+
+
+def test_glmm_slopes_probit_scenario_and_counters(engine, oracle):
+    from helpers import preset
+    spec, _, a, low = load_case("glmm_slope")
+    spec.link = S.LinkKind.Probit
+    spec.effect_sizes = [-0.52, 0.30]
+    spec.cluster.tau_squared = 0.25
+    spec.scenario = preset("realistic")
+    spec.scenario.lme = S.LmeScenarioPerturbations(random_effect_dist=S.ResidualDist.HighKurtosis, random_effect_df=6.0,
+                                                   icc_noise_sd=0.15)
+    dev = engine.run_batch(spec, [600], 32, BASE_SEED)
+    ora = oracle.run_batch(spec, [600], 32, BASE_SEED, n_threads=8)
+    assert dev.converged.mean() > 0.8
+    _compare(dev, ora, 32, slack=2)
+    red = engine.run_batch(spec, [600], 32, BASE_SEED, per_sim=False)
+    assert np.array_equal(red.counters, dev.counters)
 
 
 @pytest.mark.parametrize("preset_name", ["realistic", "doomer"])

@@ -68,3 +68,61 @@ def test_glmm_arm_run_batch(oracle):
             assert bool(f["z_sq"][1] > crit[0, 0]) == bool(r.uncorrected[sim, 0, 0])
             assert abs(f["tau_sq"] - r.tau_squared_hat[sim, 0]) < 1e-9
     assert r.uncorrected[:, 1, 0].mean() > 0.9          # beta 0.5 at n = 600: se ~ 0.11
+
+
+# ---- random slopes on the primary grouping (fit_glmm_slopes.c) ----
+
+SLOPE_CASES = {"glmm_slope": [1], "glmm_multislope": [1, 2]}
+
+
+@pytest.mark.parametrize("name", sorted(SLOPE_CASES))
+def test_glmm_slope_datasets_are_reproduced_bit_exact(name, oracle):
+    spec, base_seed, a, low = load_case(name)
+    x, y, ids, _ = oracle.generate_sim_data_ids(spec, base_seed, 0, low["n"])
+    assert np.array_equal(ids, a["cluster_ids"]) and np.array_equal(x, a["design"]) and np.array_equal(y, a["outcome"])
+
+
+@pytest.mark.parametrize("start", ["blind", "truth"])
+@pytest.mark.parametrize("name", sorted(SLOPE_CASES))
+def test_laplace_slopes_fit_matches_glmer(name, start, oracle):
+    """beta-hat inside GLMM_TOL (tolerances.R:186-200); variance components at the band glmer's own convergence allows
+    on these (near-)singular fits: glmm_slope sits on the corr = -1 boundary, where one component is pinned."""
+    spec, _, a, low = load_case(name)
+    kw = {} if start == "blind" else dict(theta_start=oracle.truth_theta(spec), beta_start=spec.effect_sizes)
+    r = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], SLOPE_CASES[name], family="logit", **kw)
+    assert r["converged"]
+    assert np.all(np.abs(r["beta"] - a["golden_beta"]) <= np.maximum(1e-4 * np.abs(a["golden_beta"]), 1e-3))
+    assert np.allclose(np.diag(r["cov"]), a["golden_vars"], rtol=1e-2)
+    sd = np.sqrt(np.diag(r["cov"]))
+    corr = (r["cov"] / np.outer(sd, sd))[np.tril_indices(len(sd), -1)]
+    assert np.allclose(corr, a["golden_corr"], atol=5e-3)
+    if name == "glmm_slope":
+        assert r["boundary_hit"] == 1 and r["pinned"] == 2 and abs(corr[0] + 1.0) < 1e-6
+
+
+def test_slopes_fit_with_q1_equals_the_scalar_fit(oracle):
+    spec, _, a, low = load_case("glmm_intercept")
+    s = oracle.glmm_fit(a["design"], a["outcome"], a["cluster_ids"], family="logit")
+    v = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], [], family="logit")
+    assert np.allclose(v["beta"], s["beta"], atol=1e-6) and abs(v["theta"][0] - s["theta"]) < 1e-6
+    assert np.allclose(v["se"], s["se"], rtol=1e-6)
+
+
+def test_glmm_arm_with_slopes_run_batch(oracle):
+    """run_batch routes a clustered GLM with primary slopes through the vector-mode fit: decisions equal refits of the
+    same bytes from the same start, tau-hat^2 = theta[0]^2, the grid carries the whole theta vector."""
+    spec, _, a, low = load_case("glmm_slope")
+    spec.scenario.truth_start = True
+    r = oracle.run_batch(spec, [400, 600], 12, BASE_SEED, n_threads=8)
+    assert r.converged.mean() > 0.8
+    crit = oracle.build_crit_table(spec, [400, 600])
+    th0 = oracle.truth_theta(spec)
+    for sim in range(3):
+        x, y, ids, _ = oracle.generate_sim_data_ids(spec, BASE_SEED, sim, 600)
+        f = oracle.glmm_slopes_fit(x[:400], y[:400], ids[:400], [1], family="logit", theta_start=th0, beta_start=spec.effect_sizes)
+        assert f["converged"] == bool(r.converged[sim, 0])
+        if f["converged"]:
+            z_sq = (f["beta"][1] / f["se"][1]) ** 2
+            assert bool(z_sq > crit[0, 0]) == bool(r.uncorrected[sim, 0, 0])
+            assert abs(f["theta"][0] ** 2 - r.tau_squared_hat[sim, 0]) < 1e-9
+            assert f["pinned"] == r.pinned_components[sim, 0]
