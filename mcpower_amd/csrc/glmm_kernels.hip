@@ -14,6 +14,9 @@
 // the cluster terms are then summed in cluster order by every lane, so the objective -- and with it every branch of
 // the simplex -- is wave-uniform.  The Wald covariance ("rx": (X'WX - sum_c theta^2 a_c a_c' / (theta^2 sw_c + 1))^-1,
 // a_c = X_c' w_c) is formed once at the optimum.
+#ifndef MCP_GLMM_WAVES
+#define MCP_GLMM_WAVES 2  // waves per SIMD the register allocator leaves room for: 2 beats 1 by 1.35-1.5x on MI355X (profiles/r01_j_occupancy.txt)
+#endif
 #include <hip/hip_runtime.h>
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
@@ -78,7 +81,11 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
   }
   gq_sync();
   const uint32_t cv = prm.cluster_v;
-  for (uint32_t c = lane; c < ncl; c += QW) {
+  // few clusters leave lanes idle: 2^ls lanes share a cluster, each takes every 2^ls-th row, and an xor butterfly
+  // leaves the same sums (bit for bit: a + b == b + a) in all of them, so the group iterates in lockstep
+  const uint32_t ls = ncl <= 8u ? 3u : (ncl <= 16u ? 2u : (ncl <= 32u ? 1u : 0u));
+  const uint32_t sub = lane & ((1u << ls) - 1u);
+  for (uint32_t c = lane >> ls; c < ncl; c += QW >> ls) {
     const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
     const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
     const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
@@ -88,13 +95,18 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         double swz = 0.0;
         sw = 0.0;
         dev = 0.0;
-        for (uint32_t i = first; i < last; i += step) {
+        for (uint32_t i = first + sub * step; i < last; i += step << ls) {
           const double e0 = m.eta0[i];
           double w, wz, d;
           fam_eval(fam, e0 + theta * u, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, d);
           sw += w;
           swz += wz - w * e0;  // w (z - eta0)
           dev += d;
+        }
+        for (uint32_t o = 1u; o < (1u << ls); o <<= 1) {
+          sw += __shfl_xor(sw, (int)o);
+          swz += __shfl_xor(swz, (int)o);
+          dev += __shfl_xor(dev, (int)o);
         }
         const double pd = dev + u * u;
         if (it > 0 && __builtin_fabs(pd - pd_prev) <= 1e-13 * (__builtin_fabs(pd) + 1.0)) break;
@@ -104,12 +116,14 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         if (un == u) break;
         u = un;
       }
-      m.tcl[c] = dev + u * u + log(theta * theta * sw + 1.0);
-    } else {
+      if (sub == 0u) m.tcl[c] = dev + u * u + log(theta * theta * sw + 1.0);
+    } else if (sub == 0u) {
       m.tcl[c] = 0.0;
     }
-    m.ucl[c] = u;
-    m.swcl[c] = sw;
+    if (sub == 0u) {
+      m.ucl[c] = u;
+      m.swcl[c] = sw;
+    }
   }
   gq_sync();
   double total = 0.0;
@@ -230,7 +244,7 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
 template <int P, bool SCEN>
-__global__ __launch_bounds__(QW) void glmm_kernel(const SimParams* __restrict__ pp) {
+__global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_q[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;

@@ -17,6 +17,9 @@
 // the cluster terms are then summed in cluster order by every lane, so the objective -- and with it every branch of
 // the simplex -- is wave-uniform.  The Wald covariance ("rx": (X'WX - sum_c theta^2 a_c a_c' / (theta^2 sw_c + 1))^-1,
 // a_c = X_c' w_c) is formed once at the optimum.
+#ifndef MCP_GLMM_WAVES
+#define MCP_GLMM_WAVES 2  // waves per SIMD the register allocator leaves room for: 2 beats 1 by 1.35-1.5x on MI355X (profiles/r01_j_occupancy.txt)
+#endif
 #include <hip/hip_runtime.h>
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
@@ -91,7 +94,10 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
   gq_sync();
   const uint32_t cv = prm.cluster_v;
   bool ok = true;
-  for (uint32_t c = lane; c < ncl; c += QW) {
+  // 2^ls lanes share a cluster (see glmm_kernels.hip): every 2^ls-th row each, xor butterfly over the partial sums
+  const uint32_t ls = ncl <= 8u ? 3u : (ncl <= 16u ? 2u : (ncl <= 32u ? 1u : 0u));
+  const uint32_t sub = lane & ((1u << ls) - 1u);
+  for (uint32_t c = lane >> ls; c < ncl; c += QW >> ls) {
     const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
     const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
     const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
@@ -113,7 +119,7 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
           for (int dd = 0; dd < Q; ++dd) M[b][dd] = 0.0;
         }
         dev = 0.0;
-        for (uint32_t i = first; i < last; i += step) {
+        for (uint32_t i = first + sub * step; i < last; i += step << ls) {
           double z[Q], a[Q], au = 0.0;
           z[0] = 1.0;
 #pragma unroll
@@ -138,6 +144,16 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
 #pragma unroll
             for (int dd = 0; dd < Q; ++dd)
               if (dd <= b) M[b][dd] += w * a[b] * a[dd];
+          }
+        }
+        for (uint32_t o = 1u; o < (1u << ls); o <<= 1) {
+          dev += __shfl_xor(dev, (int)o);
+#pragma unroll
+          for (int b = 0; b < Q; ++b) {
+            r[b] += __shfl_xor(r[b], (int)o);
+#pragma unroll
+            for (int dd = 0; dd < Q; ++dd)
+              if (dd <= b) M[b][dd] += __shfl_xor(M[b][dd], (int)o);
           }
         }
         double uu = 0.0;
@@ -202,15 +218,17 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
       double uu = 0.0;
 #pragma unroll
       for (int b = 0; b < Q; ++b) uu += u[b] * u[b];
-      m.tcl[c] = dev + uu + logdet;
-    } else {
+      if (sub == 0u) m.tcl[c] = dev + uu + logdet;
+    } else if (sub == 0u) {
       m.tcl[c] = 0.0;
     }
+    if (sub == 0u) {
 #pragma unroll
-    for (int b = 0; b < Q; ++b) {
-      m.ucl[(size_t)c * Q + b] = u[b];
+      for (int b = 0; b < Q; ++b) {
+        m.ucl[(size_t)c * Q + b] = u[b];
 #pragma unroll
-      for (int dd = 0; dd < Q; ++dd) m.lmcl[((size_t)c * Q + b) * Q + dd] = Lm[b][dd];
+        for (int dd = 0; dd < Q; ++dd) m.lmcl[((size_t)c * Q + b) * Q + dd] = Lm[b][dd];
+      }
     }
   }
   ok = __ballot(!ok) == 0ull;
@@ -350,7 +368,7 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
 template <int P, int Q, bool SCEN>
-__global__ __launch_bounds__(QW) void glmm_slopes_kernel(const SimParams* __restrict__ pp) {
+__global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_q[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;

@@ -21,6 +21,9 @@
 //      runs over the rest and X columns with y riding along as the right-hand side.
 // Wave-uniform control flow throughout: all 64 lanes carry the same simplex and take the same branches.
 #pragma once
+#ifndef MCP_LMG_WAVES
+#define MCP_LMG_WAVES 3  // waves per SIMD the register allocator leaves room for: 3 is +20% on slope designs (profiles/r01_j_occupancy.txt)
+#endif
 #include <hip/hip_runtime.h>
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
@@ -569,7 +572,7 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
 // SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
 // heteroskedastic residuals) plus the LME knobs -- random-effect shape, one ICC jitter per grouping
 template <int P, int Q0, bool SCEN>
-__global__ __launch_bounds__(GW) void lmm_general_kernel(const SimParams* __restrict__ pp) {
+__global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;

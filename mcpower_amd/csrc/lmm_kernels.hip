@@ -22,6 +22,9 @@
 // random-intercept draws on the sequential stream before the row loop), :811-857 (u_re added on the
 // latent scale), engine-contract/src/generation.rs:125-158 (row -> cluster).  The optimiser replaces
 // glmm 0.1.2 fit_on + bobyqa 0.1.1 (out of tree) with Brent's method on theta in [0, 32].
+#ifndef MCP_LMM_WAVES
+#define MCP_LMM_WAVES 1  // waves per SIMD floor for the allocator: no gain from 2..4 on MI355X (profiles/r01_j_occupancy.txt)
+#endif
 #include <hip/hip_runtime.h>
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
@@ -401,7 +404,7 @@ __device__ __forceinline__ void lmm_eval_lane(const double (&M0)[(P + 1) * (P + 
 // :1423-1430), Wald z^2, joint Wald chi2, decisions.  RED: a reduced round fits the kept columns, never feeds the
 // theta carry (:1414-1428) and runs the joint Wald over the kept targets against chi2(k_red) (:1456-1468).
 template <int P, bool RED>
-__global__ __launch_bounds__(64) void lmm_optimise_kernel(const SimParams* __restrict__ pp) {
+__global__ __launch_bounds__(64, MCP_LMM_WAVES) void lmm_optimise_kernel(const SimParams* __restrict__ pp) {
   const SimParams& prm = *pp;
   const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = local < prm.n_sims;
