@@ -13,6 +13,9 @@
 // data_gen.rs:390-398, 859-911 (uniform residual slot, Bernoulli draw).  The IRLS arithmetic
 // replaces glmm 0.1.2's glm_irls_fit (out of tree): published Fisher scoring, R glm.fit's
 // convergence rule |dev - dev_old| / (|dev| + 0.1) < 1e-8, <= 25 passes, |beta| > 30 -> not converged.
+#ifndef MCP_GLM_WAVES
+#define MCP_GLM_WAVES 1  // waves per SIMD floor for the register allocator: 2..4 change C3 by < 3% (profiles/r01_j_occupancy.txt)
+#endif
 #include <hip/hip_runtime.h>
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
@@ -171,7 +174,7 @@ __device__ __forceinline__ void irls_fit(const float* design, uint32_t n_pad, ui
 // SCEN: general data path -- per-replicate correlation factor / marginals from the scenario design records and
 // per-study effects (data_gen.rs:709-751, 990-1093); the fit still starts from the spec's effects.
 template <int P, bool FACTORS, bool RED, bool SCEN, bool LOGIT>
-__global__ __launch_bounds__(WAVE) void glm_sim_kernel(const SimParams* __restrict__ pp) {
+__global__ __launch_bounds__(WAVE, MCP_GLM_WAVES) void glm_sim_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ float lds[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
