@@ -419,6 +419,33 @@ def test_find_power_clustered_glm_device_equals_oracle(engine, oracle):
     assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 1.0 / 200 + 1e-12
 
 
+def _glmm_slope_contract():
+    c = _glmm_contract()
+    c["generation"]["cluster"]["slopes"] = [{"column": 0, "variance": 0.10, "corr_with_intercept": 0.3, "corr_with": []}]
+    return c
+
+
+def test_find_power_clustered_glm_with_a_random_slope_on_the_oracle(oracle):
+    """(1 + x1 | g) under a binary outcome: the contract's slope reaches the vector-mode Laplace fit."""
+    spec = K.contract_to_simulation_spec(_glmm_slope_contract())
+    assert spec.cluster.slopes and spec.cluster_slope_design_cols == [1]
+    r = _engine.find_power(_pack(_glmm_slope_contract()), 400, 24, 2137, None, _runner=_oracle_runner(oracle))
+    sc = r["scenarios"]["optimistic"] if "scenarios" in r else r
+    assert sc["n_sims"] == 24 and sc["convergence_rate"][0] > 0.8 and 0.3 < sc["power_uncorrected"][0][0] <= 1.0
+
+
+@pytest.mark.gpu
+def test_find_power_clustered_glm_with_a_random_slope_device_equals_oracle(engine, oracle):
+    blob = _pack(_glmm_slope_contract())
+    dev = _engine.find_power(blob, 400, 96, 2137, None)
+    ora = _engine.find_power(blob, 400, 96, 2137, None, _runner=_oracle_runner(oracle))
+    d = dev["scenarios"]["optimistic"] if "scenarios" in dev else dev
+    o = ora["scenarios"]["optimistic"] if "scenarios" in ora else ora
+    for t in range(2):
+        assert abs(d["power_uncorrected"][0][t] - o["power_uncorrected"][0][t]) <= 2.0 / 96 + 1e-12
+    assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 2.0 / 96 + 1e-12
+
+
 def test_clustered_glm_opt_in_modes_are_refused_not_approximated():
     c = _glmm_contract()
     c["nagq"] = 7
