@@ -107,6 +107,35 @@ def test_glmm_slopes_dataset_is_the_reference_capture(engine, oracle):
     assert dev.pinned_components[0, 0] == f["pinned"]
 
 
+def test_glmm_slopes_fixed_size_poisson_second_column_and_test_formula(engine, oracle):
+    """FixedSize clusters (the cluster count follows the grid: 30 clusters share lanes pairwise, 40 do not), a Poisson
+    outcome, the slope on the SECOND predictor, and a test_formula that drops the first one."""
+    spec, _, a, low = load_case("glmm_slope")
+    spec.outcome_kind = S.OutcomeKind.Count
+    spec.n_non_factor = 2
+    spec.correlation = [1.0, 0.2, 0.2, 1.0]
+    spec.var_types, spec.var_params = [S.Distribution.Normal] * 2, [0.0, 0.0]
+    spec.effect_sizes = [0.6, 0.10, 0.20]
+    spec.target_indices = [2]
+    spec.cluster = S.ClusterSpec(sizing=("FixedSize", 15), tau_squared=0.10,
+                                 slopes=[{"column": 1, "variance": 0.03, "corr_with_intercept": -0.2, "corr_with": []}])
+    spec.cluster_slope_design_cols = [2]
+    spec.scenario.truth_start = True
+    dev = engine.run_batch(spec, [450, 600], 24, BASE_SEED)
+    ora = oracle.run_batch(spec, [450, 600], 24, BASE_SEED, n_threads=8)
+    assert dev.converged.mean() > 0.8
+    _compare(dev, ora, 24, slack=2)
+    spec.fit_columns = [0, 2]
+    dev = engine.run_batch(spec, [450], 24, BASE_SEED)
+    ora = oracle.run_batch(spec, [450], 24, BASE_SEED, n_threads=8)
+    _compare(dev, ora, 24, slack=2)
+    spec.fit_columns = [0, 1]
+    spec.target_indices = [1]
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, [450], 4, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "random slope" in str(e.value)
+
+
 def test_glmm_slopes_probit_scenario_and_counters(engine, oracle):
     from helpers import preset
     spec, _, a, low = load_case("glmm_slope")
