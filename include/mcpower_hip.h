@@ -88,6 +88,8 @@ typedef enum mcp_residual_dist {  /* engine_contract::ResidualDist */
 
 typedef enum mcp_outcome_kind { MCP_OUTCOME_CONTINUOUS = 0, MCP_OUTCOME_BINARY = 1, MCP_OUTCOME_COUNT = 2 } mcp_outcome_kind;
 typedef enum mcp_link_kind { MCP_LINK_CANONICAL = 0, MCP_LINK_PROBIT = 1 } mcp_link_kind;
+/* engine-contract estimator.rs:39-56: fixed-effect Wald SE of the clustered GLM; Rx is the default */
+typedef enum mcp_wald_se { MCP_WALD_SE_RX = 0, MCP_WALD_SE_HESSIAN = 1 } mcp_wald_se;
 typedef enum mcp_estimator { MCP_EST_OLS = 0, MCP_EST_GLM = 1, MCP_EST_MLE = 2 } mcp_estimator;
 typedef enum mcp_correction {     /* engine_contract::CorrectionMethod */
   MCP_CORR_NONE = 0,
@@ -201,7 +203,8 @@ typedef struct mcp_spec {
   int32_t residual_dist;                /* mcp_residual_dist */
   uint8_t residual_pinned;
   uint8_t report_overall;
-  uint8_t _pad1[2];
+  uint8_t wald_se;                      /* mcp_wald_se: clustered GLM only (spec.rs:359-362); 0 = Rx, the default */
+  uint8_t nagq;                         /* spec.rs:363-366: 0 / 1 = Laplace; AGQ (> 1) is unsupported on the device path */
   int32_t outcome_kind;                 /* mcp_outcome_kind */
   int32_t link;                         /* mcp_link_kind */
   int32_t estimator;                    /* mcp_estimator */

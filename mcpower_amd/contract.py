@@ -368,12 +368,12 @@ def contract_to_simulation_spec(c: dict) -> S.SimulationSpec:
     """`contract_to_simulation_spec` (contract_adapter.rs:74-230)."""
     validate_contract(c)
     # wald_se / nagq only steer the clustered-GLM estimator (estimator.rs:58-66).  The device fits it by the Laplace
-    # approximation with the "rx" Wald SE -- the contract's defaults; the opt-in modes are refused, not approximated.
+    # approximation with either Wald SE mode; quadrature is refused, not approximated.
+    wald_se = S.WaldSe.Rx
     if c.get("estimator") == "glm" and c["generation"].get("cluster") is not None:
         if int(c.get("nagq", 1)) != 1:
             raise S.EngineError(S.Status.Unsupported, "unsupported on the device path: adaptive Gauss-Hermite quadrature (nagq > 1) for a clustered GLM")
-        if str(c.get("wald_se", "rx")) != "rx":
-            raise S.EngineError(S.Status.Unsupported, "unsupported on the device path: Wald SE mode 'hessian' for a clustered GLM")
+        wald_se = _lookup({"rx": S.WaldSe.Rx, "hessian": S.WaldSe.Hessian}, str(c.get("wald_se", "rx")), "wald_se")
     cols = _Columns(c)
     gen = c["generation"]
     gen_terms = _terms(c["design_generation"])
@@ -560,6 +560,7 @@ def contract_to_simulation_spec(c: dict) -> S.SimulationSpec:
         outcome_kind=_lookup(_OUTCOME, c["outcome"]["kind"], "outcome kind"),
         link=None if link is None else S.LinkKind.Probit,
         estimator=_lookup(_ESTIMATOR, c["estimator"], "estimator"),
+        wald_se=wald_se,
         intercept=float(c["outcome"]["intercept"]), posthoc=posthoc,
         max_failed_fraction=float(c["max_failed_fraction"]), cluster=cluster, scenario=scenario,
         report_overall=report_overall, factor_min_level_count=0)

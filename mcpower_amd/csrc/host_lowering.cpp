@@ -707,6 +707,9 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   prm.red_active = (npc > 0 || test_reduces || any_excl_possible || wide || ols_cluster) ? 1u : 0u;
   if (glmm) {
     prm.glmm_active = 1;
+    if (spec->wald_se > MCP_WALD_SE_HESSIAN) { err = "invalid spec: wald_se out of range"; return MCP_ERR_INVALID_SPEC; }
+    if (spec->nagq > 1) return unsupported("adaptive Gauss-Hermite quadrature (nagq > 1) for a clustered GLM");
+    prm.glmm_hessian = spec->wald_se == MCP_WALD_SE_HESSIAN ? 1u : 0u;
     prm.glmm_keep = prm.keep_mask[0];  // every column, or the test_formula subset (flag combination 0: nothing excluded)
     if (!(prm.glmm_keep & 1u)) return unsupported("intercept-free test_formula fit of a clustered GLM");
     for (uint32_t d = 0; d < spec->cluster.slopes.n_slopes; ++d)

@@ -187,6 +187,7 @@ struct SimParams {
   double lmg_theta_truth[LMG_MAX_THETA];
   uint16_t* pinned;                  // [n_sims_total][n_grid] pinned-component bits (spec.rs:566-573) or null
   double* tau_hat;                   // [n_sims_total][n_grid] tau-hat^2 of a clustered-GLM fit (spec.rs:589-593) or null
+  uint32_t glmm_hessian;             // clustered GLM: Wald SE from the finite-difference Hessian (spec.wald_se)
   uint32_t glmm_active;              // Glm estimator + cluster: the random-intercept GLMM kernel
   uint32_t glmm_keep;                // fitted columns of the clustered GLM: all, or the test_formula subset
 

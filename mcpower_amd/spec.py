@@ -51,6 +51,12 @@ class LinkKind(enum.IntEnum):
     Probit = 1
 
 
+class WaldSe(enum.IntEnum):
+    """engine-contract estimator.rs:39-56: fixed-effect Wald SE of the clustered GLM."""
+    Rx = 0
+    Hessian = 1
+
+
 class EstimatorSpec(enum.IntEnum):
     Ols = 0
     Glm = 1
@@ -224,7 +230,8 @@ class CSpec(C.Structure):
         ("residual_dist", C.c_int32),
         ("residual_pinned", C.c_uint8),
         ("report_overall", C.c_uint8),
-        ("_pad1", C.c_uint8 * 2),
+        ("wald_se", C.c_uint8),
+        ("nagq", C.c_uint8),
         ("outcome_kind", C.c_int32),
         ("link", C.c_int32),
         ("estimator", C.c_int32),
@@ -371,6 +378,8 @@ class SimulationSpec:  # spec.rs:251-417
     scenario: ScenarioPerturbations = field(default_factory=ScenarioPerturbations.optimistic)
     report_overall: bool = False
     factor_min_level_count: int = 0
+    wald_se: WaldSe = WaldSe.Rx  # spec.rs:359-362: clustered GLM only
+    nagq: int = 1                # spec.rs:363-366: 1 = Laplace
 
     @property
     def n_predictors(self) -> int:
@@ -440,6 +449,8 @@ class LoweredSpec:
         c.residual_dist = int(s.residual_dist)
         c.residual_pinned = 1 if s.residual_pinned else 0
         c.report_overall = 1 if s.report_overall else 0
+        c.wald_se = int(s.wald_se)
+        c.nagq = int(s.nagq)
         c.outcome_kind = int(s.outcome_kind)
         c.link = int(LinkKind.Canonical if s.link is None else s.link)
         c.estimator = int(s.estimator)

@@ -18,6 +18,14 @@
  * Wald SE mode "rx": Var(beta-hat) = (RX'RX)^-1 with RX'RX = X'WX - sum_c theta^2 (X_c'w_c)(X_c'w_c)' /
  * (theta^2 sum w_c + 1) at the optimum (lme4: vcov(., use.hessian = FALSE)).
  *
+ * Wald SE mode "hessian" (estimator.rs:39-56, lme4 `use.hessian = TRUE`): Var(beta-hat) = the beta block of 2 H^-1, H the
+ * central finite-difference Hessian of d over (theta, beta) at the optimum with lme4's `deriv12` stencil (delta = 1e-4;
+ * a step past a bound lands on the bound); a singular fit (a pinned component), or a block that does not factor,
+ * keeps the "rx" covariance, as `vcov.merMod` falls back when its Hessian is not positive definite -- glmer's z on the
+ * singular glmm_slope golden IS the "rx" z (3e-4).  On the interior goldens (glmm_intercept, glmm_multislope) this z
+ * is within 0.9 % of glmer's ("rx": 1.4-4.7 %); it is stable in delta (1e-4 .. 1e-2: 6 digits), glmer's own stencil
+ * differences a deviance carrying its 1e-7 PIRLS tolerance, so the residual gap is glmer's noise.
+ *
  * PARITY STATUS: beta-hat and tau-hat^2 pinned to lme4 1.1.38 glmer (Laplace) on the reference's bytes
  * (validation/data/glmm_intercept.golden.rds; GLMM_TOL of tolerances.R:186-200: 1e-4 rel / 1e-3 abs on beta).
  * The golden z is glmer's Hessian-based z, a different SE convention from the engine's "rx" default, so it
@@ -173,8 +181,91 @@ static double glmm_nelder_mead(glmm_model* m, double* x0, double step, double ft
   return fv[lo];
 }
 
+/* Wald SE mode "hessian": lower Cholesky factor (p x p, row-major) of the beta precision S / 2,
+ * S = H_bb - H_bt H_tt^-1 H_tb, from lme4's deriv12 stencil on fn over the free parameters (theta_free marks the
+ * nth leading entries; beta always free).  fn may clamp its argument.  Returns 0 and fills l_out on success,
+ * -1 when a block does not factor (the caller keeps "rx"). */
+#ifndef HESS_DELTA
+#define HESS_DELTA 1e-4  /* lme4 deriv12 default */
+#endif
+int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t nth, uint32_t p, const uint8_t* theta_free,
+                           double fx, double* l_out) {
+  enum { MAXD = MCPO_MAX_P + 6 };
+  uint32_t idx[MAXD], m = 0, mt = 0;
+  const uint32_t d = nth + p;
+  for (uint32_t k = 0; k < nth; ++k) if (theta_free[k]) idx[m++] = k;
+  mt = m;
+  for (uint32_t k = nth; k < d; ++k) idx[m++] = k;
+  double H[MAXD][MAXD], pt[MAXD];
+  const double dl = HESS_DELTA;
+  for (uint32_t a = 0; a < m; ++a) {
+    memcpy(pt, par, sizeof(double) * d); pt[idx[a]] = par[idx[a]] + dl;
+    const double fadd = fn(ctx, pt);
+    memcpy(pt, par, sizeof(double) * d); pt[idx[a]] = par[idx[a]] - dl;
+    const double fsub = fn(ctx, pt);
+    H[a][a] = fadd / (dl * dl) - 2.0 * fx / (dl * dl) + fsub / (dl * dl);
+    for (uint32_t b = 0; b < a; ++b) {
+      double fq[4];
+      for (int q = 0; q < 4; ++q) {
+        memcpy(pt, par, sizeof(double) * d);
+        pt[idx[b]] = par[idx[b]] + ((q & 2) ? -dl : dl);
+        pt[idx[a]] = par[idx[a]] + ((q & 1) ? -dl : dl);
+        fq[q] = fn(ctx, pt);
+      }
+      H[a][b] = H[b][a] = (fq[0] - fq[1] - fq[2] + fq[3]) / (4.0 * dl * dl);
+    }
+  }
+  for (uint32_t a = 0; a < m; ++a) for (uint32_t b = 0; b < m; ++b) if (!isfinite(H[a][b])) return -1;
+  /* Cholesky of H_tt, then the Schur complement onto beta */
+  double Lt[6][6], Y[6][MCPO_MAX_P];
+  for (uint32_t j = 0; j < mt; ++j) {
+    double dj = H[j][j];
+    for (uint32_t k = 0; k < j; ++k) dj -= Lt[j][k] * Lt[j][k];
+    if (!(dj > 0.0)) return -1;
+    Lt[j][j] = sqrt(dj);
+    for (uint32_t i = j + 1; i < mt; ++i) {
+      double v = H[i][j];
+      for (uint32_t k = 0; k < j; ++k) v -= Lt[i][k] * Lt[j][k];
+      Lt[i][j] = v / Lt[j][j];
+    }
+  }
+  for (uint32_t r = 0; r < p; ++r)       /* Y = Lt^-1 H_tb */
+    for (uint32_t i = 0; i < mt; ++i) {
+      double v = H[i][mt + r];
+      for (uint32_t k = 0; k < i; ++k) v -= Lt[i][k] * Y[k][r];
+      Y[i][r] = v / Lt[i][i];
+    }
+  double S[MCPO_MAX_P][MCPO_MAX_P];
+  for (uint32_t r = 0; r < p; ++r)
+    for (uint32_t c = 0; c <= r; ++c) {
+      double v = H[mt + r][mt + c];
+      for (uint32_t k = 0; k < mt; ++k) v -= Y[k][r] * Y[k][c];
+      S[r][c] = 0.5 * v;
+    }
+  double L[MCPO_MAX_P * MCPO_MAX_P];
+  memset(L, 0, sizeof L);
+  for (uint32_t j = 0; j < p; ++j) {
+    double dj = S[j][j];
+    for (uint32_t k = 0; k < j; ++k) dj -= L[j * p + k] * L[j * p + k];
+    if (!(dj > 0.0) || !isfinite(dj)) return -1;
+    L[j * p + j] = sqrt(dj);
+    for (uint32_t i = j + 1; i < p; ++i) {
+      double v = S[i][j];
+      for (uint32_t k = 0; k < j; ++k) v -= L[i * p + k] * L[j * p + k];
+      L[i * p + j] = v / L[j * p + j];
+    }
+  }
+  memcpy(l_out, L, sizeof(double) * p * p);
+  return 0;
+}
+
+static double glmm_dev_cb(void* ctx, double* par) {
+  uint32_t scratch = 0;
+  return glmm_f((glmm_model*)ctx, par, &scratch);
+}
+
 /* fit from the start (theta0, beta0); fills f (beta, lower Cholesky factor of RX'RX, sigma_sq = 1) */
-static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, mcpo_gen_fit* f) {
+static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, uint32_t mode, mcpo_gen_fit* f) {
   const uint32_t p = m->p, d = p + 1;
   double par[GLMM_MAX_DIM];
   par[0] = theta0;
@@ -231,6 +322,11 @@ static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, mcp
       f->L[i * p + j] = v / f->L[j * p + j];
     }
   }
+  if (ok && (mode & MCPO_MODE_HESSIAN) && par[0] >= GLMM_THETA_ZERO) { /* a singular fit, or a block that does not factor, keeps "rx" */
+    const uint8_t th_free = 1;
+    double lh[MCPO_MAX_P * MCPO_MAX_P];
+    if (mcpo_fd_hessian_factor(glmm_dev_cb, m, par, 1, p, &th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
+  }
   f->converged = ok;
   f->pinned = (ok && par[0] < GLMM_THETA_ZERO) ? 1u : 0u;
   f->at_upper = par[0] > GLMM_THETA_MAX - 1e-3;
@@ -241,12 +337,12 @@ static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, mcp
 }
 
 int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld, uint32_t p,
-                      uint32_t ncl, double theta0, const double* beta0, mcpo_gen_fit* f) {
+                      uint32_t ncl, double theta0, const double* beta0, uint32_t mode, mcpo_gen_fit* f) {
   if (p > MCPO_MAX_P) return MCP_ERR_UNSUPPORTED;
   glmm_model m;
   int rc = glmm_build(&m, fam, x, y, ids, n, ld, p, ncl);
   if (rc) return rc;
-  rc = glmm_fit_model(&m, theta0, beta0, f);
+  rc = glmm_fit_model(&m, theta0, beta0, mode, f);
   glmm_free(&m);
   return rc;
 }
@@ -255,10 +351,10 @@ int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* i
 int mcpo_glmm_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
                   uint32_t p, uint32_t n_clusters, double theta_start, const double* beta_start, double* beta, double* se,
                   double* z_sq, double* theta_hat, double* tau_sq, uint8_t* converged, uint8_t* boundary_hit,
-                  uint32_t* n_eval) {
+                  uint32_t* n_eval, uint32_t mode) {
   mcpo_gen_fit f;
   int rc = mcpo_glmm_fit_ids(family, x, y, cluster_ids, n, ld, p, n_clusters, theta_start > 0.0 ? theta_start : 1.0,
-                             beta_start, &f);
+                             beta_start, mode, &f);
   if (rc) return rc;
   *converged = (uint8_t)f.converged; *boundary_hit = f.boundary_hit; *theta_hat = f.theta[0];
   *tau_sq = f.theta[0] * f.theta[0]; *n_eval = f.n_eval;
@@ -342,6 +438,7 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
   if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS || spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;
   if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
   const int fam = spec->outcome_kind == MCP_OUTCOME_COUNT ? 2 : (spec->link == MCP_LINK_PROBIT ? 1 : 0);
+  const uint32_t mode = spec->wald_se == MCP_WALD_SE_HESSIAN ? MCPO_MODE_HESSIAN : 0u;
   const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
   const uint32_t nt = spec->n_target_indices;
   const uint32_t cv = cl->sizing_value ? cl->sizing_value : 1;
@@ -382,13 +479,13 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
     if ((has_prev || spec->scenario.truth_start) && th0 < 0.01) th0 = 0.01;
     mcpo_gen_fit f;
     if (q == 1) {
-      rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, &f);
+      rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, mode, &f);
     } else {
       double tv[12];
       const double* start = NULL;
       if (has_prev) start = carry_v;
       else if (spec->scenario.truth_start) { mcpo_truth_theta(cl, 1, tv); start = tv; }
-      rc = mcpo_glmm_slopes_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, q, slope_cols, start, beta0, &f);
+      rc = mcpo_glmm_slopes_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, q, slope_cols, start, beta0, mode, &f);
     }
     if (rc) break;
     if (f.converged) { carry = f.theta[0]; memcpy(carry_v, f.theta, sizeof(double) * nth); has_prev = 1; }

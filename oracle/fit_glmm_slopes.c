@@ -211,10 +211,18 @@ static double gs_nelder_mead(gs_model* m, const uint8_t* is_diag, double* x0, do
   return fv[lo];
 }
 
-/* theta0: nth start values (floored at 0.01 when given) or NULL for the blind start; beta0: p start values */
+typedef struct gs_cb { gs_model* m; const uint8_t* is_diag; } gs_cb;
+static double gs_dev_cb(void* ctx, double* par) {
+  uint32_t scratch = 0;
+  gs_cb* c = (gs_cb*)ctx;
+  return gs_f(c->m, c->is_diag, par, &scratch);
+}
+
+/* theta0: nth start values (floored at 0.01 when given) or NULL for the blind start; beta0: p start values;
+ * mode: MCPO_MODE_HESSIAN selects the finite-difference Hessian Wald covariance (fit_glmm.c) */
 int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld,
                              uint32_t p, uint32_t ncl, uint32_t q, const uint32_t* slope_cols, const double* theta0,
-                             const double* beta0, mcpo_gen_fit* f) {
+                             const double* beta0, uint32_t mode, mcpo_gen_fit* f) {
   if (p > MCPO_MAX_P || q < 1 || q > GS_MAX_Q) return MCP_ERR_UNSUPPORTED;
   gs_model m;
   memset(&m, 0, sizeof m);
@@ -318,6 +326,15 @@ int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint
       f->L[i * p + j] = v / f->L[j * p + j];
     }
   }
+  int singular = 0;
+  for (uint32_t k = 0; k < m.nth; ++k) if (is_diag[k] && par[k] < GS_THETA_ZERO) singular = 1;
+  if (ok && (mode & MCPO_MODE_HESSIAN) && !singular) { /* a singular fit, or a block that does not factor, keeps "rx" */
+    uint8_t th_free[6];
+    for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = 1;
+    gs_cb cb = {&m, is_diag};
+    double lh[MCPO_MAX_P * MCPO_MAX_P];
+    if (mcpo_fd_hessian_factor(gs_dev_cb, &cb, par, m.nth, p, th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
+  }
   f->converged = ok;
   uint32_t comp = 0;
   for (uint32_t k = 0; k < m.nth; ++k) {
@@ -337,9 +354,9 @@ int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint
 int mcpo_glmm_slopes_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
                          uint32_t p, uint32_t n_clusters, uint32_t q, const uint32_t* slope_cols, const double* theta_start,
                          const double* beta_start, double* beta, double* se, double* theta_hat, double* vars_out,
-                         uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval) {
+                         uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval, uint32_t mode) {
   mcpo_gen_fit f;
-  int rc = mcpo_glmm_slopes_fit_ids(family, x, y, cluster_ids, n, ld, p, n_clusters, q, slope_cols, theta_start, beta_start, &f);
+  int rc = mcpo_glmm_slopes_fit_ids(family, x, y, cluster_ids, n, ld, p, n_clusters, q, slope_cols, theta_start, beta_start, mode, &f);
   if (rc) return rc;
   *converged = (uint8_t)f.converged; *boundary_hit = f.boundary_hit; *pinned = f.pinned; *n_eval = f.n_eval;
   memcpy(theta_hat, f.theta, sizeof(double) * f.n_theta);

@@ -102,13 +102,13 @@ int mcpo_lmm_general_fit(const float* x, const float* y, uint32_t n, uint32_t ld
 int mcpo_glmm_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
                   uint32_t p, uint32_t n_clusters, double theta_start, const double* beta_start, double* beta, double* se,
                   double* z_sq, double* theta_hat, double* tau_sq, uint8_t* converged, uint8_t* boundary_hit,
-                  uint32_t* n_eval);
+                  uint32_t* n_eval, uint32_t mode /* bit 0: Wald SE mode "hessian" */);
 
 /* ---- GLMM with random slopes on the primary grouping (fit_glmm_slopes.c): q = 1 + slopes <= 3 ---- */
 int mcpo_glmm_slopes_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
                          uint32_t p, uint32_t n_clusters, uint32_t q, const uint32_t* slope_cols, const double* theta_start,
                          const double* beta_start, double* beta, double* se, double* theta_hat, double* vars_out,
-                         uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval);
+                         uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval, uint32_t mode);
 
 /* ---- OLS fit on provided bytes (glmm fit_suff_stats_t_sq, inferred from
  *      batch.rs:958-1142, posthoc.rs:62-99, introspect.rs:280-284) ----------- */

@@ -285,8 +285,8 @@ def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, s
 
 
 def glmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, family: str = "logit", theta_start: float = 0.0,
-             beta_start=None):
-    """Random-intercept GLMM (Laplace, Wald SE mode "rx") on provided bytes."""
+             beta_start=None, wald_se: str = "rx"):
+    """Random-intercept GLMM (Laplace; Wald SE mode "rx" or "hessian") on provided bytes."""
     n, p = design.shape
     x = np.ascontiguousarray(design.T, dtype=np.float32)
     y = np.ascontiguousarray(outcome, dtype=np.float32)
@@ -301,15 +301,16 @@ def glmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, f
                              y.ctypes.data_as(C.POINTER(C.c_float)), ids.ctypes.data_as(C.POINTER(C.c_uint32)),
                              C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), C.c_uint32(ncl), C.c_double(theta_start),
                              None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd), se.ctypes.data_as(pd),
-                             zsq.ctypes.data_as(pd), C.byref(th), C.byref(t2), C.byref(conv), C.byref(bh), C.byref(ne))
+                             zsq.ctypes.data_as(pd), C.byref(th), C.byref(t2), C.byref(conv), C.byref(bh), C.byref(ne),
+                             C.c_uint32(1 if wald_se == "hessian" else 0))
     _check(rc)
     return dict(beta=beta, se=se, z_sq=zsq, theta=th.value, tau_sq=t2.value, converged=bool(conv.value),
                 boundary_hit=bh.value, n_eval=ne.value)
 
 
 def glmm_slopes_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, slope_cols, family: str = "logit",
-                    theta_start=None, beta_start=None):
-    """GLMM with random slopes on the primary grouping (Laplace, "rx" SE) on provided bytes."""
+                    theta_start=None, beta_start=None, wald_se: str = "rx"):
+    """GLMM with random slopes on the primary grouping (Laplace; Wald SE mode "rx" or "hessian") on provided bytes."""
     n, p = design.shape
     x = np.ascontiguousarray(design.T, dtype=np.float32)
     y = np.ascontiguousarray(outcome, dtype=np.float32)
@@ -328,7 +329,8 @@ def glmm_slopes_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.nda
                                     cols.ctypes.data_as(C.POINTER(C.c_uint32)), None if t0 is None else t0.ctypes.data_as(pd),
                                     None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
                                     se.ctypes.data_as(pd), theta.ctypes.data_as(pd), vars_out.ctypes.data_as(pd),
-                                    C.byref(conv), C.byref(bh), C.byref(pinned), C.byref(ne))
+                                    C.byref(conv), C.byref(bh), C.byref(pinned), C.byref(ne),
+                                    C.c_uint32(1 if wald_se == "hessian" else 0))
     _check(rc)
     return dict(beta=beta, se=se, theta=theta[:q * (q + 1) // 2], cov=vars_out[:q, :q], converged=bool(conv.value),
                 boundary_hit=bh.value, pinned=pinned.value, n_eval=ne.value)

@@ -62,11 +62,16 @@ int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint3
 /* GLM family kernel shared by fit_glm.c and fit_glmm.c: IRLS weight, working response, deviance contribution */
 void mcpo_fam_eval(int fam, double eta, double yi, double* w_out, double* z_out, double* dev_out);
 int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld, uint32_t p,
-                      uint32_t ncl, double theta0, const double* beta0, mcpo_gen_fit* f);
+                      uint32_t ncl, double theta0, const double* beta0, uint32_t mode, mcpo_gen_fit* f);
+/* mode bits of the GLMM fits: Wald SE from the finite-difference Hessian instead of "rx" */
+#define MCPO_MODE_HESSIAN 1u
+typedef double (*mcpo_dev_fn)(void* ctx, double* par);
+int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t nth, uint32_t p, const uint8_t* theta_free,
+                           double fx, double* l_out);
 
 int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld,
                              uint32_t p, uint32_t ncl, uint32_t q, const uint32_t* slope_cols, const double* theta0,
-                             const double* beta0, mcpo_gen_fit* f);
+                             const double* beta0, uint32_t mode, mcpo_gen_fit* f);
 
 /* OLS sufficient statistics + fit (fit_ols.c) */
 typedef struct mcpo_olsfit_t {

@@ -453,10 +453,12 @@ def test_clustered_glm_opt_in_modes_are_refused_not_approximated():
         K.contract_to_simulation_spec(c)
     assert e.value.status == S.Status.Unsupported and "nagq" in str(e.value)
     c = _glmm_contract()
-    c["wald_se"] = "hessian"
-    with pytest.raises(S.EngineError) as e:
+    c["wald_se"] = "hessian"   # the rigor opt-in lowers to spec.wald_se (contract_adapter.rs:227)
+    assert K.contract_to_simulation_spec(c).wald_se == S.WaldSe.Hessian
+    assert K.contract_to_simulation_spec(_glmm_contract()).wald_se == S.WaldSe.Rx
+    c["wald_se"] = "sandwich"
+    with pytest.raises(K.ContractError):
         K.contract_to_simulation_spec(c)
-    assert e.value.status == S.Status.Unsupported and "hessian" in str(e.value)
     c = _glmm_contract()
     c["nagq"] = 4
     with pytest.raises(K.ContractError) as e:

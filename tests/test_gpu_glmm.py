@@ -136,6 +136,32 @@ def test_glmm_slopes_fixed_size_poisson_second_column_and_test_formula(engine, o
     assert e.value.status == S.Status.Unsupported and "random slope" in str(e.value)
 
 
+# ---- Wald SE mode "hessian": finite-difference Hessian of the Laplace deviance (mcp_glmm_hessian.hpp) ----
+
+@pytest.mark.parametrize("name", ["glmm_intercept", "glmm_slope", "glmm_multislope"])
+def test_glmm_hessian_wald_se_matches_oracle(name, engine, oracle):
+    """Same stencil on both sides; the second differences amplify the last-bit differences of the two family kernels
+    (delta^-2 = 1e8), so the statistics agree to ~1e-4 instead of 1e-6.  Singular fits keep the "rx" covariance."""
+    spec, _, a, low = load_case(name)
+    spec.scenario.truth_start = True
+    n_sims = 32 if name != "glmm_multislope" else 12
+    rx, stat_rx = engine.run_batch_st_capture(spec, [low["n"]], n_sims, BASE_SEED)
+    spec.wald_se = S.WaldSe.Hessian
+    dev, stat = engine.run_batch_st_capture(spec, [low["n"]], n_sims, BASE_SEED)
+    ora = oracle.run_batch(spec, [low["n"]], n_sims, BASE_SEED, n_threads=8, stat_capture=True)
+    same = ((dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+            & (dev.joint_unc == ora.joint_unc).all(axis=1) & (dev.pinned_components == ora.pinned_components).all(axis=1))
+    assert same.sum() >= n_sims - 2
+    ok = same & (dev.converged[:, 0] == 1)
+    assert np.allclose(stat[ok], ora.stat_capture[ok], rtol=2e-3)
+    # the mode moves the statistic only: estimates, convergence and pinned masks are the "rx" run's
+    assert np.array_equal(dev.converged, rx.converged) and np.array_equal(dev.pinned_components, rx.pinned_components)
+    interior = ok & (dev.pinned_components[:, 0] == 0)
+    assert np.all(stat[interior] < stat_rx[interior])            # Hessian SEs are the larger ones
+    singular = ok & (dev.pinned_components[:, 0] != 0)
+    assert np.array_equal(stat[singular], stat_rx[singular])     # vcov.merMod's fallback
+
+
 def test_glmm_slopes_probit_scenario_and_counters(engine, oracle):
     from helpers import preset
     spec, _, a, low = load_case("glmm_slope")

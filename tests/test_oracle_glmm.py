@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import BASE_SEED, load_case
+from mcpower_amd import spec as S
 
 
 def test_glmm_dataset_is_reproduced_bit_exact(oracle):
@@ -126,3 +127,48 @@ def test_glmm_arm_with_slopes_run_batch(oracle):
             assert bool(z_sq > crit[0, 0]) == bool(r.uncorrected[sim, 0, 0])
             assert abs(f["theta"][0] ** 2 - r.tau_squared_hat[sim, 0]) < 1e-9
             assert f["pinned"] == r.pinned_components[sim, 0]
+
+
+# ---- Wald SE mode "hessian" (estimator.rs:39-56; lme4 use.hessian = TRUE) ----
+
+@pytest.mark.parametrize("name", ["glmm_intercept", "glmm_multislope"])
+def test_hessian_wald_se_tracks_glmers_reported_z(name, oracle):
+    """glmer reports Hessian-based z: the "hessian" mode lands within 1 % of it on the interior goldens (the "rx" mode is
+    1.4-4.7 % away); the rest is the noise of glmer's own finite differences (its deviance carries a 1e-7 PIRLS
+    tolerance, this one 1e-13 -- the oracle's z does not move in the sixth digit between delta = 1e-4 and 1e-2)."""
+    spec, _, a, low = load_case(name)
+    fit = (lambda **kw: oracle.glmm_fit(a["design"], a["outcome"], a["cluster_ids"], family="logit", **kw)) \
+        if name == "glmm_intercept" else \
+        (lambda **kw: oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], SLOPE_CASES[name], family="logit", **kw))
+    rx, he = fit(wald_se="rx"), fit(wald_se="hessian")
+    assert np.array_equal(rx["beta"], he["beta"])
+    z_rx, z_he = rx["beta"] / rx["se"], he["beta"] / he["se"]
+    assert np.all(np.abs(z_he / a["golden_z"] - 1.0) < 0.01)
+    assert np.all(np.abs(z_he / a["golden_z"] - 1.0) < np.abs(z_rx / a["golden_z"] - 1.0))
+    assert np.all(he["se"] > rx["se"])   # "rx" ignores the beta-theta coupling: anticonservative (estimator.rs:51-54)
+
+
+def test_hessian_mode_keeps_rx_on_a_singular_fit_like_glmer(oracle):
+    """glmm_slope is singular (rho-hat = -1): vcov.merMod falls back to the RX covariance, and glmer's reported z is the
+    "rx" z to 3e-4; the "hessian" mode keeps "rx" there."""
+    spec, _, a, low = load_case("glmm_slope")
+    rx = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], [1], family="logit", wald_se="rx")
+    he = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], [1], family="logit", wald_se="hessian")
+    assert rx["pinned"] == 2 and np.array_equal(rx["se"], he["se"])
+    assert np.all(np.abs(rx["beta"] / rx["se"] / a["golden_z"] - 1.0) < 1e-3)
+
+
+def test_hessian_mode_through_run_batch(oracle):
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.scenario.truth_start = True
+    rx = oracle.run_batch(spec, [600], 16, BASE_SEED, n_threads=8, stat_capture=True)
+    spec.wald_se = S.WaldSe.Hessian
+    he = oracle.run_batch(spec, [600], 16, BASE_SEED, n_threads=8, stat_capture=True)
+    assert np.array_equal(rx.converged, he.converged) and np.allclose(rx.tau_squared_hat, he.tau_squared_hat, equal_nan=True)
+    ok = rx.converged[:, 0] == 1
+    ratio = he.stat_capture[ok, 0] / rx.stat_capture[ok, 0]
+    assert np.all(ratio < 1.0) and np.all(ratio > 0.9)   # larger SE, by a few percent
+    x, y, ids, _ = oracle.generate_sim_data_ids(spec, BASE_SEED, 0, 600)
+    f = oracle.glmm_fit(x, y, ids, family="logit", theta_start=spec.cluster.tau_squared ** 0.5, beta_start=spec.effect_sizes,
+                        wald_se="hessian")
+    assert np.isclose(f["z_sq"][1], he.stat_capture[0, 0], rtol=1e-12)
