@@ -204,7 +204,7 @@ typedef struct mcp_spec {
   uint8_t residual_pinned;
   uint8_t report_overall;
   uint8_t wald_se;                      /* mcp_wald_se: clustered GLM only (spec.rs:359-362); 0 = Rx, the default */
-  uint8_t nagq;                         /* spec.rs:363-366: 0 / 1 = Laplace; AGQ (> 1) is unsupported on the device path */
+  uint8_t nagq;                         /* spec.rs:363-366: 0 / 1 = Laplace; odd k <= 25 = adaptive Gauss-Hermite (random intercept only) */
   int32_t outcome_kind;                 /* mcp_outcome_kind */
   int32_t link;                         /* mcp_link_kind */
   int32_t estimator;                    /* mcp_estimator */

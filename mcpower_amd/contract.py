@@ -371,8 +371,8 @@ def contract_to_simulation_spec(c: dict) -> S.SimulationSpec:
     # approximation with either Wald SE mode; quadrature is refused, not approximated.
     wald_se = S.WaldSe.Rx
     if c.get("estimator") == "glm" and c["generation"].get("cluster") is not None:
-        if int(c.get("nagq", 1)) != 1:
-            raise S.EngineError(S.Status.Unsupported, "unsupported on the device path: adaptive Gauss-Hermite quadrature (nagq > 1) for a clustered GLM")
+        if int(c.get("nagq", 1)) != 1 and (c["generation"]["cluster"].get("slopes") or []):
+            raise S.EngineError(S.Status.Unsupported, "unsupported on the device path: adaptive Gauss-Hermite quadrature (nagq > 1) with random slopes (random intercept only)")
         wald_se = _lookup({"rx": S.WaldSe.Rx, "hessian": S.WaldSe.Hessian}, str(c.get("wald_se", "rx")), "wald_se")
     cols = _Columns(c)
     gen = c["generation"]
@@ -561,6 +561,7 @@ def contract_to_simulation_spec(c: dict) -> S.SimulationSpec:
         link=None if link is None else S.LinkKind.Probit,
         estimator=_lookup(_ESTIMATOR, c["estimator"], "estimator"),
         wald_se=wald_se,
+        nagq=int(c.get("nagq", 1)) if (c.get("estimator") == "glm" and c["generation"].get("cluster") is not None) else 1,
         intercept=float(c["outcome"]["intercept"]), posthoc=posthoc,
         max_failed_fraction=float(c["max_failed_fraction"]), cluster=cluster, scenario=scenario,
         report_overall=report_overall, factor_min_level_count=0)

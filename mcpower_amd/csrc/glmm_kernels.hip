@@ -116,7 +116,31 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         if (un == u) break;
         u = un;
       }
-      if (sub == 0u) m.tcl[c] = dev + u * u + log(theta * theta * sw + 1.0);
+      double term = dev + u * u + log(theta * theta * sw + 1.0);
+      if (prm.glmm_nagq > 1u) {
+        // adaptive Gauss-Hermite (lme4 glmerAGQ): the k-point rule centred at the mode, scaled by the conditional sd,
+        // as a ratio to its Laplace term; every lane of the group sweeps its rows once per off-centre node
+        const double sd = 1.0 / __builtin_sqrt(theta * theta * sw + 1.0), d0 = dev + u * u;
+        double mult = 0.0;
+        for (uint32_t j = 0; j < prm.glmm_nagq; ++j) {
+          const double zj = prm.glmm_gz[j], wj = prm.glmm_gw[j];
+          if (2u * j + 1u == prm.glmm_nagq) {
+            mult += wj;
+            continue;
+          }
+          const double v = u + sd * zj;
+          double ds = 0.0;
+          for (uint32_t i = first + sub * step; i < last; i += step << ls) {
+            double w, wz, d;
+            fam_eval(fam, m.eta0[i] + theta * v, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, d);
+            ds += d;
+          }
+          for (uint32_t o = 1u; o < (1u << ls); o <<= 1) ds += __shfl_xor(ds, (int)o);
+          mult += wj * exp(-0.5 * (ds + v * v - d0) + 0.5 * zj * zj);
+        }
+        term -= 2.0 * log(mult);
+      }
+      if (sub == 0u) m.tcl[c] = term;
     } else if (sub == 0u) {
       m.tcl[c] = 0.0;
     }

@@ -18,6 +18,43 @@
 
 namespace mcp {
 
+// k-point Gauss-Hermite rule for the weight exp(-z^2 / 2) / sqrt(2 pi): Newton on the orthonormal Hermite three-term
+// recurrence from the classical asymptotic starting guesses, scaled from the e^{-x^2} rule (z = sqrt(2) x,
+// w / sqrt(pi)); nodes descending, the centre node of an odd rule exactly 0 (lme4 GHrule convention, sum w = 1)
+static void gauss_hermite_normal(uint32_t k, double* z, double* w) {
+  const double pim4 = 0.7511255444649425;
+  const uint32_t half = (k + 1) / 2;
+  double x = 0.0, dp = 1.0;
+  for (uint32_t i = 0; i < half; ++i) {
+    if (i == 0) x = std::sqrt(2.0 * k + 1.0) - 1.85575 * std::pow(2.0 * k + 1.0, -0.16667);
+    else if (i == 1) x -= 1.14 * std::pow((double)k, 0.426) / x;
+    else if (i == 2) x = 1.86 * x - 0.86 * z[0];
+    else if (i == 3) x = 1.91 * x - 0.91 * z[1];
+    else x = 2.0 * x - z[i - 2];
+    for (int it = 0; it < 100; ++it) {
+      double h1 = pim4, h2 = 0.0;
+      for (uint32_t j = 0; j < k; ++j) {
+        const double h3 = h2;
+        h2 = h1;
+        h1 = x * std::sqrt(2.0 / (j + 1.0)) * h2 - std::sqrt((double)j / (j + 1.0)) * h3;
+      }
+      dp = std::sqrt(2.0 * k) * h2;
+      const double prev = x;
+      x = prev - h1 / dp;
+      if (std::fabs(x - prev) <= 1e-15 * (1.0 + std::fabs(x))) break;
+    }
+    z[i] = x;
+    z[k - 1 - i] = -x;
+    w[i] = w[k - 1 - i] = 2.0 / (dp * dp);
+  }
+  for (uint32_t i = 0; i < k; ++i) {
+    z[i] *= 1.4142135623730951;
+    w[i] /= 1.7724538509055159;
+  }
+  if (k & 1u) z[k / 2] = 0.0;
+}
+
+
 static bool scenario_is_optimistic(const mcp_scenario& s) {  // spec.rs:229-236
   return s.heterogeneity == 0.0 && s.heteroskedasticity_ratio == 1.0 && s.correlation_noise_sd == 0.0 &&
          s.distribution_change_prob == 0.0 && s.residual_change_prob == 0.0 && !s.has_lme;
@@ -708,7 +745,11 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (glmm) {
     prm.glmm_active = 1;
     if (spec->wald_se > MCP_WALD_SE_HESSIAN) { err = "invalid spec: wald_se out of range"; return MCP_ERR_INVALID_SPEC; }
-    if (spec->nagq > 1) return unsupported("adaptive Gauss-Hermite quadrature (nagq > 1) for a clustered GLM");
+    // validate.rs:918-945: odd, <= 25; quadrature here integrates a scalar random intercept
+    if (spec->nagq > 25 || (spec->nagq > 1 && !(spec->nagq & 1u))) { err = "invalid spec: nagq must be odd and in 1..=25"; return MCP_ERR_INVALID_SPEC; }
+    if (spec->nagq > 1 && lmm_general) return unsupported("adaptive Gauss-Hermite quadrature (nagq > 1) with random slopes (random intercept only)");
+    prm.glmm_nagq = spec->nagq > 1 ? spec->nagq : 1u;
+    if (prm.glmm_nagq > 1) gauss_hermite_normal(prm.glmm_nagq, prm.glmm_gz, prm.glmm_gw);
     prm.glmm_hessian = spec->wald_se == MCP_WALD_SE_HESSIAN ? 1u : 0u;
     prm.glmm_keep = prm.keep_mask[0];  // every column, or the test_formula subset (flag combination 0: nothing excluded)
     if (!(prm.glmm_keep & 1u)) return unsupported("intercept-free test_formula fit of a clustered GLM");

@@ -187,6 +187,8 @@ struct SimParams {
   double lmg_theta_truth[LMG_MAX_THETA];
   uint16_t* pinned;                  // [n_sims_total][n_grid] pinned-component bits (spec.rs:566-573) or null
   double* tau_hat;                   // [n_sims_total][n_grid] tau-hat^2 of a clustered-GLM fit (spec.rs:589-593) or null
+  uint32_t glmm_nagq;                // clustered GLM, random intercept: 1 = Laplace, odd k <= 25 = adaptive Gauss-Hermite (spec.nagq)
+  double glmm_gz[25], glmm_gw[25];   // the k-point rule for the standard normal weight (nodes descending, sum w = 1)
   uint32_t glmm_hessian;             // clustered GLM: Wald SE from the finite-difference Hessian (spec.wald_se)
   uint32_t glmm_active;              // Glm estimator + cluster: the random-intercept GLMM kernel
   uint32_t glmm_keep;                // fitted columns of the clustered GLM: all, or the test_formula subset

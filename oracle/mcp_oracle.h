@@ -102,7 +102,8 @@ int mcpo_lmm_general_fit(const float* x, const float* y, uint32_t n, uint32_t ld
 int mcpo_glmm_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
                   uint32_t p, uint32_t n_clusters, double theta_start, const double* beta_start, double* beta, double* se,
                   double* z_sq, double* theta_hat, double* tau_sq, uint8_t* converged, uint8_t* boundary_hit,
-                  uint32_t* n_eval, uint32_t mode /* bit 0: Wald SE mode "hessian" */);
+                  uint32_t* n_eval, uint32_t mode /* bit 0: Wald SE mode "hessian"; bits 8..15: nagq */);
+void mcpo_gh_rule(uint32_t k, double* z, double* w);
 
 /* ---- GLMM with random slopes on the primary grouping (fit_glmm_slopes.c): q = 1 + slopes <= 3 ---- */
 int mcpo_glmm_slopes_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,

@@ -285,8 +285,8 @@ def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, s
 
 
 def glmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, family: str = "logit", theta_start: float = 0.0,
-             beta_start=None, wald_se: str = "rx"):
-    """Random-intercept GLMM (Laplace; Wald SE mode "rx" or "hessian") on provided bytes."""
+             beta_start=None, wald_se: str = "rx", nagq: int = 1):
+    """Random-intercept GLMM (Laplace or nagq-point adaptive Gauss-Hermite; Wald SE mode "rx" or "hessian") on provided bytes."""
     n, p = design.shape
     x = np.ascontiguousarray(design.T, dtype=np.float32)
     y = np.ascontiguousarray(outcome, dtype=np.float32)
@@ -302,10 +302,18 @@ def glmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, f
                              C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), C.c_uint32(ncl), C.c_double(theta_start),
                              None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd), se.ctypes.data_as(pd),
                              zsq.ctypes.data_as(pd), C.byref(th), C.byref(t2), C.byref(conv), C.byref(bh), C.byref(ne),
-                             C.c_uint32(1 if wald_se == "hessian" else 0))
+                             C.c_uint32((1 if wald_se == "hessian" else 0) | (int(nagq) << 8)))
     _check(rc)
     return dict(beta=beta, se=se, z_sq=zsq, theta=th.value, tau_sq=t2.value, converged=bool(conv.value),
                 boundary_hit=bh.value, n_eval=ne.value)
+
+
+def gh_rule(k: int):
+    """k-point Gauss-Hermite rule for the standard normal weight: (nodes, weights), sum w = 1."""
+    z, w = np.zeros(k), np.zeros(k)
+    pd = C.POINTER(C.c_double)
+    lib().mcpo_gh_rule(C.c_uint32(k), z.ctypes.data_as(pd), w.ctypes.data_as(pd))
+    return z, w
 
 
 def glmm_slopes_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, slope_cols, family: str = "logit",

@@ -64,7 +64,8 @@ void mcpo_fam_eval(int fam, double eta, double yi, double* w_out, double* z_out,
 int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld, uint32_t p,
                       uint32_t ncl, double theta0, const double* beta0, uint32_t mode, mcpo_gen_fit* f);
 /* mode bits of the GLMM fits: Wald SE from the finite-difference Hessian instead of "rx" */
-#define MCPO_MODE_HESSIAN 1u
+#define MCPO_MODE_HESSIAN 1u  /* bits 8..15: nagq (0 / 1 = Laplace) */
+void mcpo_gh_rule(uint32_t k, double* z, double* w);
 typedef double (*mcpo_dev_fn)(void* ctx, double* par);
 int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t nth, uint32_t p, const uint8_t* theta_free,
                            double fx, double* l_out);

@@ -448,7 +448,10 @@ def test_find_power_clustered_glm_with_a_random_slope_device_equals_oracle(engin
 
 def test_clustered_glm_opt_in_modes_are_refused_not_approximated():
     c = _glmm_contract()
-    c["nagq"] = 7
+    c["nagq"] = 7              # quadrature over a scalar random intercept lowers to spec.nagq ...
+    assert K.contract_to_simulation_spec(c).nagq == 7 and K.contract_to_simulation_spec(_glmm_contract()).nagq == 1
+    c = _glmm_slope_contract()
+    c["nagq"] = 7              # ... the tensor rule over slopes is refused, not approximated
     with pytest.raises(S.EngineError) as e:
         K.contract_to_simulation_spec(c)
     assert e.value.status == S.Status.Unsupported and "nagq" in str(e.value)

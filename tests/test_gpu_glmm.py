@@ -162,6 +162,40 @@ def test_glmm_hessian_wald_se_matches_oracle(name, engine, oracle):
     assert np.array_equal(stat[singular], stat_rx[singular])     # vcov.merMod's fallback
 
 
+# ---- adaptive Gauss-Hermite quadrature (spec.nagq) ----
+
+@pytest.mark.parametrize("shape,nagq", [("intercept", 7), ("intercept", 25), ("laplace_bias", 7)])
+def test_glmm_agq_matches_oracle(shape, nagq, engine, oracle):
+    """lme4's glmerAGQ objective on both sides; `laplace_bias` is formulas.R:1141-1154 (150 clusters of 4, ICC 0.5)."""
+    spec, _, a, low = load_case("glmm_intercept")
+    if shape == "laplace_bias":
+        spec.cluster = S.ClusterSpec(sizing=("FixedClusters", 150), tau_squared=np.pi ** 2 / 3.0)
+    spec.scenario.truth_start = True
+    lap = engine.run_batch(spec, [600], 32, BASE_SEED)
+    spec.nagq = nagq
+    dev, stat = engine.run_batch_st_capture(spec, [600], 32, BASE_SEED)
+    ora = oracle.run_batch(spec, [600], 32, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.9
+    _compare(dev, ora, 32, stat, ora.stat_capture)
+    both = (dev.converged[:, 0] == 1) & (lap.converged[:, 0] == 1)
+    assert not np.allclose(dev.tau_squared_hat[both], lap.tau_squared_hat[both], rtol=1e-4)   # the rule changes the fit
+    if shape == "laplace_bias":   # Laplace shrinks tau-hat^2 on tiny clusters; the quadrature undoes it
+        assert np.mean(dev.tau_squared_hat[both]) > np.mean(lap.tau_squared_hat[both])
+
+
+def test_glmm_agq_with_slopes_is_refused(engine):
+    spec, _, a, low = load_case("glmm_slope")
+    spec.nagq = 5
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, [600], 4, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "nagq" in str(e.value)
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.nagq = 4
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, [600], 4, BASE_SEED)
+    assert e.value.status == S.Status.InvalidSpec
+
+
 def test_glmm_slopes_probit_scenario_and_counters(engine, oracle):
     from helpers import preset
     spec, _, a, low = load_case("glmm_slope")
