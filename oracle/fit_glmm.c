@@ -494,8 +494,18 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
                   uint8_t* joint_unc, uint8_t* joint_cor, uint8_t* overall, double* tau_hat, double* stat_row,
                   uint64_t* pinned) {
   const mcp_cluster* cl = &spec->cluster;
-  if (!cl->present || cl->n_extra_groupings || cl->slopes.n_slopes > 2) return MCP_ERR_UNSUPPORTED;
-  const uint32_t q = 1 + cl->slopes.n_slopes, nth = q * (q + 1) / 2;
+  if (!cl->present || cl->slopes.n_slopes > 2) return MCP_ERR_UNSUPPORTED;
+  /* extra groupings couple the clusters: fit_glmm_general.c (oracle only; "rx" SE, Laplace) */
+  const int general = cl->n_extra_groupings != 0;
+  if (general && (spec->wald_se == MCP_WALD_SE_HESSIAN || spec->nagq > 1)) return MCP_ERR_UNSUPPORTED;
+  const uint32_t q = 1 + cl->slopes.n_slopes;
+  uint32_t nth = q * (q + 1) / 2;
+  for (uint32_t e = 0; e < cl->n_extra_groupings; ++e) nth += (1 + cl->extra[e].slopes.n_slopes) * (2 + cl->extra[e].slopes.n_slopes) / 2;
+  uint32_t* extra_ids[MCP_MAX_EXTRA_GROUPINGS] = {NULL, NULL};
+  for (uint32_t e = 0; e < cl->n_extra_groupings; ++e) {
+    extra_ids[e] = (uint32_t*)malloc(sizeof(uint32_t) * max_n);
+    for (uint32_t i = 0; i < max_n; ++i) extra_ids[e][i] = mcpo_extra_level_of_row(cl, e, i);
+  }
   uint32_t slope_cols[2] = {0, 0};
   if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS || spec->n_contrast_pairs) return MCP_ERR_UNSUPPORTED;
   if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
@@ -521,7 +531,7 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
   } else {
     uint8_t none[16] = {0};
     p_fit = mcpo_build_exclusion_remap(spec, none, kept, remap);
-    if (p_fit == 0 || kept[0] != 0) { free(ids); return MCP_ERR_UNSUPPORTED; }
+    if (p_fit == 0 || kept[0] != 0) { free(ids); free(extra_ids[0]); free(extra_ids[1]); return MCP_ERR_UNSUPPORTED; }
     xr = (float*)malloc(sizeof(float) * (size_t)max_n * p);
     for (uint32_t rj = 0; rj < p_fit; ++rj) {
       memcpy(xr + (size_t)rj * max_n, ws->x + (size_t)kept[rj] * max_n, sizeof(float) * max_n);
@@ -529,19 +539,39 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
     }
     xfit = xr;
     for (uint32_t d = 0; d + 1 < q; ++d) {  /* a random slope needs its column in the fitted design */
-      if (remap[cl->slopes.design_cols[d]] < 0) { free(ids); free(xr); return MCP_ERR_UNSUPPORTED; }
+      if (remap[cl->slopes.design_cols[d]] < 0) { free(ids); free(xr); free(extra_ids[0]); free(extra_ids[1]); return MCP_ERR_UNSUPPORTED; }
       slope_cols[d] = (uint32_t)remap[cl->slopes.design_cols[d]];
     }
   }
   int has_prev = 0, rc = MCP_OK;
-  double carry = 0.0, carry_v[6] = {0};
+  double carry = 0.0, carry_v[12] = {0};
+  if (general && test_reduces) { /* slopes of the extra groupings ride on fitted columns as well */
+    for (uint32_t e = 0; e < cl->n_extra_groupings && rc == MCP_OK; ++e)
+      for (uint32_t d = 0; d < cl->extra[e].slopes.n_slopes; ++d)
+        if (remap[cl->extra[e].slopes.design_cols[d]] < 0) rc = MCP_ERR_UNSUPPORTED;
+  }
   for (uint32_t g = 0; g < n_ns && rc == MCP_OK; ++g) {
     const uint32_t n = ns[g];
     const uint32_t ncl = fixed_clusters ? cv : (n + cv - 1) / cv;
     double th0 = has_prev ? carry : (spec->scenario.truth_start ? sqrt(fmax(cl->tau_squared, 0.0)) : 1.0);
     if ((has_prev || spec->scenario.truth_start) && th0 < 0.01) th0 = 0.01;
     mcpo_gen_fit f;
-    if (q == 1) {
+    if (general) {
+      mcpo_re_term terms[3];
+      memset(terms, 0, sizeof terms);
+      for (uint32_t t = 0; t <= cl->n_extra_groupings; ++t) {
+        const mcp_re_slopes* sl = t == 0 ? &cl->slopes : &cl->extra[t - 1].slopes;
+        terms[t].q = 1u + sl->n_slopes;
+        terms[t].n_levels = t == 0 ? ncl : mcpo_extra_n_levels_at(cl, t - 1, n);
+        terms[t].ids = t == 0 ? ids : extra_ids[t - 1];
+        for (uint32_t d = 0; d < sl->n_slopes; ++d) terms[t].cols[d] = (uint32_t)remap[sl->design_cols[d]];
+      }
+      double tv[12];
+      const double* start = NULL;
+      if (has_prev) start = carry_v;
+      else if (spec->scenario.truth_start) { mcpo_truth_theta(cl, 1, tv); start = tv; }
+      rc = mcpo_glmm_general_fit_terms(fam, xfit, ws->y, n, max_n, p_fit, terms, 1 + cl->n_extra_groupings, start, beta0, &f);
+    } else if (q == 1) {
       rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, mode, &f);
     } else {
       double tv[12];
@@ -583,5 +613,6 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
   }
   free(ids);
   free(xr);
+  for (uint32_t e = 0; e < MCP_MAX_EXTRA_GROUPINGS; ++e) free(extra_ids[e]);
   return rc;
 }

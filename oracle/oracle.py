@@ -284,6 +284,38 @@ def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, s
                 converged=bool(conv.value), boundary_hit=conv.value and bh.value, pinned=pinned.value, n_eval=ne.value)
 
 
+def glmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, slope_cols, family: str = "logit",
+                     theta_start=None, beta_start=None):
+    """GLMM (Laplace, "rx" SE) with any carried random-effect structure on provided bytes; arguments as lmm_general_fit."""
+    n, p = design.shape
+    x = np.ascontiguousarray(design.T, dtype=np.float32)
+    y = np.ascontiguousarray(outcome, dtype=np.float32)
+    nt = len(term_ids)
+    ids = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.uint32) for v in term_ids]))
+    q = np.asarray(term_q, dtype=np.uint32)
+    levels = np.asarray([int(v.max()) + 1 for v in ids], dtype=np.uint32)
+    cols = np.zeros((nt, S.MAX_RE_SLOPES), dtype=np.uint32)
+    for t, cs in enumerate(slope_cols):
+        cols[t, :len(cs)] = cs
+    n_theta = int(sum(int(v) * (int(v) + 1) // 2 for v in q))
+    beta, se = np.zeros(p), np.zeros(p)
+    theta, vars_out = np.zeros(max(n_theta, 1)), np.zeros((nt, 3, 3))
+    conv, bh, ne, pinned = C.c_uint8(), C.c_uint8(), C.c_uint32(), C.c_uint64()
+    pd, pu = C.POINTER(C.c_double), C.POINTER(C.c_uint32)
+    t0 = None if theta_start is None else np.ascontiguousarray(theta_start, dtype=np.float64)
+    b0 = None if beta_start is None else np.ascontiguousarray(beta_start, dtype=np.float64)
+    rc = lib().mcpo_glmm_general_fit(C.c_int(GLM_FAMILIES[family]), x.ctypes.data_as(C.POINTER(C.c_float)),
+                                     y.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(n), C.c_uint32(n), C.c_uint32(p),
+                                     C.c_uint32(nt), q.ctypes.data_as(pu), levels.ctypes.data_as(pu), ids.ctypes.data_as(pu),
+                                     cols.ctypes.data_as(pu), None if t0 is None else t0.ctypes.data_as(pd),
+                                     None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
+                                     se.ctypes.data_as(pd), theta.ctypes.data_as(pd), vars_out.ctypes.data_as(pd),
+                                     C.byref(conv), C.byref(bh), C.byref(pinned), C.byref(ne))
+    _check(rc)
+    return dict(beta=beta, se=se, theta=theta[:n_theta], cov=vars_out, converged=bool(conv.value), boundary_hit=bh.value,
+                pinned=pinned.value, n_eval=ne.value)
+
+
 def glmm_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, family: str = "logit", theta_start: float = 0.0,
              beta_start=None, wald_se: str = "rx", nagq: int = 1):
     """Random-intercept GLMM (Laplace or nagq-point adaptive Gauss-Hermite; Wald SE mode "rx" or "hessian") on provided bytes."""

@@ -252,7 +252,8 @@ def make_cases():
 
 MIXED_CASES = ("lmm_crossed_a", "lmm_crossed_b", "lmm_nested_a", "lmm_nested_b", "lmm_crossed_nested_a", "lmm_slope_a",
                "lmm_slope_b", "lmm_multislope", "lmm_slope_crossed", "lmm_slope_crossed_extra_slopes",
-               "lmm_slope_nested_extra_slopes", "glmm_intercept", "glmm_slope", "glmm_multislope")
+               "lmm_slope_nested_extra_slopes", "glmm_intercept", "glmm_slope", "glmm_multislope", "glmm_slope_crossed",
+               "glmm_slope_crossed_extra_slopes", "glmm_slope_nested_extra_slopes")
 
 
 def _one(v):

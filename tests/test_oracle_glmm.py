@@ -240,3 +240,63 @@ def test_agq_on_the_laplace_bias_shape_and_through_run_batch(oracle):
     spec.cluster_slope_design_cols = [1]
     with pytest.raises(Exception):
         oracle.run_batch(spec, [600], 2, 2404, n_threads=2)
+
+
+# ---- extra groupings under a GLM family (fit_glmm_general.c; ORACLE ONLY -- the device path refuses them) ----
+
+GENERAL_CASES = ["glmm_slope_crossed", "glmm_slope_crossed_extra_slopes", "glmm_slope_nested_extra_slopes"]
+
+
+def _glmm_terms(spec, a):
+    ids = [a["cluster_ids"]] + [a["extra_ids"][g] for g in range(a["extra_ids"].shape[0])]
+    q = [1 + len(spec.cluster.slopes)] + [1 + len(g.get("slopes", [])) for g in spec.cluster.extra_groupings]
+    cols = [spec.cluster_slope_design_cols] + list(spec.extra_slope_cols)
+    return ids, q, cols
+
+
+@pytest.mark.parametrize("name", GENERAL_CASES)
+def test_general_glmm_datasets_are_reproduced_bit_exact(name, oracle):
+    spec, base_seed, a, low = load_case(name)
+    x, y, ids, extra = oracle.generate_sim_data_ids(spec, base_seed, 0, low["n"])
+    assert np.array_equal(ids, a["cluster_ids"]) and np.array_equal(x, a["design"]) and np.array_equal(y, a["outcome"])
+    assert all(np.array_equal(e, a["extra_ids"][g]) for g, e in enumerate(extra))
+
+
+@pytest.mark.parametrize("start", ["blind", "truth"])
+@pytest.mark.parametrize("name", GENERAL_CASES)
+def test_general_laplace_fit_matches_glmer(name, start, oracle):
+    """The remaining three of the reference's M4 GLMM cases (formulas.R:1130-1181): crossed / nested extra groupings,
+    slopes on both.  beta-hat inside GLMM_TOL (1e-4 rel with a 1e-3 abs floor), variance components within 1 %; all
+    three are singular fits with the same pinned structure as glmer's, whose reported z is then the "rx" z."""
+    spec, _, a, low = load_case(name)
+    ids, q, cols = _glmm_terms(spec, a)
+    kw = {} if start == "blind" else dict(theta_start=oracle.truth_theta(spec), beta_start=spec.effect_sizes)
+    r = oracle.glmm_general_fit(a["design"], a["outcome"], ids, q, cols, family="logit", **kw)
+    assert r["converged"] and r["boundary_hit"] == 1
+    assert np.all(np.abs(r["beta"] - a["golden_beta"]) <= np.maximum(1e-4 * np.abs(a["golden_beta"]), 1e-3))
+    got = np.concatenate([np.diag(r["cov"][t])[:qq] for t, qq in enumerate(q)])
+    assert np.allclose(got, a["golden_vars"], rtol=1e-2, atol=1e-6)
+    assert np.all(np.abs(r["beta"] / r["se"] / a["golden_z"] - 1.0) < 2e-3)
+
+
+def test_general_fit_on_a_single_grouping_equals_the_per_cluster_fit(oracle):
+    spec, _, a, low = load_case("glmm_multislope")
+    v = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], [1, 2], family="logit")
+    g = oracle.glmm_general_fit(a["design"], a["outcome"], [a["cluster_ids"]], [3], [[1, 2]], family="logit")
+    assert np.allclose(g["beta"], v["beta"], atol=2e-6) and np.allclose(g["theta"], v["theta"], atol=2e-5)
+    assert np.allclose(g["se"], v["se"], rtol=1e-5)
+
+
+def test_glmm_arm_with_extra_groupings_run_batch(oracle):
+    spec, _, a, low = load_case("glmm_slope_crossed")
+    spec.scenario.truth_start = True
+    r = oracle.run_batch(spec, [480], 6, BASE_SEED, n_threads=6, stat_capture=True)
+    assert r.converged.mean() > 0.6
+    ids, q, cols = _glmm_terms(spec, a)
+    x, y, cid, extra = oracle.generate_sim_data_ids(spec, BASE_SEED, 0, 480)
+    f = oracle.glmm_general_fit(x, y, [cid] + list(extra), q, cols, family="logit", theta_start=oracle.truth_theta(spec),
+                                beta_start=spec.effect_sizes)
+    assert f["converged"] == bool(r.converged[0, 0])
+    if f["converged"]:
+        assert np.isclose((f["beta"][1] / f["se"][1]) ** 2, r.stat_capture[0, 0], rtol=1e-10)
+        assert f["pinned"] == r.pinned_components[0, 0] and np.isclose(f["theta"][0] ** 2, r.tau_squared_hat[0, 0])
