@@ -52,6 +52,8 @@ WORKLOADS = {
     "glmm": ("spec_glmm", 600, 4.5e7, 4 * 600 * 2),
     # ... with a random slope (reference case glmm_slope, formulas.R): ~900 evaluations, 2 x 2 penalised systems per cluster
     "glmm_slope": ("spec_glmm_slope", 600, 1.6e8, 4 * 600 * 2),
+    # ... and a crossed grouping (reference case glmm_slope_crossed, formulas.R:1130-1140): 54 random effects, joint modes
+    "glmm_crossed": ("spec_glmm_crossed", 480, 1.2e9, 4 * 480 * 2),
     "lmm_slope": ("spec_lmm_slope", 480, 2.6e5, 4 * 480 * 2),
     "lmm_crossed": ("spec_lmm_crossed", 480, 3.4e5, 4 * 480 * 3),
     # C5: C2b design on the grid N = 50..1000 (20 prefix fits per replicate on shared draws) under the three
@@ -134,7 +136,7 @@ def main():
     if args.workload.startswith("c5_"):
         spec.scenario = helpers.preset(args.workload[3:])
         ns = helpers.C5_GRID
-    S = args.sims_per_gpu or ({"c3": 1_000_000, "c4": 1_000_000, "lmm_slope": 40_000, "lmm_crossed": 40_000, "glmm": 40_000, "glmm_slope": 16_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
+    S = args.sims_per_gpu or ({"c3": 1_000_000, "c4": 1_000_000, "lmm_slope": 40_000, "lmm_crossed": 40_000, "glmm": 40_000, "glmm_slope": 16_000, "glmm_crossed": 4_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
     staged = args.pipeline == "staged"
 
     def barrier():
@@ -203,19 +205,19 @@ def main():
             "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM', 'glmm_slope': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
-                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'glmm_slope': 'logit, Laplace, (1 + x1 | g), 30 clusters x 20', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
+            "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM', 'glmm_slope': 'GLMM', 'glmm_crossed': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
+                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'glmm_slope': 'logit, Laplace, (1 + x1 | g), 30 clusters x 20', 'glmm_crossed': 'logit, Laplace, (1 + x1 | g) + (1 | item), 24 x 6 levels', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": "1 all-reduce(sum) of counters per step"},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),
         }
-        is_ols = args.workload not in ("c3", "c4", "lmm_slope", "lmm_crossed", "glmm", "glmm_slope")
+        is_ols = args.workload not in ("c3", "c4", "lmm_slope", "lmm_crossed", "glmm", "glmm_slope", "glmm_crossed")
         is_c5 = args.workload.startswith("c5_")
         if not staged:
             fits_per_launch *= len(ns)  # a replicate on a grid is len(ns) prefix fits (throughput.rs:1111-1113)
             ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"glmm_slopes_kernel<{spec.n_predictors},2>" if args.workload == "glmm_slope" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
+            out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"glmm_slopes_kernel<{spec.n_predictors},2>" if args.workload == "glmm_slope" else f"glmm_general_kernel<{spec.n_predictors}>" if args.workload == "glmm_crossed" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
                                "traffic": (pmc_traffic(args.workload, f"ols_sim_kernel<{spec.n_predictors}, 0,")
                                            if (is_ols and not is_c5 and S == 1_000_000) else None),

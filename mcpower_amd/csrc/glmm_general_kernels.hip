@@ -1,0 +1,1051 @@
+// glmm_general_kernels.hip -- gfx950 kernel of the clustered GLM with EXTRA GROUPINGS (crossed with / nested in the
+// primary one, random slopes on any of them): the structure glmm_kernels.hip / glmm_slopes_kernels.hip cannot split
+// by cluster.  Same objective (lme4's glmer, Laplace), same simplex; the conditional modes are found jointly:
+//   d(theta, beta) = sum_i devres_i + |u~|^2 + log|I + A'WA|,   u <- (I + A'WA)^-1 A'W (z - eta0),   A = Z Lambda_theta,
+// over all R = sum_t q_t L_t random effects, following oracle/fit_glmm_general.c operation for operation.
+//
+// One wavefront per replicate, everything in LDS (R <= ~115: the R x R system is the big tenant).  One Fisher
+// step: lane = row evaluates the family kernel (weight, working residual, deviance); then, term by term, lane = level
+// folds the rows of that level into the columns of I + A'WA it OWNS (its own q x q block and the strips against
+// later terms) -- no two lanes ever touch the same entry, and every entry sums its rows in row order; a
+// right-looking dense Cholesky with lane = row (entries update in ascending pivot order: the oracle's dot-product
+// order) skips exact zeros, which is most of the primary block-diagonal part; two triangular solves give the step.
+// Wald covariance "rx": X'WX - (A'WX)' (I + A'WA)^-1 (A'WX) from the last factor.
+// (clustered branch of the Glm arm, crates/engine-core/src/batch.rs:1575-1830; structure: mixed_workspace.rs:112-198)
+#ifndef MCP_GLMM_WAVES
+#define MCP_GLMM_WAVES 2
+#endif
+#include <hip/hip_runtime.h>
+
+#include "mcp_device.hpp"
+#include "mcp_params.hpp"
+#include "mcp_scenario.hpp"
+#include "mcp_rows.hpp"
+#include "mcp_decide.hpp"
+#include "mcp_glm_family.hpp"
+
+#pragma clang fp contract(off)
+
+namespace mcp {
+namespace {
+
+constexpr int QW = 64;
+constexpr uint32_t GLMM_MAX_EVAL = 30000;
+constexpr double GLMM_THETA_MAX = 32.0;
+constexpr double GLMM_THETA_ZERO = 1e-6;
+constexpr int GLMM_PIRLS_ITERS = 60;
+constexpr double GLMM_NEAR_ZERO = 1e-30;
+constexpr int GLMM_ROW = 20;  // simplex row stride (d = n_theta + P <= 12 + 6)
+constexpr uint32_t GG_MAX_TERMS = 3;
+
+typedef __attribute__((address_space(3))) double gdd;
+typedef __attribute__((address_space(3))) float gdf;
+typedef __attribute__((address_space(3))) uint16_t gdu;
+
+struct GlmmLds {
+  gdd *eta0, *wrow, *res, *M, *u, *r, *un, *C, *T, *simplex, *fv, *tail;
+  gdf *design, *draws;
+  gdu* lvl;          // level of a row in extra term t at lvl[(t - 1) * n_pad + i]
+  gdu* rows;         // rows of extra term t grouped by level (ascending within a level) at rows[(t - 1) * n_pad + ..]
+  gdu* lstart;       // first slot of level l of extra term t at lstart[so[t] + l] (levels + 1 entries)
+  uint32_t so[GG_MAX_TERMS];
+  float* st;
+  uint32_t R, RS;    // random effects in total, row stride of M (odd: lanes on different rows spread over the banks)
+  uint32_t off[GG_MAX_TERMS], doff[GG_MAX_TERMS], diag_mask;
+};
+
+__device__ __forceinline__ void gq_sync() { __syncthreads(); }
+
+__device__ __forceinline__ double gq_wave_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < QW; m <<= 1) v += __shfl_xor(v, m, QW);
+  return v;
+}
+
+// extra_level_of_row (generation.rs:402-427)
+__device__ __forceinline__ uint32_t gg_level_of_row(const SimParams& prm, uint32_t t, uint32_t i) {
+  const uint32_t v = prm.cluster_v;
+  if (t == 0u) return prm.cluster_fixed_clusters ? i % v : i / v;
+  const uint32_t bl = prm.lmg_count[t];
+  if (prm.cluster_fixed_clusters) {
+    uint32_t stride = v;
+    for (uint32_t h = 1; h < t; ++h) stride *= prm.lmg_count[h];
+    const uint32_t within = (i / stride) % bl;
+    return prm.lmg_relation[t] == 0u ? within : (i % v) * bl + within;
+  }
+  return (i / v) * bl + (i % v) % bl;
+}
+
+// a = Lambda_t' z of row i for term t (q entries); returns the row's level in that term
+template <int P>
+__device__ __forceinline__ uint32_t gg_row_term(const SimParams& prm, const GlmmLds& m, uint32_t t, uint32_t i, uint32_t n_pad,
+                                                double (&a)[3]) {
+  const uint32_t q = prm.lmg_q[t];
+  double z[3];
+  z[0] = 1.0;
+  z[1] = q > 1u ? (double)m.design[(size_t)(prm.lmg_cols[t][0] - 1u) * n_pad + i] : 0.0;
+  z[2] = q > 2u ? (double)m.design[(size_t)(prm.lmg_cols[t][1] - 1u) * n_pad + i] : 0.0;
+  const gdd* T = m.T + t * 9u;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    double s = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < 3; ++dd)
+      if (dd >= b) s += ((uint32_t)dd < q && (uint32_t)b < q) ? T[dd * 3 + b] * z[dd] : 0.0;
+    a[b] = s;
+  }
+  return t == 0u ? gg_level_of_row(prm, 0u, i) : (uint32_t)m.lvl[(size_t)(t - 1u) * n_pad + i];
+}
+
+// in-place lower Cholesky of the R x R matrix (row stride RS).  The leading R0 rows / columns are the primary
+// grouping's q0 x q0 diagonal blocks, everything below them is dense.  Phase 1: lane = primary level factors its block
+// and scales the dense rows of its columns (left-looking: each entry subtracts its products in ascending pivot order,
+// then divides -- the operation sequence of the plain right-looking loop).  Phase 2: lanes over the (row, column)
+// pairs of the dense block subtract the primary columns' products, ascending.  Phase 3: right-looking on the dense
+// block, lane = row.  log|.| sums the pivots in index order.
+__device__ __noinline__ bool gg_chol(gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, uint32_t lane, gdd* tmp,
+                                     double& logdet) {
+  bool ok = true;
+  const uint32_t L0 = R0 / q0, Re = R - R0;
+  gq_sync();
+  for (uint32_t l = lane; l < L0; l += QW) {
+    const uint32_t base = l * q0;
+    for (uint32_t jj = 0; jj < q0; ++jj) {
+      const uint32_t j = base + jj;
+      double dj = M[(size_t)j * RS + j];
+      for (uint32_t k = 0; k < jj; ++k) dj -= M[(size_t)j * RS + base + k] * M[(size_t)j * RS + base + k];
+      ok = ok && (dj > 0.0) && (dj < __builtin_inf());
+      const double ljj = __builtin_sqrt(dj);
+      M[(size_t)j * RS + j] = ljj;
+      for (uint32_t ii = jj + 1u; ii < q0; ++ii) {
+        const uint32_t i = base + ii;
+        double v = M[(size_t)i * RS + j];
+        for (uint32_t k = 0; k < jj; ++k) v -= M[(size_t)i * RS + base + k] * M[(size_t)j * RS + base + k];
+        M[(size_t)i * RS + j] = v / ljj;
+      }
+      for (uint32_t i = R0; i < R; ++i) {
+        double v = M[(size_t)i * RS + j];
+        for (uint32_t k = 0; k < jj; ++k) v -= M[(size_t)i * RS + base + k] * M[(size_t)j * RS + base + k];
+        M[(size_t)i * RS + j] = v / ljj;
+      }
+    }
+  }
+  gq_sync();
+  for (uint32_t e = lane; e < Re * (Re + 1u) / 2u; e += QW) {
+    uint32_t ii = (uint32_t)((__builtin_sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while (ii * (ii + 1u) / 2u > e) --ii;
+    while ((ii + 1u) * (ii + 2u) / 2u <= e) ++ii;
+    const uint32_t cc = e - ii * (ii + 1u) / 2u;
+    const gdd* Mi = M + (size_t)(R0 + ii) * RS;
+    const gdd* Mc = M + (size_t)(R0 + cc) * RS;
+    double v = Mi[R0 + cc];
+    for (uint32_t j = 0; j < R0; ++j) {
+      const double lij = Mi[j];
+      if (lij != 0.0) v -= lij * Mc[j];
+    }
+    M[(size_t)(R0 + ii) * RS + R0 + cc] = v;
+  }
+  for (uint32_t j = R0; j < R; ++j) {
+    gq_sync();
+    const double dj = M[(size_t)j * RS + j];
+    ok = ok && (dj > 0.0) && (dj < __builtin_inf());
+    const double ljj = __builtin_sqrt(dj);
+    gq_sync();
+    if (lane == 0u) M[(size_t)j * RS + j] = ljj;
+    for (uint32_t i = j + 1u + lane; i < R; i += QW) M[(size_t)i * RS + j] = M[(size_t)i * RS + j] / ljj;
+    gq_sync();
+    for (uint32_t i = j + 1u + lane; i < R; i += QW) {
+      const double lij = M[(size_t)i * RS + j];
+      if (lij == 0.0) continue;
+      gdd* Mi = M + (size_t)i * RS;
+      uint32_t c = j + 1u;
+      for (; c + 3u <= i; c += 4u) {  // the pivot column is read-only here: loads first, then four independent updates
+        const double l0 = M[(size_t)c * RS + j], l1 = M[(size_t)(c + 1u) * RS + j];
+        const double l2 = M[(size_t)(c + 2u) * RS + j], l3 = M[(size_t)(c + 3u) * RS + j];
+        const double m0 = Mi[c], m1 = Mi[c + 1u], m2 = Mi[c + 2u], m3 = Mi[c + 3u];
+        Mi[c] = m0 - lij * l0;
+        Mi[c + 1u] = m1 - lij * l1;
+        Mi[c + 2u] = m2 - lij * l2;
+        Mi[c + 3u] = m3 - lij * l3;
+      }
+      for (; c <= i; ++c) Mi[c] -= lij * M[(size_t)c * RS + j];
+    }
+  }
+  gq_sync();
+  for (uint32_t a = lane; a < R; a += QW) tmp[a] = 2.0 * log(M[(size_t)a * RS + a]);
+  ok = __ballot(!ok) == 0ull;
+  gq_sync();
+  double ld = 0.0;
+  for (uint32_t a = 0; a < R; ++a) ld += tmp[a];
+  gq_sync();
+  logdet = ld;
+  return ok;
+}
+
+// L x = b in place (b: nrhs columns, row stride bs): primary blocks by their lanes, the dense rows' products with them
+// in ascending column order, then the dense block column by column -- every entry subtracts in the dot product's order
+__device__ __noinline__ void gg_forward(const gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, gdd* b, uint32_t bs,
+                                        uint32_t nrhs, uint32_t lane) {
+  const uint32_t L0 = R0 / q0;
+  gq_sync();
+  for (uint32_t l = lane; l < L0; l += QW) {
+    const uint32_t base = l * q0;
+    for (uint32_t jj = 0; jj < q0; ++jj) {
+      const uint32_t j = base + jj;
+      for (uint32_t c = 0; c < nrhs; ++c) {
+        double v = b[(size_t)j * bs + c];
+        for (uint32_t k = 0; k < jj; ++k) v -= M[(size_t)j * RS + base + k] * b[(size_t)(base + k) * bs + c];
+        b[(size_t)j * bs + c] = v / M[(size_t)j * RS + j];
+      }
+    }
+  }
+  gq_sync();
+  for (uint32_t e = lane; e < (R - R0) * nrhs; e += QW) {
+    const uint32_t a = R0 + e / nrhs, c = e % nrhs;
+    double v = b[(size_t)a * bs + c];
+    for (uint32_t j = 0; j < R0; ++j) {
+      const double laj = M[(size_t)a * RS + j];
+      if (laj != 0.0) v -= laj * b[(size_t)j * bs + c];
+    }
+    b[(size_t)a * bs + c] = v;
+  }
+  for (uint32_t k = R0; k < R; ++k) {
+    gq_sync();
+    const double lkk = M[(size_t)k * RS + k];
+    if (lane < nrhs) b[(size_t)k * bs + lane] = b[(size_t)k * bs + lane] / lkk;
+    gq_sync();
+    for (uint32_t a = k + 1u + lane; a < R; a += QW) {
+      const double lak = M[(size_t)a * RS + k];
+      if (lak != 0.0)
+        for (uint32_t c = 0; c < nrhs; ++c) b[(size_t)a * bs + c] -= lak * b[(size_t)k * bs + c];
+    }
+  }
+  gq_sync();
+}
+
+// L' x = t (t in r, consumed; x to un): the dense block from the bottom, then every primary block by its lane
+__device__ __noinline__ void gg_backward(const gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, gdd* r, gdd* un,
+                                         uint32_t lane) {
+  for (uint32_t kk = R; kk-- > R0;) {
+    gq_sync();
+    const double unk = r[kk] / M[(size_t)kk * RS + kk];
+    if (lane == 0u) un[kk] = unk;
+    gq_sync();
+    for (uint32_t a = R0 + lane; a < kk; a += QW) {
+      const double lka = M[(size_t)kk * RS + a];
+      if (lka != 0.0) r[a] -= lka * unk;
+    }
+  }
+  gq_sync();
+  const uint32_t L0 = R0 / q0;
+  for (uint32_t l = lane; l < L0; l += QW) {
+    const uint32_t base = l * q0;
+    for (uint32_t jj = q0; jj-- > 0u;) {
+      const uint32_t j = base + jj;
+      double v = r[j];
+      for (uint32_t e = R; e-- > R0;) {
+        const double lej = M[(size_t)e * RS + j];
+        if (lej != 0.0) v -= lej * un[e];
+      }
+      for (uint32_t kk = q0; kk-- > jj + 1u;) v -= M[(size_t)(base + kk) * RS + j] * un[base + kk];
+      un[j] = v / M[(size_t)j * RS + j];
+    }
+  }
+  gq_sync();
+}
+
+// Laplace deviance at par = (theta vech per term, beta); leaves the modes in m.u and the factor of I + A'WA in m.M
+template <int P>
+__device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
+                                         uint32_t ncl, uint32_t n_pad, uint32_t keep) {
+  const uint32_t fam = prm.glm_family, nterms = prm.lmg_n_terms, nth = prm.lmg_n_theta, R = m.R, RS = m.RS;
+  const uint32_t cv = prm.cluster_v;
+  double beta[P];
+  {
+    uint32_t k = nth;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+      const bool kept = (keep >> c) & 1u;
+      beta[c] = kept ? par[k] : 0.0;
+      k += kept ? 1u : 0u;
+    }
+  }
+  if (lane < 27u) m.T[lane] = 0.0;
+  gq_sync();
+  if (lane == 0u) {  // lower templates, column-major vech per term (mixed_workspace.rs:112-198)
+    uint32_t k = 0;
+    for (uint32_t t = 0; t < nterms; ++t)
+      for (uint32_t c = 0; c < prm.lmg_q[t]; ++c)
+        for (uint32_t r = c; r < prm.lmg_q[t]; ++r) m.T[t * 9u + r * 3u + c] = par[k++];
+  }
+  for (uint32_t i = lane; i < n; i += QW) {
+    double e = beta[0];
+#pragma unroll
+    for (int c = 1; c < P; ++c) e += (double)m.design[(size_t)(c - 1) * n_pad + i] * beta[c];
+    m.eta0[i] = e;
+  }
+  for (uint32_t a = lane; a < R; a += QW) m.u[a] = 0.0;
+  gq_sync();
+  double pd_prev = __builtin_inf(), dev = 0.0, logdet = 0.0, uu = 0.0;
+  bool ok = true;
+  for (int it = 0; it < GLMM_PIRLS_ITERS; ++it) {
+    // ---- lane = row: weight, working residual, deviance at the current modes ----
+    double devp = 0.0;
+    for (uint32_t i = lane; i < n; i += QW) {
+      double au = 0.0;
+      for (uint32_t t = 0; t < nterms; ++t) {
+        double a[3];
+        const uint32_t l = gg_row_term<P>(prm, m, t, i, n_pad, a);
+        const gdd* ut = m.u + m.off[t] + l * prm.lmg_q[t];
+        au += a[0] * ut[0];
+        if (prm.lmg_q[t] > 1u) au += a[1] * ut[1];
+        if (prm.lmg_q[t] > 2u) au += a[2] * ut[2];
+      }
+      const double e0 = m.eta0[i];
+      double w, wz, dv;
+      fam_eval(fam, e0 + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
+      m.wrow[i] = w;
+      m.res[i] = wz - w * e0;  // w (z - eta0)
+      devp += dv;
+    }
+    dev = gq_wave_sum(devp);
+    for (uint32_t e = lane; e < R * RS; e += QW) m.M[e] = 0.0;
+    gq_sync();
+    // ---- lane = level of term t: the columns of I + A'WA (and the entries of A'W(z - eta0)) that level owns ----
+    for (uint32_t t = 0; t < nterms; ++t) {
+      const uint32_t q = prm.lmg_q[t], nl = t == 0u ? ncl : prm.lmg_levels[t];
+      for (uint32_t l = lane; l < nl; l += QW) {
+        double rl[3] = {0.0, 0.0, 0.0}, bl[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+        // rows of the level: an arithmetic progression for the primary grouping, the level's slice of the row list else
+        const uint32_t first = t == 0u ? (prm.cluster_fixed_clusters ? l : l * cv) : (uint32_t)m.lstart[m.so[t] + l];
+        const uint32_t step = t == 0u ? (prm.cluster_fixed_clusters ? cv : 1u) : 1u;
+        const uint32_t last = t == 0u ? (prm.cluster_fixed_clusters ? n : ((l + 1u) * cv < n ? (l + 1u) * cv : n))
+                                      : (uint32_t)m.lstart[m.so[t] + l + 1u];
+        const uint32_t colbase = m.off[t] + l * q;
+        for (uint32_t s = first; s < last; s += step) {
+          const uint32_t i = t == 0u ? s : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + s];
+          if (i >= n) break;  // ascending within a level: the rest lies past this grid point's sample
+          double a[3];
+          gg_row_term<P>(prm, m, t, i, n_pad, a);
+          const double w = m.wrow[i], rs = m.res[i];
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            rl[b] += rs * a[b];
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd)
+              if (dd <= b) bl[b][dd] += w * a[b] * a[dd];
+          }
+          for (uint32_t t2 = t + 1u; t2 < nterms; ++t2) {  // strips against later terms: rows of the later term, my columns
+            double a2[3];
+            const uint32_t l2 = gg_row_term<P>(prm, m, t2, i, n_pad, a2);
+            const uint32_t q2 = prm.lmg_q[t2], rowbase = m.off[t2] + l2 * q2;
+            for (uint32_t b2 = 0; b2 < q2; ++b2)
+              for (uint32_t b = 0; b < q; ++b) m.M[(size_t)(rowbase + b2) * RS + colbase + b] += w * a2[b2] * a[b];
+          }
+        }
+        for (uint32_t b = 0; b < q; ++b) {
+          m.r[colbase + b] = rl[b];
+          for (uint32_t dd = 0; dd <= b; ++dd) m.M[(size_t)(colbase + b) * RS + colbase + dd] = bl[b][dd] + (b == dd ? 1.0 : 0.0);
+        }
+      }
+      gq_sync();
+    }
+    // levels past this grid point's sample (FixedSize sizing) hold no rows: identity rows, zero modes
+    for (uint32_t a = lane; a < R; a += QW) {
+      if (m.M[(size_t)a * RS + a] == 0.0) {
+        m.M[(size_t)a * RS + a] = 1.0;
+        m.r[a] = 0.0;
+      }
+    }
+    double uup = 0.0;
+    for (uint32_t a = lane; a < R; a += QW) uup += m.u[a] * m.u[a];
+    uu = gq_wave_sum(uup);
+    gq_sync();
+    const double pd = dev + uu;
+    ok = gg_chol(m.M, R, RS, m.off[1], prm.lmg_q[0], lane, m.un, logdet);
+    if (!ok) break;
+    if (it > 0 && __builtin_fabs(pd - pd_prev) <= 1e-13 * (__builtin_fabs(pd) + 1.0)) break;
+    gg_forward(m.M, R, RS, m.off[1], prm.lmg_q[0], m.r, 1u, 1u, lane);
+    gg_backward(m.M, R, RS, m.off[1], prm.lmg_q[0], m.r, m.un, lane);
+    bool same = true;
+    for (uint32_t a = lane; a < R; a += QW) {
+      double v = m.un[a];
+      const double uo = m.u[a];
+      if (it > 0 && pd > pd_prev) v = 0.5 * (uo + v);
+      same = same && (v == uo);
+      m.un[a] = v;
+    }
+    same = __ballot(!same) == 0ull;
+    pd_prev = pd;
+    if (same) break;
+    gq_sync();
+    for (uint32_t a = lane; a < R; a += QW) m.u[a] = m.un[a];
+    gq_sync();
+  }
+  gq_sync();
+  const double total = dev + uu + logdet;
+  return (ok && total < __builtin_inf() && total > -__builtin_inf()) ? total : __builtin_inf();
+}
+
+template <int P>
+__device__ __forceinline__ double glmm_f(const SimParams& prm, const GlmmLds& m, gdd* x, uint32_t lane, uint32_t n, uint32_t ncl,
+                                         uint32_t n_pad, uint32_t keep, uint32_t& n_eval) {
+  const uint32_t nth = prm.lmg_n_theta;
+  if (lane < nth + (uint32_t)__popc(keep)) {
+    double v = x[lane];
+    if (lane < nth) {
+      if ((m.diag_mask >> lane) & 1u) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+      else v = v < -GLMM_THETA_MAX ? -GLMM_THETA_MAX : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+    } else {
+      v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
+    }
+    x[lane] = v;
+  }
+  gq_sync();
+  ++n_eval;
+  return glmm_eval<P>(prm, m, x, lane, n, ncl, n_pad, keep);
+}
+
+// one Nelder-Mead run from simplex row 0 with initial edge `step`; the best point ends in row 0
+template <int P>
+__device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const GlmmLds m, double step, double ftol, double xtol,
+                                                uint32_t lane, uint32_t n, uint32_t ncl, uint32_t n_pad, uint32_t keep,
+                                                uint32_t& n_eval) {
+  const uint32_t d = prm.lmg_n_theta + (uint32_t)__popc(keep);
+  gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe
+  gdd* fv = m.fv;
+  gdd* cen = sx + (size_t)(d + 1u) * GLMM_ROW;
+  gdd* xr = cen + GLMM_ROW;
+  gdd* xe = xr + GLMM_ROW;
+  const double inf = __builtin_inf();
+  const double f0 = glmm_f<P>(prm, m, sx, lane, n, ncl, n_pad, keep, n_eval);
+  if (lane == 0u) fv[0] = f0;
+  for (uint32_t i = 0; i < d; ++i) {
+    gdd* v = sx + (size_t)(i + 1u) * GLMM_ROW;
+    if (lane < d) v[lane] = sx[lane] + (lane == i ? step : 0.0);
+    gq_sync();
+    const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
+    if (lane == 0u) fv[i + 1u] = fi;
+  }
+  gq_sync();
+  while (n_eval < GLMM_MAX_EVAL) {
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t i = 1; i <= d; ++i) {
+      if (fv[i] < fv[lo]) lo = i;
+      if (fv[i] > fv[hi]) hi = i;
+    }
+    uint32_t nh = lo;
+    for (uint32_t i = 0; i <= d; ++i)
+      if (i != hi && fv[i] > fv[nh]) nh = i;
+    double size = 0.0;
+    for (uint32_t i = 0; i <= d; ++i)
+      for (uint32_t k = 0; k < d; ++k) {
+        const double dd = __builtin_fabs(sx[(size_t)i * GLMM_ROW + k] - sx[(size_t)lo * GLMM_ROW + k]);
+        size = dd > size ? dd : size;
+      }
+    if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
+    const double flo = fv[lo], fhi = fv[hi], fnh = fv[nh];
+    gq_sync();
+    if (lane < d) {
+      double s = 0.0;
+      for (uint32_t i = 0; i <= d; ++i)
+        if (i != hi) s += sx[(size_t)i * GLMM_ROW + lane];
+      const double c = s / (double)d;
+      cen[lane] = c;
+      xr[lane] = c + (c - sx[(size_t)hi * GLMM_ROW + lane]);
+    }
+    gq_sync();
+    const double fr = glmm_f<P>(prm, m, xr, lane, n, ncl, n_pad, keep, n_eval);
+    gdd* worst = sx + (size_t)hi * GLMM_ROW;
+    if (fr < flo) {
+      if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
+      gq_sync();
+      const double fe = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
+      if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
+      if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
+    } else if (fr < fnh) {
+      if (lane < d) worst[lane] = xr[lane];
+      if (lane == 0u) fv[hi] = fr;
+    } else {
+      const bool outside = fr < fhi;
+      if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
+      gq_sync();
+      const double fc = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
+      if (fc < (outside ? fr : fhi)) {
+        if (lane < d) worst[lane] = xe[lane];
+        if (lane == 0u) fv[hi] = fc;
+      } else {
+        for (uint32_t i = 0; i <= d; ++i) {
+          if (i == lo) continue;
+          gdd* v = sx + (size_t)i * GLMM_ROW;
+          if (lane < d) v[lane] = sx[(size_t)lo * GLMM_ROW + lane] + 0.5 * (v[lane] - sx[(size_t)lo * GLMM_ROW + lane]);
+          gq_sync();
+          const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
+          if (lane == 0u) fv[i] = fi;
+          gq_sync();
+        }
+      }
+    }
+    gq_sync();
+  }
+  uint32_t lo = 0;
+  for (uint32_t i = 1; i <= d; ++i)
+    if (fv[i] < fv[lo]) lo = i;
+  const double best = fv[lo];
+  gq_sync();
+  double best_k = 0.0;
+  if (lane < d) best_k = sx[(size_t)lo * GLMM_ROW + lane];
+  gq_sync();
+  if (lane < d) sx[lane] = best_k;
+  gq_sync();
+  return best;
+}
+
+// SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
+// random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
+#include "mcp_glmm_hessian.hpp"
+
+
+// SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
+// random-effect shape and per-replicate tau^2 of every grouping (data_gen.rs:146-161, 1069-1092)
+template <int P, bool SCEN>
+__global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_general_kernel(const SimParams* __restrict__ pp) {
+  extern __shared__ double lds_q[];
+  const SimParams& prm = *pp;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lsim = blockIdx.x;
+  const uint64_t sim_id = prm.sim_begin + lsim;
+  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+  const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
+  const uint32_t ncl_max = prm.n_clusters_max;
+  const uint32_t cv = prm.cluster_v;
+  const uint32_t nterms = prm.lmg_n_terms, nth = prm.lmg_n_theta;
+  const uint32_t dmax = nth + (uint32_t)P;
+  GlmmLds m;
+  {
+    m.R = prm.lmg_levels[0] * prm.lmg_q[0] + prm.lmg_R;
+    m.RS = m.R | 1u;
+    uint32_t nd = 0, dm = 0, k = 0;
+    for (uint32_t t = 0; t < GG_MAX_TERMS; ++t) {
+      m.off[t] = t == 0u ? 0u : prm.lmg_levels[0] * prm.lmg_q[0] + prm.lmg_roff[t];
+      m.doff[t] = nd;
+      if (t < nterms) {
+        nd += prm.lmg_levels[t] * prm.lmg_q[t];
+        for (uint32_t c = 0; c < prm.lmg_q[t]; ++c)
+          for (uint32_t r = c; r < prm.lmg_q[t]; ++r) dm |= (r == c ? 1u : 0u) << k++;
+      }
+    }
+    m.diag_mask = dm;
+    gdd* q = (gdd*)lds_q;
+    m.eta0 = q; q += n_pad;
+    m.wrow = q; q += n_pad;
+    m.res = q; q += n_pad;
+    m.M = q; q += (size_t)m.R * m.RS;
+    m.u = q; q += m.R;
+    m.r = q; q += m.R;
+    m.un = q; q += m.R;
+    m.C = q; q += (size_t)m.R * P;
+    m.T = q; q += 28;
+    m.simplex = q; q += (size_t)(dmax + 4u) * GLMM_ROW;
+    m.fv = q; q += (dmax + 2u) & ~1u;
+    m.tail = q; q += 8;
+    gdf* f = (gdf*)q;
+    m.design = f; f += (size_t)P * n_pad;
+    m.draws = f; f += (nd + 1u) & ~1u;
+    m.lvl = (gdu*)f; f += (size_t)(nterms - 1u) * n_pad / 2u + 2u;
+    m.rows = (gdu*)f; f += (size_t)(nterms - 1u) * n_pad / 2u + 2u;
+    m.lstart = (gdu*)f;
+    {
+      uint32_t so = 0;
+      for (uint32_t t = 0; t < GG_MAX_TERMS; ++t) {
+        m.so[t] = so;
+        if (t >= 1u && t < nterms) so += prm.lmg_levels[t] + 2u;
+      }
+      f += (so + 3u) / 2u + 1u;
+    }
+    m.st = (float*)f + lane;
+  }
+  // ---- 1. random effects on the sequential stream (data_gen.rs:146-284): per grouping its intercepts, then its
+  //         correlated slopes through chol(diag(tau) R diag(tau)); draw order: primary intercepts, primary slopes, every
+  //         extra grouping's intercepts, every extra grouping's slopes (the lowering's lmg_seq offsets) ----
+  auto re_draw = [&](uint32_t ordinal) -> double {
+    if (SCEN) return draw_cluster_effect(prm, k0, k1, ordinal);
+    return (double)norm_inv_cdf_f32(u32_to_unit_f32(sequential_word(k0, k1, (uint64_t)ordinal)));
+  };
+  for (uint32_t t = 0; t < nterms; ++t) {
+    const uint32_t q = prm.lmg_q[t], nl = prm.lmg_levels[t];
+    gdf* ux = m.draws + m.doff[t];
+    double tau_t = prm.lmg_tau[t];
+    if (SCEN && prm.scen_tau_sq) {  // realised tau per grouping (ICC jitter, data_gen.rs:1069-1092)
+      const double t2 = prm.scen_tau_sq[(size_t)t * prm.scen_stride + lsim];
+      tau_t = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
+    }
+    for (uint32_t c = lane; c < nl; c += QW) ux[(size_t)c * q] = (float)(re_draw(prm.lmg_seq[2u * t] + c) * tau_t);
+    gq_sync();
+    if (q > 1u) {
+      double lt[9];
+      if (!SCEN) {
+        for (uint32_t i = 0; i < 9u; ++i) lt[i] = prm.lmg_chol[t][i];
+      } else {  // chol_lower (data_gen.rs:55-75) of the replicate's own D
+        const double tv[3] = {tau_t, prm.lmg_slope_sd[t][0], prm.lmg_slope_sd[t][1]};
+        double dm[9];
+        for (uint32_t i = 0; i < 9u; ++i) lt[i] = 0.0;
+        for (uint32_t i = 0; i < q; ++i)
+          for (uint32_t j = 0; j < q; ++j) dm[i * q + j] = tv[i] * prm.lmg_recorr[t][i * q + j] * tv[j];
+        for (uint32_t j = 0; j < q; ++j) {
+          double diag = dm[j * q + j];
+          for (uint32_t k = 0; k < j; ++k) diag -= lt[j * q + k] * lt[j * q + k];
+          const double ljj = __builtin_sqrt(diag > 0.0 ? diag : 0.0);
+          lt[j * q + j] = ljj;
+          for (uint32_t i = j + 1u; i < q; ++i)
+            if (ljj > 0.0) {
+              double sacc = dm[i * q + j];
+              for (uint32_t k = 0; k < j; ++k) sacc -= lt[i * q + k] * lt[j * q + k];
+              lt[i * q + j] = sacc / ljj;
+            }
+        }
+      }
+      for (uint32_t c = lane; c < nl; c += QW) {
+        double z[3];
+        z[0] = tau_t > 0.0 ? (double)ux[(size_t)c * q] / tau_t : 0.0;
+        for (uint32_t j = 1; j < q; ++j) z[j] = re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u) + (j - 1u));
+        for (uint32_t k = 1; k < q; ++k) {
+          double uk = 0.0;
+          for (uint32_t j = 0; j <= k; ++j) uk += lt[k * q + j] * z[j];
+          ux[(size_t)c * q + k] = (float)uk;
+        }
+      }
+    }
+    gq_sync();
+  }
+  for (uint32_t t = 1; t < nterms; ++t)
+    for (uint32_t i = lane; i < max_n; i += QW) m.lvl[(size_t)(t - 1u) * n_pad + i] = (uint16_t)gg_level_of_row(prm, t, i);
+  gq_sync();
+  for (uint32_t t = 1; t < nterms; ++t) {  // counting sort of the rows by level, once per replicate
+    const uint32_t nl = prm.lmg_levels[t];
+    const gdu* lv = m.lvl + (size_t)(t - 1u) * n_pad;
+    gdu* ls = m.lstart + m.so[t];
+    for (uint32_t l = lane; l < nl; l += QW) {
+      uint32_t cnt = 0;
+      for (uint32_t i = 0; i < max_n; ++i) cnt += (uint32_t)lv[i] == l ? 1u : 0u;
+      ls[l + 1u] = (uint16_t)cnt;
+    }
+    gq_sync();
+    if (lane == 0u) {
+      ls[0] = 0;
+      for (uint32_t l = 0; l < nl; ++l) ls[l + 1u] = (uint16_t)((uint32_t)ls[l] + (uint32_t)ls[l + 1u]);
+    }
+    gq_sync();
+    for (uint32_t l = lane; l < nl; l += QW) {
+      uint32_t slot = ls[l];
+      for (uint32_t i = 0; i < max_n; ++i)
+        if ((uint32_t)lv[i] == l) m.rows[(size_t)(t - 1u) * n_pad + slot++] = (uint16_t)i;
+    }
+  }
+  gq_sync();
+  // latent-scale random effect of a row in the reference's order: primary intercept, extras (intercept, slopes),
+  // primary slopes (data_gen.rs:812-842)
+  auto row_effect = [&](uint32_t rr, const float (&x)[P]) -> double {
+    uint32_t cid = gg_level_of_row(prm, 0u, rr);
+    cid = cid < ncl_max ? cid : 0u;
+    const uint32_t q0 = prm.lmg_q[0];
+    double u_re = (double)m.draws[(size_t)cid * q0];
+    for (uint32_t t = 1; t < nterms; ++t) {
+      const uint32_t q = prm.lmg_q[t], lv = (uint32_t)m.lvl[(size_t)(t - 1u) * n_pad + rr];
+      const gdf* ux = m.draws + m.doff[t] + (size_t)lv * q;
+      u_re += (double)ux[0];
+      for (uint32_t s2 = 1; s2 < q; ++s2) {
+        float xv = 0.0f;
+#pragma unroll
+        for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[t][s2 - 1u] ? x[c] : xv;
+        u_re += (double)ux[s2] * (double)xv;
+      }
+    }
+    for (uint32_t s2 = 1; s2 < q0; ++s2) {
+      float xv = 0.0f;
+#pragma unroll
+      for (int c = 1; c < P; ++c) xv = (uint32_t)c == prm.lmg_cols[0][s2 - 1u] ? x[c] : xv;
+      u_re += (double)m.draws[(size_t)cid * q0 + s2] * (double)xv;
+    }
+    return u_re;
+  };
+  RowCtx<P> cx;
+  row_ctx_init<P, true>(prm, cx);
+  ScenLane<P> sl;
+  if (SCEN) scen_lane_load<P>(prm, lsim, sl);
+  const uint32_t bmask = prm.between_mask;
+  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += QW) {
+    stage_group<P, QW, 1, SCEN>(prm, k0, k1, ctr, m.st, SCEN ? sl.meta : 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t rr = 4u * ctr + r;
+      if (rr < max_n) {
+        float x[P], y;
+        const float e = build_x<P, true, QW, SCEN>(prm, cx, k0, k1, m.st, r, rr, x, &sl);
+        if (bmask == 0u) finish_row<P, 1, SCEN>(prm, cx, x, e, y, row_effect(rr, x), &sl);
+        else y = e;  // the outcome draw waits until the cluster-level columns are broadcast
+#pragma unroll
+        for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
+        m.design[(size_t)(P - 1) * n_pad + rr] = y;
+      }
+    }
+  }
+  gq_sync();
+  if (bmask != 0u) {
+    // cluster-level predictors (data_gen.rs:606-636), as in lmm_kernels.hip: broadcast from the representative row,
+    // rebuild interactions and the outcome, rewrite the marked columns last
+    for (uint32_t rr = lane; rr < max_n; rr += QW) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cv : rr - (rr % cv);
+      float x[P];
+      x[0] = 1.0f;
+#pragma unroll
+      for (int c = 1; c < P; ++c) {
+        const uint32_t src = ((bmask >> c) & 1u) ? rep : rr;
+        x[c] = m.design[(size_t)(c - 1) * n_pad + src];
+      }
+      rebuild_interactions<P>(cx, x);
+      const float e = m.design[(size_t)(P - 1) * n_pad + rr];
+      float y;
+      finish_row<P, 1, SCEN>(prm, cx, x, e, y, row_effect(rr, x), &sl);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if (((bmask >> c) & 1u) == 0u && ((cx.inter_any >> c) & 1u)) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
+      m.design[(size_t)(P - 1) * n_pad + rr] = y;
+    }
+    gq_sync();
+    for (uint32_t rr = lane; rr < max_n; rr += QW) {
+      const uint32_t rep = prm.cluster_fixed_clusters ? rr % cv : rr - (rr % cv);
+#pragma unroll
+      for (int c = 1; c < P; ++c)
+        if ((bmask >> c) & 1u) {
+          const float v = m.design[(size_t)(c - 1) * n_pad + rep];
+          __builtin_amdgcn_wave_barrier();
+          m.design[(size_t)(c - 1) * n_pad + rr] = v;
+        }
+    }
+    gq_sync();
+  }
+  bool has_prev = false;
+  double carry[12];
+#pragma unroll
+  for (uint32_t k = 0; k < 12u; ++k) carry[k] = 0.0;
+  const uint32_t nt = prm.n_tests;
+  // fitted columns: all of them, or the test_formula subset (no factor exclusion on clustered specs, batch.rs:1583)
+  const uint32_t keep = prm.glmm_keep;
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n = prm.ns[g];
+    const uint32_t ncl = prm.cluster_fixed_clusters ? cv : (n + cv - 1u) / cv;
+    gdd* x0 = m.simplex;
+    if (lane == 0u) {
+#pragma unroll
+      for (uint32_t k = 0; k < 12u; ++k)
+        if (k < nth) {  // carried theta-hat / truth / blind THETA0 (identity templates)
+          double v = has_prev ? carry[k] : (prm.truth_start ? prm.lmg_theta_truth[k] : (((m.diag_mask >> k) & 1u) ? 1.0 : 0.0));
+          if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;
+          x0[k] = v;
+        }
+      uint32_t k = nth;
+      for (uint32_t c = 0; c < (uint32_t)P; ++c)
+        if ((keep >> c) & 1u) x0[k++] = prm.beta[c];                      // beta starts at the truth, unconditionally
+    }
+    gq_sync();
+    uint32_t n_eval = 0;
+    double best = glmm_nelder_mead<P>(prm, m, 0.25, 1e-9, 1e-6, lane, n, ncl, n_pad, keep, n_eval);
+    for (int restart = 0; restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
+      const double prev = best;
+      best = glmm_nelder_mead<P>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
+      if (!(prev - best > 1e-8)) break;
+    }
+    double cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
+    for (uint32_t k = 0; k < nth; ++k) {
+      if (!((m.diag_mask >> k) & 1u)) continue;
+      const double th_keep = x0[k];
+      if (th_keep != 0.0 && th_keep <= 1e-4) {  // snap onto the boundary when that costs no deviance
+        gq_sync();
+        if (lane == 0u) x0[k] = 0.0;
+        gq_sync();
+        const double f0 = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
+        if (f0 <= cur + 1e-8) cur = f0;
+        else {
+          gq_sync();
+          if (lane == 0u) x0[k] = th_keep;
+          gq_sync();
+        }
+      }
+    }
+    cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);  // modes and the factor of the final point
+    bool ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
+    // ---- RX'RX = X'WX - C' (I + A'WA)^-1 C, C = A'WX (R x P): weights at the final modes, C folded by its owners ----
+    double A[P * (P + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = 0.0;
+    for (uint32_t i = lane; i < n; i += QW) {
+      double au = 0.0;
+      for (uint32_t t = 0; t < nterms; ++t) {
+        double a[3];
+        const uint32_t l = gg_row_term<P>(prm, m, t, i, n_pad, a);
+        const gdd* ut = m.u + m.off[t] + l * prm.lmg_q[t];
+        au += a[0] * ut[0];
+        if (prm.lmg_q[t] > 1u) au += a[1] * ut[1];
+        if (prm.lmg_q[t] > 2u) au += a[2] * ut[2];
+      }
+      double w, wz, dv;
+      fam_eval(prm.glm_family, m.eta0[i] + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
+      m.wrow[i] = w;
+      double xd[P];
+      xd[0] = 1.0;
+#pragma unroll
+      for (int r = 1; r < P; ++r) xd[r] = (double)m.design[(size_t)(r - 1) * n_pad + i];
+      int idx = 0;
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) A[idx++] += w * xd[r] * xd[s2];
+    }
+    for (uint32_t e = lane; e < m.R * (uint32_t)P; e += QW) m.C[e] = 0.0;
+    gq_sync();
+    for (uint32_t t = 0; t < nterms; ++t) {
+      const uint32_t q = prm.lmg_q[t], nl = t == 0u ? ncl : prm.lmg_levels[t];
+      for (uint32_t l = lane; l < nl; l += QW) {
+        double cl[3][P];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int r = 0; r < P; ++r) cl[b][r] = 0.0;
+        // rows of the level: an arithmetic progression for the primary grouping, the level's slice of the row list else
+        const uint32_t first = t == 0u ? (prm.cluster_fixed_clusters ? l : l * cv) : (uint32_t)m.lstart[m.so[t] + l];
+        const uint32_t step = t == 0u ? (prm.cluster_fixed_clusters ? cv : 1u) : 1u;
+        const uint32_t last = t == 0u ? (prm.cluster_fixed_clusters ? n : ((l + 1u) * cv < n ? (l + 1u) * cv : n))
+                                      : (uint32_t)m.lstart[m.so[t] + l + 1u];
+        for (uint32_t s = first; s < last; s += step) {
+          const uint32_t i = t == 0u ? s : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + s];
+          if (i >= n) break;  // ascending within a level: the rest lies past this grid point's sample
+          double a[3];
+          gg_row_term<P>(prm, m, t, i, n_pad, a);
+          const double w = m.wrow[i];
+#pragma unroll
+          for (int r = 0; r < P; ++r) {
+            const double xr = r == 0 ? 1.0 : (double)m.design[(size_t)(r - 1) * n_pad + i];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) cl[b][r] += w * a[b] * xr;
+          }
+        }
+        const uint32_t base = m.off[t] + l * q;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+          if ((uint32_t)b < q)
+#pragma unroll
+            for (int r = 0; r < P; ++r) m.C[(size_t)(base + b) * P + r] = cl[b][r];
+      }
+    }
+    gq_sync();
+    gg_forward(m.M, m.R, m.RS, m.off[1], prm.lmg_q[0], m.C, (uint32_t)P, (uint32_t)P, lane);  // D = L^-1 C
+    {
+      double dd[P * (P + 1) / 2];
+#pragma unroll
+      for (int i = 0; i < P * (P + 1) / 2; ++i) dd[i] = 0.0;
+      for (uint32_t a = lane; a < m.R; a += QW) {
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < P; ++r)
+#pragma unroll
+          for (int s2 = 0; s2 <= r; ++s2) dd[idx++] += m.C[(size_t)a * P + r] * m.C[(size_t)a * P + s2];
+      }
+#pragma unroll
+      for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]) - gq_wave_sum(dd[i]);
+    }
+    double Lx[P][P];
+    {
+      int idx = 0;
+      double Af[P][P];
+#pragma unroll
+      for (int r = 0; r < P; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 <= r; ++s2) {  // a dropped column is an identity row / column: the kept block factors as the gathered system
+          const double v = A[idx++];
+          Af[r][s2] = (((keep >> r) & 1u) && ((keep >> s2) & 1u)) ? v : (r == s2 ? 1.0 : 0.0);
+        }
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        double dj = Af[j][j];
+#pragma unroll
+        for (int t = 0; t < j; ++t) dj -= Lx[j][t] * Lx[j][t];
+        ok = ok && (dj > 0.0) && (dj < __builtin_inf());
+        Lx[j][j] = __builtin_sqrt(dj);
+#pragma unroll
+        for (int i = j + 1; i < P; ++i) {
+          double v = Af[i][j];
+#pragma unroll
+          for (int t = 0; t < j; ++t) v -= Lx[i][t] * Lx[j][t];
+          Lx[i][j] = v / Lx[j][j];
+        }
+      }
+    }
+    bool conv = ok;
+    bool at_upper = false;
+    uint32_t pinned = 0u;
+    {
+      uint32_t comp = 0;
+      for (uint32_t k = 0; k < nth; ++k)
+        if ((m.diag_mask >> k) & 1u) {
+          const double thk = x0[k];
+          if (conv && thk < GLMM_THETA_ZERO) pinned |= 1u << comp;
+          at_upper = at_upper || thk > GLMM_THETA_MAX - 1e-3;
+          ++comp;
+        }
+    }
+    const uint32_t bh = !conv ? 0u : (at_upper ? 2u : (pinned ? 1u : 0u));
+    if (at_upper) conv = false;
+    const double th0 = x0[0];
+    if (conv) {
+#pragma unroll
+      for (uint32_t k = 0; k < 12u; ++k) carry[k] = k < nth ? x0[k] : 0.0;
+      has_prev = true;
+    }
+    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions ----
+    double beta[P];
+    {
+      uint32_t k = nth;
+#pragma unroll
+      for (int c = 0; c < P; ++c) {
+        const bool kept = (keep >> c) & 1u;
+        beta[c] = kept ? x0[k] : 0.0;
+        k += kept ? 1u : 0u;
+      }
+    }
+    const double* crow = prm.crit + (size_t)g * prm.crit_stride;
+    double tsq[MAX_T_WAVE];
+    double U[MAX_T_WAVE][P];
+#pragma unroll
+    for (int t = 0; t < MAX_T_WAVE; ++t) {
+      tsq[t] = __builtin_nan("");
+#pragma unroll
+      for (int i = 0; i < P; ++i) U[t][i] = 0.0;
+      if ((uint32_t)t < nt && conv) {
+        const double* c = prm.contrast + t * MAX_P;
+        double est = 0.0, nq = 0.0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+          est = __builtin_fma(c[i], beta[i], est);
+          double acc = c[i];
+#pragma unroll
+          for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i][q], U[t][q], acc);
+          U[t][i] = acc / Lx[i][i];
+          nq = __builtin_fma(U[t][i], U[t][i], nq);
+        }
+        if (nq > GLMM_NEAR_ZERO && nq < __builtin_inf()) tsq[t] = est * est / nq;
+      }
+    }
+    bool joint_sig = false;
+    if (conv && nt != 0u) {
+      double Lc[MAX_T_WAVE][MAX_T_WAVE], cj[MAX_T_WAVE];
+      bool jok = true;
+      double qsum = 0.0;
+#pragma unroll
+      for (int j = 0; j < MAX_T_WAVE; ++j) {
+        if ((uint32_t)j < nt) {
+          double dd = 0.0;
+#pragma unroll
+          for (int i = 0; i < P; ++i) dd = __builtin_fma(U[j][i], U[j][i], dd);
+#pragma unroll
+          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j][t], Lc[j][t], dd);
+          jok = jok && (dd > 0.0);
+          Lc[j][j] = __builtin_sqrt(dd);
+#pragma unroll
+          for (int i2 = j + 1; i2 < MAX_T_WAVE; ++i2) {
+            if ((uint32_t)i2 < nt) {
+              double vv = 0.0;
+#pragma unroll
+              for (int i = 0; i < P; ++i) vv = __builtin_fma(U[i2][i], U[j][i], vv);
+#pragma unroll
+              for (int t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2][t], Lc[j][t], vv);
+              Lc[i2][j] = vv / Lc[j][j];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MAX_T_WAVE; ++i) {
+        if ((uint32_t)i < nt) {
+          const double* c = prm.contrast + i * MAX_P;
+          double vv = 0.0;
+#pragma unroll
+          for (int q = 0; q < P; ++q) vv = __builtin_fma(c[q], beta[q], vv);
+#pragma unroll
+          for (int t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i][t], cj[t], vv);
+          cj[i] = vv / Lc[i][i];
+          qsum = __builtin_fma(cj[i], cj[i], qsum);
+        }
+      }
+      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > prm.joint_crit_k[nt]);
+    }
+    uint32_t unc_bits = 0, cor_bits = 0;
+    decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
+    if (!conv) {
+      unc_bits = 0;
+      cor_bits = 0;
+    }
+    if (lane == 0u) {
+      const size_t cell = (size_t)(prm.out_base + lsim) * prm.n_grid + g;
+#pragma unroll
+      for (int t = 0; t < MAX_T_WAVE; ++t)
+        if ((uint32_t)t < nt) {
+          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
+          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
+        }
+      prm.conv[cell] = conv ? 1 : 0;
+      prm.boundary[cell] = (uint8_t)bh;
+      prm.joint[cell] = joint_sig ? 1 : 0;
+      if (prm.pinned) prm.pinned[cell] = (uint16_t)pinned;
+      if (prm.tau_hat) prm.tau_hat[cell] = conv ? th0 * th0 : __builtin_nan("");
+      if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1750-1753
+      if (prm.stat && g == 0u) {
+#pragma unroll
+        for (int t = 0; t < MAX_T_WAVE; ++t)
+          if ((uint32_t)t < nt) prm.stat[(size_t)(prm.out_base + lsim) * nt + t] = tsq[t];
+      }
+    }
+    gq_sync();
+  }
+}
+
+}  // namespace
+
+size_t glmm_general_lds_bytes(const SimParams& prm) {
+  const size_t P = prm.P, n_pad = ((size_t)prm.max_n + 3u) & ~(size_t)3u;
+  const size_t R = (size_t)prm.lmg_levels[0] * prm.lmg_q[0] + prm.lmg_R, RS = R | 1u;
+  const size_t dmax = prm.lmg_n_theta + P;
+  size_t nd = 0;
+  for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) nd += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
+  const size_t dbl = 3 * n_pad + R * RS + 3 * R + R * P + 28 + (dmax + 4) * GLMM_ROW + ((dmax + 2) & ~(size_t)1) + 8;
+  size_t so = 0;
+  for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) so += (size_t)prm.lmg_levels[t] + 2;
+  const size_t flt = P * n_pad + ((nd + 1) & ~(size_t)1) + 2 * ((prm.lmg_n_terms - 1) * n_pad / 2 + 2) + (so + 3) / 2 + 1 +
+                     (size_t)4 * (P + 1) * QW;
+  return dbl * 8 + flt * 4 + 64;
+}
+
+hipError_t launch_glmm_general(int P, const SimParams* d_prm, uint32_t n_sims, size_t lds, bool scen, hipStream_t st) {
+  const dim3 block(QW), grid(n_sims);
+#define GQ(PP)                                                                                                         \
+  case PP: {                                                                                                           \
+    if (lds > 48 * 1024) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute(scen ? (const void*)glmm_general_kernel<PP, true>                             \
+                                              : (const void*)glmm_general_kernel<PP, false>,                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+      if (e != hipSuccess) return e;                                                                                   \
+    }                                                                                                                  \
+    if (scen) hipLaunchKernelGGL((glmm_general_kernel<PP, true>), grid, block, lds, st, d_prm);                        \
+    else hipLaunchKernelGGL((glmm_general_kernel<PP, false>), grid, block, lds, st, d_prm);                            \
+  } break;
+  switch (P) {
+    GQ(2) GQ(3) GQ(4) GQ(5) GQ(6)
+    default: return hipErrorInvalidValue;
+  }
+#undef GQ
+  return hipGetLastError();
+}
+
+}  // namespace mcp

@@ -44,6 +44,8 @@ size_t glmm_lds_bytes(int P, uint32_t max_n, uint32_t ncl_max);
 hipError_t launch_glmm_slopes(int P, int Q, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, uint32_t ncl_max, bool scen,
                               hipStream_t st);
 size_t glmm_slopes_lds_bytes(int P, int Q, uint32_t max_n, uint32_t ncl_max);
+hipError_t launch_glmm_general(int P, const SimParams* d_prm, uint32_t n_sims, size_t lds, bool scen, hipStream_t st);
+size_t glmm_general_lds_bytes(const SimParams& prm);
 hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 hipError_t launch_lmm_general_scen(int P, int q0, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st);
 size_t lmg_lds_bytes(const SimParams& prm);
@@ -292,8 +294,13 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
   const bool lmg = mle && prm.lmg_active;  // random slopes / extra groupings: the general mixed-model kernel
   const bool glmm = prm.glmm_active != 0u;  // clustered GLM: random-intercept GLMM kernel (writes flags like the Mle arm)
-  const bool glmm_slopes = glmm && prm.lmg_active;  // ... with random slopes on the primary grouping (vector modes)
-  if (glmm && (glmm_slopes ? mcp::glmm_slopes_lds_bytes((int)P, (int)prm.lmg_q[0], prm.max_n, prm.n_clusters_max)
+  const bool glmm_general = glmm && prm.lmg_active && prm.lmg_n_terms > 1u;  // ... with extra groupings: joint modes, dense system
+  const bool glmm_slopes = glmm && prm.lmg_active && !glmm_general;  // ... with random slopes on the primary grouping (vector modes)
+  if (glmm_general && mcp::glmm_general_lds_bytes(prm) > 158u * 1024u) {
+    mcp_free_result(out);
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: clustered GLM whose random effects (levels x widths over all groupings) do not fit one wave's LDS budget");
+  }
+  if (glmm && !glmm_general && (glmm_slopes ? mcp::glmm_slopes_lds_bytes((int)P, (int)prm.lmg_q[0], prm.max_n, prm.n_clusters_max)
                            : mcp::glmm_lds_bytes((int)P, prm.max_n, prm.n_clusters_max)) > 158u * 1024u) {
     mcp_free_result(out);
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: clustered GLM design does not fit one wave's LDS budget");
@@ -514,7 +521,8 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
-      if (glmm_slopes) DEV_TRY(mcp::launch_glmm_slopes((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, scen, st));
+      if (glmm_general) DEV_TRY(mcp::launch_glmm_general((int)P, d_prm + c, h_prm[c].n_sims, mcp::glmm_general_lds_bytes(prm), scen, st));
+      else if (glmm_slopes) DEV_TRY(mcp::launch_glmm_slopes((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, scen, st));
       else if (glmm) DEV_TRY(mcp::launch_glmm((int)P, d_prm + c, h_prm[c].n_sims, prm.max_n, prm.n_clusters_max, scen, st));
       else if (lmg && scen) DEV_TRY(mcp::launch_lmm_general_scen((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));
       else if (lmg) DEV_TRY(mcp::launch_lmm_general((int)P, (int)prm.lmg_q[0], d_prm + c, h_prm[c].n_sims, mcp::lmg_lds_bytes(prm), st));

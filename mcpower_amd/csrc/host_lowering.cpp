@@ -282,8 +282,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
   const bool glmm = spec->cluster.present && spec->estimator == MCP_EST_GLM;  // batch.rs:1575-1830
-  if (glmm && spec->cluster.n_extra_groupings)
-    return unsupported("clustered GLM with extra groupings (primary grouping only: random intercept, optional random slopes)");
+  if (glmm && spec->cluster.n_extra_groupings && (spec->wald_se != MCP_WALD_SE_RX || spec->nagq > 1))
+    return unsupported("clustered GLM with extra groupings under Wald SE mode 'hessian' or nagq > 1 (Laplace with the 'rx' SE only)");
   if (lmm_general) {
     if (spec->estimator != MCP_EST_MLE && !glmm) return unsupported("random slopes / extra groupings outside the Mle / clustered Glm estimators");
     if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");
@@ -753,9 +753,11 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     prm.glmm_hessian = spec->wald_se == MCP_WALD_SE_HESSIAN ? 1u : 0u;
     prm.glmm_keep = prm.keep_mask[0];  // every column, or the test_formula subset (flag combination 0: nothing excluded)
     if (!(prm.glmm_keep & 1u)) return unsupported("intercept-free test_formula fit of a clustered GLM");
-    for (uint32_t d = 0; d < spec->cluster.slopes.n_slopes; ++d)
-      if (!((prm.glmm_keep >> spec->cluster.slopes.design_cols[d]) & 1u))
-        return unsupported("test_formula dropping a column that carries a random slope");
+    for (uint32_t t = 0; t <= spec->cluster.n_extra_groupings; ++t) {
+      const mcp_re_slopes& sl = t == 0 ? spec->cluster.slopes : spec->cluster.extra[t - 1].slopes;
+      for (uint32_t d = 0; d < sl.n_slopes; ++d)
+        if (!((prm.glmm_keep >> sl.design_cols[d]) & 1u)) return unsupported("test_formula dropping a column that carries a random slope");
+    }
     prm.red_active = 0;  // no factor exclusion on clustered specs (batch.rs:1583)
   }
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))

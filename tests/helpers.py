@@ -191,6 +191,13 @@ def spec_glmm_slope() -> S.SimulationSpec:
     return spec
 
 
+def spec_glmm_crossed() -> S.SimulationSpec:
+    """Reference case glmm_slope_crossed (validation/formulas.R:1130-1140): logit, (1 + x1 | g) + (1 | item), 24 x 6."""
+    spec = load_case("glmm_slope_crossed")[0]
+    spec.scenario.truth_start = True
+    return spec
+
+
 def spec_lmm_slope() -> S.SimulationSpec:
     """Reference case lmm_slope_a (validation/formulas.R:461-469): y ~ x1 + (1 + x1 | g), 24 clusters x 20."""
     spec = load_case("lmm_slope_a")[0]

@@ -75,9 +75,59 @@ def test_glmm_two_predictors_fixed_size_clusters_counters_and_shards(engine, ora
 def test_glmm_refuses_what_it_cannot_do(engine):
     spec, _, a, low = load_case("glmm_intercept")
     spec.cluster.extra_groupings = [{"relation": {"Crossed": {"n_clusters": 8}}, "tau_squared": 0.2, "slopes": []}]
+    spec.wald_se = S.WaldSe.Hessian
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(spec, [600], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "extra groupings" in str(e.value)
+
+
+# ---- extra groupings: glmm_general_kernels.hip vs oracle/fit_glmm_general.c (formulas.R:1130-1181) ----
+
+@pytest.mark.parametrize("name,n_sims", [("glmm_slope_crossed", 24), ("glmm_slope_crossed_extra_slopes", 16),
+                                         ("glmm_slope_nested_extra_slopes", 12)])
+def test_glmm_with_extra_groupings_matches_oracle(name, n_sims, engine, oracle):
+    spec, _, a, low = load_case(name)
+    spec.scenario.truth_start = True
+    dev, stat = engine.run_batch_st_capture(spec, [low["n"]], n_sims, BASE_SEED)
+    ora = oracle.run_batch(spec, [low["n"]], n_sims, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.7
+    _compare(dev, ora, n_sims, stat, ora.stat_capture, slack=2)
+
+
+def test_glmm_extra_groupings_under_a_scenario_preset_poisson(engine, oracle):
+    """General data path + heavy-tailed random effects + one ICC jitter per grouping, Poisson outcome, nested grouping
+    under FixedSize sizing (levels follow the grid)."""
+    from helpers import preset
+    spec, _, a, low = load_case("glmm_slope_nested_extra_slopes")
+    spec.outcome_kind = S.OutcomeKind.Count
+    spec.effect_sizes = [0.5, 0.15]
+    spec.cluster.tau_squared = 0.10
+    spec.scenario = preset("realistic")
+    spec.scenario.lme = S.LmeScenarioPerturbations(random_effect_dist=S.ResidualDist.HighKurtosis, random_effect_df=6.0,
+                                                   icc_noise_sd=0.05)
+    dev = engine.run_batch(spec, [360, 720], 12, BASE_SEED)
+    ora = oracle.run_batch(spec, [360, 720], 12, BASE_SEED, n_threads=8)
+    assert dev.converged.mean() > 0.6
+    _compare(dev, ora, 12, slack=2)
+
+
+def test_glmm_extra_groupings_reference_capture_and_grid(engine, oracle):
+    """sim 0 of the reference's glmm_slope_crossed seed equals a refit of the captured bytes; a two-point grid carries
+    theta-hat; counters-only aggregation equals the per-replicate run."""
+    spec, base_seed, a, low = load_case("glmm_slope_crossed")
+    spec.scenario.truth_start = True
+    dev, stat = engine.run_batch_st_capture(spec, [low["n"]], 1, base_seed)
+    ids = [a["cluster_ids"]] + [a["extra_ids"][g] for g in range(a["extra_ids"].shape[0])]
+    f = oracle.glmm_general_fit(a["design"], a["outcome"], ids, [2, 1], [[1], []], family="logit",
+                                theta_start=oracle.truth_theta(spec), beta_start=spec.effect_sizes)
+    assert dev.converged[0, 0] == 1 and f["converged"]
+    assert np.isclose(stat[0, 0], (f["beta"][1] / f["se"][1]) ** 2, rtol=1e-5)
+    assert dev.pinned_components[0, 0] == f["pinned"]
+    dev = engine.run_batch(spec, [240, 480], 12, BASE_SEED)
+    ora = oracle.run_batch(spec, [240, 480], 12, BASE_SEED, n_threads=8)
+    _compare(dev, ora, 12, slack=2)
+    red = engine.run_batch(spec, [240, 480], 12, BASE_SEED, per_sim=False)
+    assert np.array_equal(red.counters, dev.counters)
 
 
 # ---- random slopes on the primary grouping: glmm_slopes_kernels.hip vs oracle/fit_glmm_slopes.c ----
