@@ -94,21 +94,49 @@ def test_glmm_with_extra_groupings_matches_oracle(name, n_sims, engine, oracle):
     _compare(dev, ora, n_sims, stat, ora.stat_capture, slack=2)
 
 
-def test_glmm_extra_groupings_under_a_scenario_preset_poisson(engine, oracle):
-    """General data path + heavy-tailed random effects + one ICC jitter per grouping, Poisson outcome, nested grouping
-    under FixedSize sizing (levels follow the grid)."""
+@pytest.mark.parametrize("link", ["logit", "probit"])
+def test_glmm_extra_groupings_under_a_scenario_preset(link, engine, oracle):
+    """General data path + heavy-tailed random effects + one ICC jitter per grouping; nested grouping on a two-point
+    grid; statistics compared, not only decisions."""
     from helpers import preset
     spec, _, a, low = load_case("glmm_slope_nested_extra_slopes")
-    spec.outcome_kind = S.OutcomeKind.Count
-    spec.effect_sizes = [0.5, 0.15]
-    spec.cluster.tau_squared = 0.10
+    if link == "probit":
+        spec.link = S.LinkKind.Probit
+        spec.effect_sizes = [-0.52, 0.30]
+        spec.cluster.tau_squared = 0.25
     spec.scenario = preset("realistic")
     spec.scenario.lme = S.LmeScenarioPerturbations(random_effect_dist=S.ResidualDist.HighKurtosis, random_effect_df=6.0,
                                                    icc_noise_sd=0.05)
-    dev = engine.run_batch(spec, [360, 720], 12, BASE_SEED)
-    ora = oracle.run_batch(spec, [360, 720], 12, BASE_SEED, n_threads=8)
+    dev, stat = engine.run_batch_st_capture(spec, [360, 720], 12, BASE_SEED)
+    ora = oracle.run_batch(spec, [360, 720], 12, BASE_SEED, n_threads=8, stat_capture=True)
     assert dev.converged.mean() > 0.6
-    _compare(dev, ora, 12, slack=2)
+    _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
+
+
+def test_glmm_extra_groupings_two_predictors_test_formula_and_count_refusal(engine, oracle):
+    """P = 3 with the slope on the second predictor, a crossed grouping, a test_formula dropping the first predictor;
+    Count outcomes with extra groupings are refused (the joint-mode kernel is verified on Binary outcomes only)."""
+    spec, _, a, low = load_case("glmm_slope_crossed")
+    spec.n_non_factor = 2
+    spec.correlation = [1.0, 0.2, 0.2, 1.0]
+    spec.var_types, spec.var_params = [S.Distribution.Normal] * 2, [0.0, 0.0]
+    spec.effect_sizes = [-0.85, 0.3, 0.5]
+    spec.target_indices = [1, 2]
+    spec.cluster.slopes = [{"column": 1, "variance": 0.10, "corr_with_intercept": 0.3, "corr_with": []}]
+    spec.cluster_slope_design_cols = [2]
+    spec.scenario.truth_start = True
+    dev, stat = engine.run_batch_st_capture(spec, [480], 12, BASE_SEED)
+    ora = oracle.run_batch(spec, [480], 12, BASE_SEED, n_threads=8, stat_capture=True)
+    _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
+    spec.fit_columns = [0, 2]
+    spec.target_indices = [2]
+    dev, stat = engine.run_batch_st_capture(spec, [480], 12, BASE_SEED)
+    ora = oracle.run_batch(spec, [480], 12, BASE_SEED, n_threads=8, stat_capture=True)
+    _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
+    spec.outcome_kind = S.OutcomeKind.Count
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, [480], 4, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "Count outcome" in str(e.value)
 
 
 def test_glmm_extra_groupings_reference_capture_and_grid(engine, oracle):
