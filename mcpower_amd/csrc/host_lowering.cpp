@@ -284,10 +284,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   const bool glmm = spec->cluster.present && spec->estimator == MCP_EST_GLM;  // batch.rs:1575-1830
   if (glmm && spec->cluster.n_extra_groupings && (spec->wald_se != MCP_WALD_SE_RX || spec->nagq > 1))
     return unsupported("clustered GLM with extra groupings under Wald SE mode 'hessian' or nagq > 1 (Laplace with the 'rx' SE only)");
-  // the joint-mode kernel is verified against the oracle on Binary outcomes only: its Wald covariance disagrees with the
-  // oracle's on Count outcomes, so those are refused rather than served
-  if (glmm && spec->cluster.n_extra_groupings && spec->outcome_kind == MCP_OUTCOME_COUNT)
-    return unsupported("Count outcome with extra groupings (clustered GLM with extra groupings: Binary outcomes only)");
   if (lmm_general) {
     if (spec->estimator != MCP_EST_MLE && !glmm) return unsupported("random slopes / extra groupings outside the Mle / clustered Glm estimators");
     if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");

@@ -10,8 +10,7 @@
  *
  * PARITY STATUS: data bit-exact on validation/data/glmm_slope_crossed.rds, glmm_slope_crossed_extra_slopes.rds,
  * glmm_slope_nested_extra_slopes.rds; beta-hat against lme4 1.1.38 glmer on those bytes inside GLMM_TOL
- * (tolerances.R:186-200).  Optimiser, boundary rules: **parity unpinned**.  Checker of glmm_general_kernels.hip (Binary
- * outcomes; the device path refuses Count outcomes with extra groupings).
+ * (tolerances.R:186-200).  Optimiser, boundary rules: **parity unpinned**.  Checker of glmm_general_kernels.hip.
  */
 #include <math.h>
 #include <stdlib.h>

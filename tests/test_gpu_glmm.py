@@ -94,7 +94,7 @@ def test_glmm_with_extra_groupings_matches_oracle(name, n_sims, engine, oracle):
     _compare(dev, ora, n_sims, stat, ora.stat_capture, slack=2)
 
 
-@pytest.mark.parametrize("link", ["logit", "probit"])
+@pytest.mark.parametrize("link", ["logit", "probit", "poisson"])
 def test_glmm_extra_groupings_under_a_scenario_preset(link, engine, oracle):
     """General data path + heavy-tailed random effects + one ICC jitter per grouping; nested grouping on a two-point
     grid; statistics compared, not only decisions."""
@@ -104,6 +104,10 @@ def test_glmm_extra_groupings_under_a_scenario_preset(link, engine, oracle):
         spec.link = S.LinkKind.Probit
         spec.effect_sizes = [-0.52, 0.30]
         spec.cluster.tau_squared = 0.25
+    if link == "poisson":
+        spec.outcome_kind = S.OutcomeKind.Count
+        spec.effect_sizes = [0.5, 0.15]
+        spec.cluster.tau_squared = 0.10
     spec.scenario = preset("realistic")
     spec.scenario.lme = S.LmeScenarioPerturbations(random_effect_dist=S.ResidualDist.HighKurtosis, random_effect_df=6.0,
                                                    icc_noise_sd=0.05)
@@ -113,9 +117,9 @@ def test_glmm_extra_groupings_under_a_scenario_preset(link, engine, oracle):
     _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
 
 
-def test_glmm_extra_groupings_two_predictors_test_formula_and_count_refusal(engine, oracle):
+def test_glmm_extra_groupings_two_predictors_test_formula_and_counts(engine, oracle):
     """P = 3 with the slope on the second predictor, a crossed grouping, a test_formula dropping the first predictor;
-    Count outcomes with extra groupings are refused (the joint-mode kernel is verified on Binary outcomes only)."""
+    then the same design with a Count outcome."""
     spec, _, a, low = load_case("glmm_slope_crossed")
     spec.n_non_factor = 2
     spec.correlation = [1.0, 0.2, 0.2, 1.0]
@@ -134,9 +138,12 @@ def test_glmm_extra_groupings_two_predictors_test_formula_and_count_refusal(engi
     ora = oracle.run_batch(spec, [480], 12, BASE_SEED, n_threads=8, stat_capture=True)
     _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
     spec.outcome_kind = S.OutcomeKind.Count
-    with pytest.raises(S.EngineError) as e:
-        engine.run_batch(spec, [480], 4, BASE_SEED)
-    assert e.value.status == S.Status.Unsupported and "Count outcome" in str(e.value)
+    spec.effect_sizes = [0.5, 0.10, 0.15]
+    spec.cluster.tau_squared = 0.10
+    dev, stat = engine.run_batch_st_capture(spec, [480], 12, BASE_SEED)
+    ora = oracle.run_batch(spec, [480], 12, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.7
+    _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
 
 
 def test_glmm_extra_groupings_reference_capture_and_grid(engine, oracle):
