@@ -508,6 +508,8 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
 
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 of every grouping (data_gen.rs:146-161, 1069-1092)
+#include "mcp_glmm_hessian.hpp"
+
 template <int P, bool SCEN>
 __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_q[];
@@ -848,30 +850,68 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_general_kernel(const 
 #pragma unroll
       for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]) - gq_wave_sum(dd[i]);
     }
+    bool singular = false;
+    for (uint32_t k = 0; k < nth; ++k) singular = singular || (((m.diag_mask >> k) & 1u) && x0[k] < GLMM_THETA_ZERO);
     double Lx[P][P];
-    {
+    // lower Cholesky factor of a packed precision matrix over the kept columns; a dropped column is an identity row /
+    // column: the kept block factors as the gathered system
+    auto factor = [&](const double (&Ap)[P * (P + 1) / 2], double (&L)[P][P]) -> bool {
+      bool fok = true;
       int idx = 0;
       double Af[P][P];
 #pragma unroll
       for (int r = 0; r < P; ++r)
 #pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) {  // a dropped column is an identity row / column: the kept block factors as the gathered system
-          const double v = A[idx++];
-          Af[r][s2] = (((keep >> r) & 1u) && ((keep >> s2) & 1u)) ? v : (r == s2 ? 1.0 : 0.0);
+        for (int s = 0; s <= r; ++s) {
+          const double v = Ap[idx++];
+          Af[r][s] = (((keep >> r) & 1u) && ((keep >> s) & 1u)) ? v : (r == s ? 1.0 : 0.0);
         }
 #pragma unroll
       for (int j = 0; j < P; ++j) {
-        double dj = Af[j][j];
+        double dd = Af[j][j];
 #pragma unroll
-        for (int t = 0; t < j; ++t) dj -= Lx[j][t] * Lx[j][t];
-        ok = ok && (dj > 0.0) && (dj < __builtin_inf());
-        Lx[j][j] = __builtin_sqrt(dj);
+        for (int t = 0; t < j; ++t) dd -= L[j][t] * L[j][t];
+        fok = fok && (dd > 0.0) && (dd < __builtin_inf());
+        L[j][j] = __builtin_sqrt(dd);
 #pragma unroll
         for (int i = j + 1; i < P; ++i) {
           double v = Af[i][j];
 #pragma unroll
-          for (int t = 0; t < j; ++t) v -= Lx[i][t] * Lx[j][t];
-          Lx[i][j] = v / Lx[j][j];
+          for (int t = 0; t < j; ++t) v -= L[i][t] * L[j][t];
+          L[i][j] = v / L[j][j];
+        }
+      }
+      return fok;
+    };
+    ok = factor(A, Lx) && ok;
+    if (prm.glmm_hessian && ok && !(singular)) {
+      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp); a singular fit, or a block that does not factor, keeps "rx"
+      auto fdev = [&](gdd* pt) -> double {
+        uint32_t scratch = 0;
+        return glmm_f<P>(prm, m, pt, lane, n, ncl, n_pad, keep, scratch);
+      };
+      const uint32_t nth_h = nth, d_h = nth_h + (uint32_t)__popc(keep);
+      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane)) {
+        double Ah[P * (P + 1) / 2], Lh[P][P];
+        const gdd* Hs = m.simplex + GLMM_ROW;
+        int idx = 0;
+        uint32_t kr = 0;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+          uint32_t kc = 0;
+#pragma unroll
+          for (int s = 0; s <= r; ++s) {
+            const bool both = ((keep >> r) & 1u) && ((keep >> s) & 1u);
+            Ah[idx++] = both ? Hs[(size_t)(nth_h + kr) * GLMM_ROW + nth_h + kc] : 0.0;
+            kc += ((keep >> s) & 1u) ? 1u : 0u;
+          }
+          kr += ((keep >> r) & 1u) ? 1u : 0u;
+        }
+        if (factor(Ah, Lh)) {
+#pragma unroll
+          for (int r = 0; r < P; ++r)
+#pragma unroll
+            for (int s = 0; s <= r; ++s) Lx[r][s] = Lh[r][s];
         }
       }
     }

@@ -282,8 +282,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (spec->n_contrast_pairs) return unsupported("contrast pairs under the GLM estimator");
   }
   const bool glmm = spec->cluster.present && spec->estimator == MCP_EST_GLM;  // batch.rs:1575-1830
-  if (glmm && spec->cluster.n_extra_groupings && (spec->wald_se != MCP_WALD_SE_RX || spec->nagq > 1))
-    return unsupported("clustered GLM with extra groupings under Wald SE mode 'hessian' or nagq > 1 (Laplace with the 'rx' SE only)");
+  if (glmm && spec->cluster.n_extra_groupings && spec->nagq > 1)
+    return unsupported("adaptive Gauss-Hermite quadrature (nagq > 1) for a clustered GLM with extra groupings (Laplace only)");
   if (lmm_general) {
     if (spec->estimator != MCP_EST_MLE && !glmm) return unsupported("random slopes / extra groupings outside the Mle / clustered Glm estimators");
     if (P > 6u) return unsupported("random slopes / extra groupings with more than 6 design columns");

@@ -248,7 +248,7 @@ static double glmm_nelder_mead(glmm_model* m, double* x0, double step, double ft
 #endif
 int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t nth, uint32_t p, const uint8_t* theta_free,
                            double fx, double* l_out) {
-  enum { MAXD = MCPO_MAX_P + 6 };
+  enum { MAXD = MCPO_MAX_P + 12 };
   uint32_t idx[MAXD], m = 0, mt = 0;
   const uint32_t d = nth + p;
   for (uint32_t k = 0; k < nth; ++k) if (theta_free[k]) idx[m++] = k;
@@ -275,7 +275,7 @@ int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_
   }
   for (uint32_t a = 0; a < m; ++a) for (uint32_t b = 0; b < m; ++b) if (!isfinite(H[a][b])) return -1;
   /* Cholesky of H_tt, then the Schur complement onto beta */
-  double Lt[6][6], Y[6][MCPO_MAX_P];
+  double Lt[12][12], Y[12][MCPO_MAX_P];
   for (uint32_t j = 0; j < mt; ++j) {
     double dj = H[j][j];
     for (uint32_t k = 0; k < j; ++k) dj -= Lt[j][k] * Lt[j][k];
@@ -497,7 +497,7 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
   if (!cl->present || cl->slopes.n_slopes > 2) return MCP_ERR_UNSUPPORTED;
   /* extra groupings couple the clusters: fit_glmm_general.c (oracle only; "rx" SE, Laplace) */
   const int general = cl->n_extra_groupings != 0;
-  if (general && (spec->wald_se == MCP_WALD_SE_HESSIAN || spec->nagq > 1)) return MCP_ERR_UNSUPPORTED;
+  if (general && spec->nagq > 1) return MCP_ERR_UNSUPPORTED;
   const uint32_t q = 1 + cl->slopes.n_slopes;
   uint32_t nth = q * (q + 1) / 2;
   for (uint32_t e = 0; e < cl->n_extra_groupings; ++e) nth += (1 + cl->extra[e].slopes.n_slopes) * (2 + cl->extra[e].slopes.n_slopes) / 2;
@@ -570,7 +570,7 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
       const double* start = NULL;
       if (has_prev) start = carry_v;
       else if (spec->scenario.truth_start) { mcpo_truth_theta(cl, 1, tv); start = tv; }
-      rc = mcpo_glmm_general_fit_terms(fam, xfit, ws->y, n, max_n, p_fit, terms, 1 + cl->n_extra_groupings, start, beta0, &f);
+      rc = mcpo_glmm_general_fit_terms(fam, xfit, ws->y, n, max_n, p_fit, terms, 1 + cl->n_extra_groupings, start, beta0, mode, &f);
     } else if (q == 1) {
       rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, mode, &f);
     } else {

@@ -208,9 +208,15 @@ static double gg_nelder_mead(gg_model* m, double* x0, double step, double ftol, 
   return fv[lo];
 }
 
+static double gg_dev_cb(void* ctx, double* par) {
+  uint32_t scratch = 0;
+  return gg_f((gg_model*)ctx, par, &scratch);
+}
+
+/* mode: MCPO_MODE_HESSIAN selects the finite-difference Hessian Wald covariance (fit_glmm.c); singular fits keep "rx" */
 int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                 const mcpo_re_term* terms, uint32_t n_terms, const double* theta0, const double* beta0,
-                                mcpo_gen_fit* f) {
+                                uint32_t mode, mcpo_gen_fit* f) {
   if (p > MCPO_MAX_P || n_terms == 0 || n_terms > GG_MAX_TERMS) return MCP_ERR_UNSUPPORTED;
   gg_model m;
   memset(&m, 0, sizeof m);
@@ -305,6 +311,14 @@ int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_
       f->L[i * p + j] = v / f->L[j * p + j];
     }
   }
+  int singular = 0;
+  for (uint32_t k = 0; k < m.nth; ++k) if (m.is_diag[k] && par[k] < GG_THETA_ZERO) singular = 1;
+  if (ok && (mode & MCPO_MODE_HESSIAN) && !singular) {
+    uint8_t th_free[12];
+    for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = 1;
+    double lh[MCPO_MAX_P * MCPO_MAX_P];
+    if (mcpo_fd_hessian_factor(gg_dev_cb, &m, par, m.nth, p, th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
+  }
   f->converged = ok;
   uint32_t comp = 0;
   for (uint32_t k = 0; k < m.nth; ++k) {
@@ -323,7 +337,8 @@ int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_
 int mcpo_glmm_general_fit(int family, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, uint32_t n_terms,
                           const uint32_t* term_q, const uint32_t* term_levels, const uint32_t* ids, const uint32_t* slope_cols,
                           const double* theta_start, const double* beta_start, double* beta, double* se, double* theta_hat,
-                          double* vars_out, uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval) {
+                          double* vars_out, uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval,
+                          uint32_t mode) {
   if (n_terms == 0 || n_terms > GG_MAX_TERMS) return MCP_ERR_UNSUPPORTED;
   mcpo_re_term terms[GG_MAX_TERMS];
   for (uint32_t t = 0; t < n_terms; ++t) {
@@ -332,7 +347,7 @@ int mcpo_glmm_general_fit(int family, const float* x, const float* y, uint32_t n
     for (uint32_t d = 0; d < MCP_MAX_RE_SLOPES; ++d) terms[t].cols[d] = slope_cols[t * MCP_MAX_RE_SLOPES + d];
   }
   mcpo_gen_fit f;
-  int rc = mcpo_glmm_general_fit_terms(family, x, y, n, ld, p, terms, n_terms, theta_start, beta_start, &f);
+  int rc = mcpo_glmm_general_fit_terms(family, x, y, n, ld, p, terms, n_terms, theta_start, beta_start, mode, &f);
   if (rc) return rc;
   *converged = (uint8_t)f.converged; *boundary_hit = f.boundary_hit; *pinned = f.pinned; *n_eval = f.n_eval;
   memcpy(theta_hat, f.theta, sizeof(double) * f.n_theta);

@@ -109,7 +109,8 @@ void mcpo_gh_rule(uint32_t k, double* z, double* w);
 int mcpo_glmm_general_fit(int family, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, uint32_t n_terms,
                           const uint32_t* term_q, const uint32_t* term_levels, const uint32_t* ids, const uint32_t* slope_cols,
                           const double* theta_start, const double* beta_start, double* beta, double* se, double* theta_hat,
-                          double* vars_out, uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval);
+                          double* vars_out, uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval,
+                          uint32_t mode);
 
 /* ---- GLMM with random slopes on the primary grouping (fit_glmm_slopes.c): q = 1 + slopes <= 3 ---- */
 int mcpo_glmm_slopes_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,

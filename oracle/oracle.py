@@ -285,7 +285,7 @@ def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, s
 
 
 def glmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, slope_cols, family: str = "logit",
-                     theta_start=None, beta_start=None):
+                     theta_start=None, beta_start=None, wald_se: str = "rx"):
     """GLMM (Laplace, "rx" SE) with any carried random-effect structure on provided bytes; arguments as lmm_general_fit."""
     n, p = design.shape
     x = np.ascontiguousarray(design.T, dtype=np.float32)
@@ -310,7 +310,8 @@ def glmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, 
                                      cols.ctypes.data_as(pu), None if t0 is None else t0.ctypes.data_as(pd),
                                      None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
                                      se.ctypes.data_as(pd), theta.ctypes.data_as(pd), vars_out.ctypes.data_as(pd),
-                                     C.byref(conv), C.byref(bh), C.byref(pinned), C.byref(ne))
+                                     C.byref(conv), C.byref(bh), C.byref(pinned), C.byref(ne),
+                                     C.c_uint32(1 if wald_se == "hessian" else 0))
     _check(rc)
     return dict(beta=beta, se=se, theta=theta[:n_theta], cov=vars_out, converged=bool(conv.value), boundary_hit=bh.value,
                 pinned=pinned.value, n_eval=ne.value)

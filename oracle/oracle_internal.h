@@ -68,7 +68,7 @@ int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* i
 void mcpo_gh_rule(uint32_t k, double* z, double* w);
 int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                 const mcpo_re_term* terms, uint32_t n_terms, const double* theta0, const double* beta0,
-                                mcpo_gen_fit* f);
+                                uint32_t mode, mcpo_gen_fit* f);
 typedef double (*mcpo_dev_fn)(void* ctx, double* par);
 int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t nth, uint32_t p, const uint8_t* theta_free,
                            double fx, double* l_out);

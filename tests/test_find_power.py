@@ -446,6 +446,31 @@ def test_find_power_clustered_glm_with_a_random_slope_device_equals_oracle(engin
     assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 2.0 / 96 + 1e-12
 
 
+def _glmm_crossed_contract():
+    c = _glmm_slope_contract()
+    c["generation"]["cluster"]["extra_groupings"] = [{"relation": {"Crossed": {"n_clusters": 5}}, "tau_squared": 0.16, "slopes": []}]
+    return c
+
+
+def test_find_power_clustered_glm_with_a_crossed_grouping_on_the_oracle(oracle):
+    """(1 + x1 | g) + (1 | item) under a binary outcome: the contract reaches the joint-mode Laplace fit."""
+    r = _engine.find_power(_pack(_glmm_crossed_contract()), 400, 12, 2137, None, _runner=_oracle_runner(oracle))
+    sc = r["scenarios"]["optimistic"] if "scenarios" in r else r
+    assert sc["n_sims"] == 12 and sc["convergence_rate"][0] > 0.7 and 0.2 < sc["power_uncorrected"][0][0] <= 1.0
+
+
+@pytest.mark.gpu
+def test_find_power_clustered_glm_with_a_crossed_grouping_device_equals_oracle(engine, oracle):
+    blob = _pack(_glmm_crossed_contract())
+    dev = _engine.find_power(blob, 400, 48, 2137, None)
+    ora = _engine.find_power(blob, 400, 48, 2137, None, _runner=_oracle_runner(oracle))
+    d = dev["scenarios"]["optimistic"] if "scenarios" in dev else dev
+    o = ora["scenarios"]["optimistic"] if "scenarios" in ora else ora
+    for t in range(2):
+        assert abs(d["power_uncorrected"][0][t] - o["power_uncorrected"][0][t]) <= 2.0 / 48 + 1e-12
+    assert abs(d["convergence_rate"][0] - o["convergence_rate"][0]) <= 2.0 / 48 + 1e-12
+
+
 def test_clustered_glm_opt_in_modes_are_refused_not_approximated():
     c = _glmm_contract()
     c["nagq"] = 7              # quadrature over a scalar random intercept lowers to spec.nagq ...

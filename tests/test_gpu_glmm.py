@@ -75,7 +75,7 @@ def test_glmm_two_predictors_fixed_size_clusters_counters_and_shards(engine, ora
 def test_glmm_refuses_what_it_cannot_do(engine):
     spec, _, a, low = load_case("glmm_intercept")
     spec.cluster.extra_groupings = [{"relation": {"Crossed": {"n_clusters": 8}}, "tau_squared": 0.2, "slopes": []}]
-    spec.wald_se = S.WaldSe.Hessian
+    spec.nagq = 5
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(spec, [600], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "extra groupings" in str(e.value)
@@ -144,6 +144,30 @@ def test_glmm_extra_groupings_two_predictors_test_formula_and_counts(engine, ora
     ora = oracle.run_batch(spec, [480], 12, BASE_SEED, n_threads=8, stat_capture=True)
     assert dev.converged.mean() > 0.7
     _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
+
+
+def test_glmm_extra_groupings_hessian_wald_se(engine, oracle):
+    """Wald SE mode "hessian" through the joint-mode kernel: interior fits get the larger, Hessian-based SE; singular
+    fits keep "rx" (vcov.merMod's fallback); statistics against the oracle at the stencil's amplification (2e-3)."""
+    spec, _, a, low = load_case("glmm_slope_crossed")
+    spec.cluster.tau_squared = 1.2
+    spec.cluster.slopes = [{"column": 0, "variance": 0.6, "corr_with_intercept": 0.2, "corr_with": []}]
+    spec.cluster.extra_groupings[0]["tau_squared"] = 0.5
+    spec.scenario.truth_start = True
+    rx, stat_rx = engine.run_batch_st_capture(spec, [480], 16, BASE_SEED)
+    spec.wald_se = S.WaldSe.Hessian
+    dev, stat = engine.run_batch_st_capture(spec, [480], 16, BASE_SEED)
+    ora = oracle.run_batch(spec, [480], 16, BASE_SEED, n_threads=8, stat_capture=True)
+    same = ((dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+            & (dev.pinned_components == ora.pinned_components).all(axis=1))
+    assert same.sum() >= 14
+    ok = same & (dev.converged[:, 0] == 1)
+    assert np.allclose(stat[ok], ora.stat_capture[ok], rtol=2e-3)
+    assert np.array_equal(dev.converged, rx.converged) and np.array_equal(dev.pinned_components, rx.pinned_components)
+    interior = ok & (dev.pinned_components[:, 0] == 0)
+    assert interior.sum() >= 4 and np.all(stat[interior] < stat_rx[interior])
+    singular = ok & (dev.pinned_components[:, 0] != 0)
+    assert np.array_equal(stat[singular], stat_rx[singular])
 
 
 def test_glmm_extra_groupings_reference_capture_and_grid(engine, oracle):

@@ -300,3 +300,17 @@ def test_glmm_arm_with_extra_groupings_run_batch(oracle):
     if f["converged"]:
         assert np.isclose((f["beta"][1] / f["se"][1]) ** 2, r.stat_capture[0, 0], rtol=1e-10)
         assert f["pinned"] == r.pinned_components[0, 0] and np.isclose(f["theta"][0] ** 2, r.tau_squared_hat[0, 0])
+
+
+def test_general_fit_hessian_mode_interior_and_singular(oracle):
+    """Hessian SE through the joint-mode oracle: on a single grouping it equals the per-cluster fit's Hessian SE; the
+    singular reference fits keep "rx"."""
+    spec, _, a, low = load_case("glmm_multislope")
+    v = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], [1, 2], family="logit", wald_se="hessian")
+    g = oracle.glmm_general_fit(a["design"], a["outcome"], [a["cluster_ids"]], [3], [[1, 2]], family="logit", wald_se="hessian")
+    assert np.allclose(g["se"], v["se"], rtol=2e-4) and np.all(np.abs(g["beta"] / g["se"] / a["golden_z"] - 1.0) < 0.01)
+    spec, _, a, low = load_case("glmm_slope_crossed")
+    ids, q, cols = _glmm_terms(spec, a)
+    rx = oracle.glmm_general_fit(a["design"], a["outcome"], ids, q, cols, family="logit")
+    he = oracle.glmm_general_fit(a["design"], a["outcome"], ids, q, cols, family="logit", wald_se="hessian")
+    assert rx["pinned"] != 0 and np.array_equal(rx["se"], he["se"])
