@@ -136,7 +136,7 @@ def main():
     if args.workload.startswith("c5_"):
         spec.scenario = helpers.preset(args.workload[3:])
         ns = helpers.C5_GRID
-    S = args.sims_per_gpu or ({"c3": 1_000_000, "c4": 1_000_000, "lmm_slope": 40_000, "lmm_crossed": 40_000, "glmm": 40_000, "glmm_slope": 16_000, "glmm_crossed": 4_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
+    S = args.sims_per_gpu or ({"c3": 100_000, "c4": 10_000, "lmm_slope": 40_000, "lmm_crossed": 40_000, "glmm": 40_000, "glmm_slope": 16_000, "glmm_crossed": 4_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
     staged = args.pipeline == "staged"
 
     def barrier():
