@@ -367,8 +367,8 @@ def report_targets_and_contrasts(c: dict):
 def contract_to_simulation_spec(c: dict) -> S.SimulationSpec:
     """`contract_to_simulation_spec` (contract_adapter.rs:74-230)."""
     validate_contract(c)
-    # wald_se / nagq only steer the clustered-GLM estimator (estimator.rs:58-66).  The device fits it by the Laplace
-    # approximation with either Wald SE mode; quadrature is refused, not approximated.
+    # wald_se / nagq only steer the clustered-GLM estimator (estimator.rs:58-66).  The device serves both Wald SE modes
+    # and quadrature over a scalar random intercept; quadrature over slopes is refused, not approximated.
     wald_se = S.WaldSe.Rx
     if c.get("estimator") == "glm" and c["generation"].get("cluster") is not None:
         if int(c.get("nagq", 1)) != 1 and (c["generation"]["cluster"].get("slopes") or []):
