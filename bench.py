@@ -10,7 +10,10 @@ per GPU at BASELINE.json configs[1] (OLS, n=200, p=5: x1,x2,x3 + x1:x2; C2a in B
 data generated in-kernel from Philox (there are no input tensors; the launch-constant block is
 resident in HBM before the timed region).  Replicates shard by sim_id range with the same
 base_seed (weak scaling: per-GPU work is fixed) and every step ends with the path's single
-collective: one all-reduce (sum) of the rejection counters over RCCL.
+collective: one all-reduce (sum) of the rejection counters over RCCL -- issued INSIDE the C-ABI call
+(`MCP_ALLREDUCE_COUNTERS`: ncclAllReduce on the device-resident vector, on the launch stream, before
+the call's one device-to-host copy).  torch.distributed is the control plane only (rendezvous of the
+128-byte communicator id, barriers, the max over ranks of the elapsed time).
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` for the dominant
 kernel of the timed region, `roofline_staged_fit` for the HBM-bound staged fit kernel, and
@@ -26,7 +29,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # chip constants: /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec; ~6300 GB/s measured achievable
@@ -64,6 +66,12 @@ WORKLOADS = {
 }
 
 
+# the same algorithmic counts with an f64 multiply-add taken as ONE lane-op (the convention of PEAK_VALU_TOPS, where a
+# v_fma is one issue slot): C2a 200 Philox calls x 50 + 800 inverse CDFs x 22 + 5 000 MAC = 3.26e4; C2b 300 x 50 +
+# 1 200 x 22 + 5 600 = 4.70e4
+OPS_FMA_AS_ONE = {"c2a": 3.26e4, "c2b": 4.70e4}
+
+
 def pmc_traffic(workload, kernel_tag):
     """HBM bytes per launch of `kernel_tag` from the newest committed rocprofv3 PMC summary (profiles/*_pmc.csv,
     collected in separate --pmc passes by tools/profile_bench.sh).  gfx950 correction from
@@ -97,16 +105,19 @@ def main():
     ap.add_argument("--pipeline", default="fused", choices=["fused", "staged"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend; gloo only to rehearse the N>1 logic with several ranks on one GPU")
+    ap.add_argument("--backend", default="capi", choices=["capi", "nccl", "gloo"],
+                    help="capi (default): the collective runs inside the C ABI on RCCL, torch.distributed (gloo) is "
+                         "the control plane; nccl: host counter blocks pooled through torch's RCCL process group "
+                         "(the round-1 path); gloo: the same through gloo, to rehearse N>1 with several ranks on one GPU")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight per rank (1..4)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
-    import helpers
     from mcpower_amd import dist as mdist
     from mcpower_amd import engine
+    from mcpower_amd import workloads as helpers
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -115,19 +126,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if engine.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    dev_index = local_rank if args.backend == "nccl" else local_rank % engine.device_count()
+    dev_index = local_rank if args.backend != "gloo" else local_rank % engine.device_count()
     torch.cuda.set_device(dev_index)
     engine.set_device(dev_index)
+    capi = args.backend == "capi" and world > 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":  # RCCL over xGMI
+        if args.backend == "nccl":  # host blocks through torch's RCCL process group
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
+        else:                       # control plane only
             dist.init_process_group(backend="gloo")
-        # bring the communicator up before anything is timed (the first RCCL collective builds the rings over xGMI),
-        # whatever --warmup says
-        t_init = torch.zeros(1, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t_init)
+        if capi:
+            # the product's communicator: rank 0 creates the id, gloo carries it, every rank joins; mcp_comm_init
+            # returns after a one-word all-reduce has crossed the rings, so nothing of the bring-up is timed
+            mdist.init_comm(rank, world)
+        else:
+            t_init = torch.zeros(1, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t_init)
         dist.barrier()
 
     fac, n_obs, ops_per_fit, bytes_per_fit = WORKLOADS[args.workload]
@@ -149,35 +164,59 @@ def main():
     def submit(i):
         # weak scaling: every rank simulates S new replicates per step; ids never repeat across steps
         off = (i * world + rank) * S
-        return engine.submit_batch(lowered, ns, S, helpers.BASE_SEED, sim_offset=off, staged=staged)
+        return engine.submit_batch(lowered, ns, S, helpers.BASE_SEED, sim_offset=off, staged=staged, allreduce=capi)
+
+    depth = max(1, min(int(args.depth), 4))
 
     def run_steps(first, count):
-        """`count` steps, software-pipelined two deep: batch i+1 is enqueued (its host-side lowering and upload
-        hide behind batch i's kernel) before batch i is collected, and the all-reduce of batch i's counters is
-        collected one step later still.  Every batch and every collective completes before this returns."""
-        acc = dict(kernel_ms=0.0, aux_ms=0.0, launches=0, pooled_sims=0.0, pooled=None, last=None)
+        """`count` steps, software-pipelined `depth` deep: up to `depth` batches are in flight, each on its own stream
+        (the host-side lowering and upload of batch i+1 hide behind batch i's kernel, and the partly filled last round
+        of batch i's workgroups shares the chip with the head of batch i+1).  With the C-ABI communicator the
+        all-reduce of a batch's counters is part of that batch's stream; otherwise the host blocks are pooled one step
+        later through the torch process group.  Every batch and every collective completes before this returns."""
+        acc = dict(kernel_ms=0.0, aux_ms=0.0, launches=0, pooled_sims=0.0, pooled=None, last=None, spans=[])
         if count <= 0:
             return acc
 
         def absorb(pend):
-            acc["pooled"] = pend.wait()
+            acc["pooled"] = pend.wait() if hasattr(pend, "wait") else pend
             acc["pooled_sims"] += float(acc["pooled"][0, acc["last"].layout["n_sims"]])
 
-        ticket = submit(first)
+        tickets = [submit(first + j) for j in range(min(depth, count))]
+        issued = len(tickets)
         reduce_in_flight = None
         for i in range(count):
-            nxt = submit(first + i + 1) if i + 1 < count else None
-            r = ticket.collect()
+            r = tickets.pop(0).collect()
+            if issued < count:
+                tickets.append(submit(first + issued))
+                issued += 1
             acc["last"] = r
             acc["kernel_ms"] += r.kernel_ms
             acc["aux_ms"] += r.aux_kernel_ms
             acc["launches"] += r.n_kernel_launches
-            if reduce_in_flight is not None:
-                absorb(reduce_in_flight)
-            reduce_in_flight = mdist.allreduce_counters_async(r.counters)
-            ticket = nxt
-        absorb(reduce_in_flight)
+            acc["spans"].append((r.kernel_begin_ms, r.kernel_end_ms))
+            if capi or world == 1:
+                absorb(r.counters)  # already pooled on the device (or there is nothing to pool)
+            else:
+                if reduce_in_flight is not None:
+                    absorb(reduce_in_flight)
+                reduce_in_flight = mdist.allreduce_counters_async(r.counters)
+        if reduce_in_flight is not None:
+            absorb(reduce_in_flight)
         return acc
+
+    def busy_ms(spans):
+        """Union of the dominant-kernel intervals: batches in flight overlap on the device, so the kernel-busy time of
+        the region is not the sum of the per-launch durations."""
+        total, cur_b, cur_e = 0.0, None, None
+        for b, e in sorted(spans):
+            if cur_e is None or b > cur_e:
+                if cur_e is not None:
+                    total += cur_e - cur_b
+                cur_b, cur_e = b, e
+            else:
+                cur_e = max(cur_e, e)
+        return total + ((cur_e - cur_b) if cur_e is not None else 0.0)
 
     run_steps(0, args.warmup)
     barrier()
@@ -199,7 +238,9 @@ def main():
         nt = spec.n_targets
         k_unc = pooled[0, r.layout["k_unc"]:r.layout["k_unc"] + nt].astype(np.float64)
         n_pool = float(pooled[0, r.layout["n_sims"]])
-        avg_launch_ms = kernel_ms / max(launches, 1)          # HIP events on the launch stream (host_api.hip)
+        avg_launch_ms = kernel_ms / max(launches, 1)          # HIP events on each launch's stream (host_api.hip)
+        kernel_busy_ms = busy_ms(acc["spans"])                # union of those intervals over the timed region
+        concurrency = kernel_ms / kernel_busy_ms if kernel_busy_ms > 0 else 1.0
         fits_per_launch = S / max(launches / args.steps, 1)
         out = {
             "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
@@ -209,23 +250,35 @@ def main():
                                    f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'glmm_slope': 'logit, Laplace, (1 + x1 | g), 30 clusters x 20', 'glmm_crossed': 'logit, Laplace, (1 + x1 | g) + (1 | item), 24 x 6 levels', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
-                       "collective": "1 all-reduce(sum) of counters per step"},
+                       "collective": ("1 ncclAllReduce(sum, uint64) of the device-resident counters per step, inside the C ABI"
+                                      if capi or world == 1 else f"1 all-reduce(sum) of host counter blocks per step via torch ({args.backend})"),
+                       "batches_in_flight": depth},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),
         }
         is_ols = args.workload not in ("c3", "c4", "lmm_slope", "lmm_crossed", "glmm", "glmm_slope", "glmm_crossed")
         is_c5 = args.workload.startswith("c5_")
         if not staged:
             fits_per_launch *= len(ns)  # a replicate on a grid is len(ns) prefix fits (throughput.rs:1111-1113)
-            ach = ops_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e12
+            # launches overlap (depth > 1: each batch on its own stream), so the rate of the kernel over the timed region
+            # is work / kernel-busy time = per-launch work x mean concurrency / average launch duration
+            ach = ops_per_fit * fits_per_launch * concurrency / (avg_launch_ms * 1e-3) / 1e12
+            ops_1op = OPS_FMA_AS_ONE.get(args.workload)
             out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"glmm_slopes_kernel<{spec.n_predictors},2>" if args.workload == "glmm_slope" else f"glmm_general_kernel<{spec.n_predictors}>" if args.workload == "glmm_crossed" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
+                               "frac_fma_as_one_op": (ops_1op / ops_per_fit * ach / PEAK_VALU_TOPS) if ops_1op else None,
+                               "ops_per_fit_fma_as_one_op": ops_1op,
+                               "kernel_busy_ms": kernel_busy_ms, "mean_concurrent_launches": concurrency,
                                "traffic": (pmc_traffic(args.workload, f"ols_sim_kernel<{spec.n_predictors}, 0,")
                                            if (is_ols and not is_c5 and S == 1_000_000) else None),
                                "ops_per_fit": ops_per_fit, "avg_launch_ms": avg_launch_ms,
                                "fits_per_launch": fits_per_launch,
                                "note": "fused generate+fit: no design bytes touch HBM; bound is VALU/integer issue "
-                                       "(SURVEY.md 8d); HBM-equivalent rate in hbm_equiv_gbs",
-                               "hbm_equiv_gbs": bytes_per_fit * fits_per_launch / (avg_launch_ms * 1e-3) / 1e9}
+                                       "(SURVEY.md 8d); achieved = ops_per_fit x fits_per_launch x mean_concurrent_launches "
+                                       "/ avg_launch_ms (launches of batches in flight overlap; avg_launch_ms is the per-launch "
+                                       "HIP-event duration rocprofv3 --kernel-trace also reports); ops_per_fit counts an f64 MAC "
+                                       "as 2 ops, frac_fma_as_one_op counts it as 1 like the lane-op peak does; "
+                                       "HBM-equivalent rate in hbm_equiv_gbs",
+                               "hbm_equiv_gbs": bytes_per_fit * fits_per_launch * concurrency / (avg_launch_ms * 1e-3) / 1e9}
         if not staged and is_ols and not is_c5 and spec.n_predictors <= 8:  # the staged pipeline serves the register-resident kernels
             # the HBM-bound kernel of the path: staged fit over a resident design tile (measured outside the timed region)
             rs = engine.run_batch(spec, ns, S, helpers.BASE_SEED, per_sim=False, staged=True)
@@ -249,7 +302,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             # the CPU oracle ("port"): same spec, same seeds, on this host's cores, bounded sample
             from oracle import oracle
-            cores = max(1, min(os.cpu_count() or 1, 16))
+            flags = oracle.use_native_build()  # -O3 -march=native, built here on the timing host
+            # the GPU box hands a one-GPU job a 16-core share of its host (os.cpu_count() reports the whole machine:
+            # 256 threads oversubscribing 16 cores ran 30 % slower than 16)
+            cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
             probe = 50_000 if is_ols else 2_000  # iterative fits run 1e2..1e4 per second: keep the probe in seconds
             t1 = time.perf_counter()
             oracle.run_batch(spec, ns, probe, helpers.BASE_SEED, n_threads=cores)
@@ -260,6 +316,7 @@ def main():
             dt = time.perf_counter() - t1
             g = engine.run_batch(spec, ns, sample, helpers.BASE_SEED, per_sim=False)
             out["cpu_baseline"] = {"value": sample / dt, "unit": "fits/s", "cores": cores, "kind": "port",
+                                   "compiler_flags": "gcc " + flags,
                                    "sample": f"{sample} replicates of the same workload (sim_id 0..{sample - 1}), "
                                              f"oracle/ C restatement, {cores} pthreads, {dt:.1f} s",
                                    "power_delta_pp_vs_gpu": float(np.max(np.abs(
@@ -267,6 +324,8 @@ def main():
                                        / sample * 100.0)}
         print(json.dumps(out))
     if world > 1:
+        if capi:
+            engine.comm_destroy()
         dist.destroy_process_group()
 
 

@@ -26,6 +26,9 @@
  *   ProgressSink::report / is_cancelled             spec.rs:38-52             mcp_progress_fn
  *   aggregate_batch counters (what a multi-GPU      orchestrator/src/
  *     merge pools)                                  aggregation.rs:61-330     mcp_counter_layout + counters[]
+ *   merge_power_results (pool per-worker counters   orchestrator/src/         mcp_comm_unique_id / mcp_comm_init /
+ *     on the host; here: one RCCL all-reduce of     merge.rs:26-70            mcp_comm_destroy + MCP_ALLREDUCE_COUNTERS,
+ *     the device-resident counter vector)                                     mcp_shard_range
  *   introspect::capture_sim0_data (debug: the       introspect.rs:104         mcp_generate_design
  *     generated design/outcome of chosen sims)
  *   introspect::fit_provided_data (debug: fit       introspect.rs:174         mcp_fit_design
@@ -52,7 +55,7 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 2u
+#define MCP_ABI_VERSION 3u
 
 /* ---- status codes (EngineError, spec.rs:20-29) --------------------------- */
 typedef enum mcp_status {
@@ -272,6 +275,10 @@ typedef struct mcp_batch_result {
   double aux_kernel_ms;        /* staged pipeline: generator kernel, summed over launches; 0 otherwise */
   uint32_t n_kernel_launches;
   uint32_t _pad;
+  /* when the first dominant-kernel launch of the call began and the last one ended, in ms since this host thread's
+   * first call: batches in flight overlap on the device (mcp_run_batch_submit), so a caller that wants the kernel-busy
+   * time of a region takes the union of these intervals instead of adding kernel_ms */
+  double kernel_begin_ms, kernel_end_ms;
 } mcp_batch_result;
 
 /* progress / cancel: ProgressSink::report(current,total)->bool (spec.rs:41);
@@ -282,6 +289,13 @@ typedef int (*mcp_progress_fn)(uint64_t current, uint64_t total, void* user);
 #define MCP_WANT_PER_SIM      0x1u   /* fill the sim-major u8 tensors (BatchResult parity) */
 #define MCP_WANT_STAT_CAPTURE 0x2u   /* run_batch_st_capture (batch.rs:180) */
 #define MCP_PIPELINE_STAGED   0x4u   /* generator -> HBM design -> fit kernels instead of the fused kernel */
+#define MCP_ALLREDUCE_COUNTERS 0x8u  /* pool `counters` over the ranks of this process's communicator: one
+                                        ncclAllReduce(sum, uint64) of the device-resident vector on the launch stream,
+                                        before the call's single device-to-host copy (merge.rs:26-70).  Every rank of
+                                        the communicator must make the same call (same spec, sample sizes and flags;
+                                        its own sim_offset / n_sims shard).  Per-sim tensors stay local.  A progress
+                                        callback that cancels on ANY rank cancels the call on EVERY rank: the verdict
+                                        rides in the reduced payload, so all ranks leave the collective together */
 
 typedef struct mcp_run_options {
   uint32_t flags;
@@ -319,12 +333,39 @@ void mcp_free_result(mcp_batch_result* r);
  * `submit` validates, lowers and enqueues the whole batch on the launch stream and returns at once with a
  * ticket; `collect` waits for that batch and fills `*out` (counters, layout, shape, timings -- the reduced
  * form: MCP_WANT_PER_SIM / MCP_WANT_STAT_CAPTURE are rejected, there is no progress callback).  Up to four
- * batches may be in flight per host thread; they execute in submission order on one stream, so the host-side
- * work of batch i+1 hides behind the kernels of batch i.  A ticket is collected exactly once, on the thread
+ * batches may be in flight per host thread, each on a stream of its own: the host-side work of batch i+1 hides
+ * behind the kernels of batch i, and the partly filled last round of batch i's workgroups shares the chip with the
+ * first round of batch i+1 (pass opts->hip_stream to force one in-order stream).  Results do not depend on the
+ * order (every batch owns its buffers).  A ticket is collected exactly once, on the thread
  * that submitted it; the result is released with mcp_free_result. */
 int mcp_run_batch_submit(const mcp_spec* spec, const uint32_t* sample_sizes, uint32_t n_sample_sizes,
                          uint32_t n_sims, uint64_t base_seed, const mcp_run_options* opts, uint64_t* ticket_out);
 int mcp_run_batch_collect(uint64_t ticket, mcp_batch_result* out);
+
+/* ---- multi-GPU: one process per GPU, ONE collective -------------------------------------------------------------
+ * The reference pools per-worker counters on the host (merge_power_results, orchestrator/src/merge.rs:26-70; browser
+ * worker pool ports/wasm/src/seeds.ts:98-103).  Here each process owns one MI355X; rank r of W simulates the replicate
+ * slice mcp_shard_range gives it under the SAME base_seed (union bit-identical to a one-GPU run) and the counters are
+ * summed by RCCL over xGMI while still in HBM.  Bring-up, once per process:
+ *   rank 0:  mcp_comm_unique_id(&id);  ...host broadcasts the 128 bytes over its own channel...
+ *   all:     mcp_set_device(local_rank);  mcp_comm_init(rank, world, &id);          (collective)
+ *   per run: mcp_run_batch[_submit](..., opts.flags |= MCP_ALLREDUCE_COUNTERS, opts.sim_offset / n_sims = the shard)
+ *   end:     mcp_comm_destroy();                                                    (collective)
+ * RCCL is bound at the first of these calls (librccl.so.1); a process that never calls them never loads it. */
+#define MCP_COMM_ID_BYTES 128u
+typedef struct mcp_comm_id { uint8_t bytes[MCP_COMM_ID_BYTES]; } mcp_comm_id;   /* an ncclUniqueId, verbatim */
+
+/* Create the rendezvous id of a new communicator (rank 0 only).  Needs the device: MCP_ERR_DEVICE without one. */
+int mcp_comm_unique_id(mcp_comm_id* id_out);
+/* Join the communicator as `rank` of `world` on the device chosen with mcp_set_device; returns once every rank has
+ * joined and a one-word all-reduce has crossed the rings.  One communicator per process. */
+int mcp_comm_init(int rank, int world, const mcp_comm_id* id);
+/* Leave and free the communicator (waits for the device first).  No-op without one. */
+int mcp_comm_destroy(void);
+int mcp_comm_rank(void);    /* -1 without a communicator */
+int mcp_comm_world(void);   /*  0 without a communicator */
+/* The sharding rule: rank r of W owns sim_ids [r*S/W, (r+1)*S/W) of a run of S replicates (host-only arithmetic). */
+int mcp_shard_range(uint64_t n_sims_total, int rank, int world, uint64_t* offset_out, uint64_t* count_out);
 
 /* Host-only part of run_batch (no device): validation (batch.rs:208-330) and
  * the critical-value table (critvals.rs:827-1012).  `crit_out` receives, per

@@ -261,18 +261,38 @@ def sharded_runner(rank: int, world: int, group=None, run_batch=None):
     """Runner for `find_power` / `find_sample_size` when one process drives one GPU: this rank simulates its
     contiguous slice of the replicates (same base seed, so the union is the single-device run), one all-reduce pools
     the counters, and every rank aggregates the same pooled block -- identical results on all ranks.
-    Usage: `find_power(blob, n, n_sims, seed, _runner=sharded_runner(rank, world))` on every rank."""
+    Usage: `find_power(blob, n, n_sims, seed, _runner=sharded_runner(rank, world))` on every rank.
+
+    With a C-ABI communicator of this world (`mcpower_amd.dist.init_comm`) the collective runs inside `run_batch`
+    on the device-resident counters, and a cancelling progress callback on any rank cancels every rank (the verdict
+    rides in the reduced payload).  Without one (gloo rehearsals, `run_batch=` stand-ins) the host blocks are pooled
+    through the torch process group; there only rank 0 drives the progress sink and its verdict is agreed on with a
+    one-word all-reduce ahead of the block's, so no rank is left waiting in a collective."""
     def run(spec, sample_sizes, n_sims, base_seed, sink):
         from . import dist as mdist
-        if run_batch is None:
-            from . import engine
-            call = lambda cnt, off: engine.run_batch(spec, sample_sizes, cnt, base_seed, sink, per_sim=False, sim_offset=off)
-        else:
-            call = lambda cnt, off: run_batch(spec, sample_sizes, cnt, base_seed, off)
+        from . import engine
         off, cnt = mdist.shard_range(int(n_sims), rank, world)
-        local = call(cnt, off)
+        if run_batch is None and engine.comm_world() == world and world > 1:
+            local = engine.run_batch(spec, sample_sizes, cnt, base_seed, sink, per_sim=False, sim_offset=off, allreduce=True)
+        else:
+            my_sink = sink if rank == 0 else None
+            cancelled = 0
+            try:
+                if run_batch is None:
+                    local = engine.run_batch(spec, sample_sizes, cnt, base_seed, my_sink, per_sim=False, sim_offset=off)
+                else:
+                    local = run_batch(spec, sample_sizes, cnt, base_seed, off)
+                block = local.counters
+            except S.EngineError as e:
+                if e.status != S.Status.Cancelled:
+                    raise
+                cancelled, local, block = 1, None, None
+            # agree on the verdict first (rank 0 may hold no block to contribute if its sink cancelled), then pool
+            verdict = mdist.allreduce_counters(np.array([cancelled], dtype=np.uint64), group)
+            if verdict[0] != 0:
+                raise S.EngineError(S.Status.Cancelled, "cancelled by host")
+            local.counters = mdist.allreduce_counters(block, group)
         local.uncorrected = None  # a runner handing back per-sim tensors of its shard must not be mistaken for the whole
-        local.counters = mdist.allreduce_counters(local.counters, group)
         local.shape.n_sims = int(n_sims)
         return local
     return run

@@ -310,7 +310,8 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
   gq_sync();
   double pd_prev = __builtin_inf(), dev = 0.0, logdet = 0.0, uu = 0.0;
   bool ok = true;
-  for (int it = 0; it < GLMM_PIRLS_ITERS; ++it) {
+  const int pirls_cap = (int)prm.glmm_pirls_cap;  // GLMM_PIRLS_ITERS unless the diagnostic knob lowered it
+  for (int it = 0; it < pirls_cap; ++it) {
     // ---- lane = row: weight, working residual, deviance at the current modes ----
     double devp = 0.0;
     for (uint32_t i = lane; i < n; i += QW) {
@@ -583,11 +584,6 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
   gq_sync();
   return best;
 }
-
-// SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
-// random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
-#include "mcp_glmm_hessian.hpp"
-
 
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 of every grouping (data_gen.rs:146-161, 1069-1092)
@@ -875,10 +871,21 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
 #pragma unroll
     for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = 0.0;
     for (uint32_t i = lane; i < n; i += QW) {
-      // the last Fisher step's weights: the modes did not move after it.  (Recomputing them here from m.u, as the
-      // oracle does, gave a covariance 20-40 % off on Count outcomes with the deviance and the optimum still exact:
-      // unexplained; this form is verified against the oracle on every family)
-      const double w = m.wrow[i];
+      // weights at the FINAL modes, as oracle/fit_glmm_general.c:275-287: equal to the last Fisher step's whenever the
+      // step loop ended on a convergence test (the modes did not move after that step); when it ran into its
+      // iteration cap the modes moved once more after the factor was formed, and the weights follow them
+      double au = 0.0;
+      for (uint32_t t = 0; t < nterms; ++t) {
+        double a[3];
+        const uint32_t l = gg_row_term<P>(prm, m, t, i, n_pad, a);
+        const gdd* ut = m.u + m.off[t] + l * prm.lmg_q[t];
+        au += a[0] * ut[0];
+        if (prm.lmg_q[t] > 1u) au += a[1] * ut[1];
+        if (prm.lmg_q[t] > 2u) au += a[2] * ut[2];
+      }
+      double w, wz, dv;
+      fam_eval(prm.glm_family, m.eta0[i] + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
+      m.wrow[i] = w;
       double xd[P];
       xd[0] = 1.0;
 #pragma unroll

@@ -51,6 +51,7 @@ hipError_t launch_lmm_general_scen(int P, int q0, const SimParams* d_prm, uint32
 size_t lmg_lds_bytes(const SimParams& prm);
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st);
+int comm_allreduce_u64(unsigned long long* d_words, size_t n, hipStream_t st, std::string& err);  // host_comm.cpp
 }  // namespace mcp
 
 namespace {
@@ -123,8 +124,9 @@ struct Arena {
   }
 };
 thread_local Arena g_arena;
-// batches in flight (mcp_run_batch_submit / _collect): each ticket owns an arena, all share g_arena's stream so
-// the kernels of successive batches run back to back, in order, and their event timings stay per kernel
+// batches in flight (mcp_run_batch_submit / _collect): each ticket owns an arena AND a stream, so the kernels of
+// successive batches may overlap at their edges (tail of one, head of the next); a caller-provided stream
+// (mcp_run_options.hip_stream) keeps them strictly in order instead
 constexpr int MAX_IN_FLIGHT = 4;
 struct Ticket {
   bool busy = false;
@@ -138,6 +140,7 @@ struct Ticket {
 };
 thread_local Ticket g_tickets[MAX_IN_FLIGHT];
 thread_local hipStream_t g_upload_stream = nullptr;  // a batch in flight uploads its tables beside the running kernel
+thread_local hipEvent_t g_epoch = nullptr;           // recorded once per host thread: origin of kernel_begin_ms / kernel_end_ms
 
 enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS, S_PINNED, S_TAU_HAT };
 
@@ -157,6 +160,12 @@ int ensure_device(hipStream_t* st, const mcp_run_options* opts, Arena* extra = n
   }
   if (opts && opts->hip_stream) {
     *st = (hipStream_t)opts->hip_stream;
+  } else if (extra) {
+    // a batch in flight launches on its ticket's own stream: the last, partly filled round of resident waves of batch i
+    // (a 10^6-replicate launch is 3.05 rounds of 1 280 workgroups) then shares the chip with the head of batch i + 1
+    // instead of running alone on a few CUs
+    if (!extra->stream) HIP_TRY(hipStreamCreateWithFlags(&extra->stream, hipStreamNonBlocking));
+    *st = extra->stream;
   } else {
     if (!g_arena.stream) HIP_TRY(hipStreamCreateWithFlags(&g_arena.stream, hipStreamNonBlocking));
     *st = g_arena.stream;
@@ -187,6 +196,39 @@ int mcp_set_device(int device_index) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MCP_ERR_DEVICE, "no HIP device visible");
   if (device_index < 0 || device_index >= n) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: device index out of range");
   g_device = device_index;
+  return MCP_OK;
+}
+
+int mcp_comm_unique_id(mcp_comm_id* id_out) {
+  if (!id_out) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null communicator id pointer");
+  std::string err;
+  const int rc = mcp::comm_unique_id(id_out, g_device, err);
+  return rc ? fail(rc, err) : MCP_OK;
+}
+
+int mcp_comm_init(int rank, int world, const mcp_comm_id* id) {
+  if (!id) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null communicator id pointer");
+  if (world < 1 || rank < 0 || rank >= world)
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: communicator rank must lie in [0, world) with world >= 1");
+  std::string err;
+  const int rc = mcp::comm_init(rank, world, id, g_device, err);
+  return rc ? fail(rc, err) : MCP_OK;
+}
+
+int mcp_comm_destroy(void) {
+  std::string err;
+  const int rc = mcp::comm_destroy(err);
+  return rc ? fail(rc, err) : MCP_OK;
+}
+
+int mcp_comm_rank(void) { return mcp::comm_rank(); }
+int mcp_comm_world(void) { return mcp::comm_world(); }
+
+int mcp_shard_range(uint64_t n_sims_total, int rank, int world, uint64_t* offset_out, uint64_t* count_out) {
+  if (!offset_out || !count_out) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null shard output pointer");
+  if (world < 1 || rank < 0 || rank >= world)
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: shard rank must lie in [0, world) with world >= 1");
+  mcp::shard_range(n_sims_total, (uint32_t)rank, (uint32_t)world, offset_out, count_out);
   return MCP_OK;
 }
 
@@ -249,6 +291,15 @@ int finish_timing(Arena& ar, hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t la
   out->kernel_ms = kernel_ms;
   out->aux_kernel_ms = aux_ms;
   out->n_kernel_launches = launched;
+  if (launched && g_epoch) {  // dominant kernel: the simulate / fused kernel, or the fit kernel of the staged pipeline
+    const size_t last = (size_t)(launched - 1) * ev_per_chunk;
+    hipEvent_t kb = staged ? ar.events[3] : ar.events[2];
+    hipEvent_t ke = staged ? ar.events[4 + last] : ar.events[3 + last];
+    HIP_TRY(hipEventElapsedTime(&ms, g_epoch, kb));
+    out->kernel_begin_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, g_epoch, ke));
+    out->kernel_end_ms = ms;
+  }
   return MCP_OK;
 }
 
@@ -269,6 +320,13 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   const uint32_t flags = opts ? opts->flags : (uint32_t)MCP_WANT_PER_SIM;
   const bool per_sim = flags & MCP_WANT_PER_SIM;
   const bool want_stat = flags & MCP_WANT_STAT_CAPTURE;
+  // pool the counters over the ranks of this process's communicator (merge.rs:26-70): checked before anything is
+  // enqueued, so a rank without a communicator fails here and not inside the collective
+  const bool pool = flags & MCP_ALLREDUCE_COUNTERS;
+  if (pool && !mcp::comm_active())
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: MCP_ALLREDUCE_COUNTERS without a communicator (call mcp_comm_init first)");
+  if (pool && mcp::comm_device() != g_device)
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: the communicator was created on another device than the one selected now");
   const bool mle = spec->estimator == MCP_EST_MLE;
   const bool glm = spec->estimator == MCP_EST_GLM || mle;  // wave-per-replicate kernels + flag fold
   const bool reduced = prm.red_active && !glm;             // reduced-design OLS kernel, flags folded afterwards
@@ -291,7 +349,11 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   out->n_variance_components = (spec->estimator == MCP_EST_MLE || (spec->estimator == MCP_EST_GLM && spec->cluster.present)) ? 1u : 0u;
   out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
-  if (n_sims == 0) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
+  if (n_sims == 0 && !pool) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
+  if (n_sims == 0) {  // an empty shard still owes the other ranks its (zero) contribution
+    mcp_free_result(out);
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: MCP_ALLREDUCE_COUNTERS needs n_sims > 0 on every rank (fewer replicates than ranks?)");
+  }
   const bool lmg = mle && prm.lmg_active;  // random slopes / extra groupings: the general mixed-model kernel
   const bool glmm = prm.glmm_active != 0u;  // clustered GLM: random-intercept GLMM kernel (writes flags like the Mle arm)
   const bool glmm_general = glmm && prm.lmg_active && prm.lmg_n_terms > 1u;  // ... with extra groupings: joint modes, dense system
@@ -377,7 +439,9 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   d_crit = (double*)(d_blob + off_crit);
   d_levels = d_blob + off_levels;
   const uint32_t n_ctr = n_ns * layout.stride;
-  const uint32_t copy_stride = (n_ctr + 15u) & ~15u;  // whole 128-byte lines per copy
+  // whole 128-byte lines per copy, and at least one spare word behind the counters: the reduced vector's word n_ctr
+  // carries the cancel verdict through the all-reduce (zero from the memset unless a rank's callback cancelled)
+  const uint32_t copy_stride = (n_ctr + 1u + 15u) & ~15u;
   const size_t ctr_words = (size_t)copy_stride * (mcp::CTR_COPIES + 1);  // copies, then the reduced vector
   DEV_TRY(ar.get(S_COUNTERS, ctr_words * sizeof(uint64_t), (void**)&d_ctr));
   uint8_t *d_ph_unc = nullptr, *d_ph_cor = nullptr, *d_fx = nullptr;
@@ -452,6 +516,10 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   hipEvent_t ev_begin, ev_end;
   DEV_TRY(ar.event(0, &ev_begin));
   DEV_TRY(ar.event(1, &ev_end));
+  if (!g_epoch) {
+    DEV_TRY(hipEventCreate(&g_epoch));
+    DEV_TRY(hipEventRecord(g_epoch, st));
+  }
   DEV_TRY(hipEventRecord(ev_begin, st));
   hipStream_t up = st;  // where the counter reset and the table upload go
   if (defer) {
@@ -555,6 +623,18 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
       }
     }
   }
+  unsigned long long* d_ctr_final = d_ctr + (size_t)copy_stride * mcp::CTR_COPIES;
+  if (cancelled && pool) {
+    // the other ranks are on their way to the collective: join it with the verdict word set, so that every rank
+    // learns of the cancellation from the pooled payload and all of them leave together
+    DEV_TRY(hipMemsetD32Async((hipDeviceptr_t)(d_ctr_final + n_ctr), 1, 1, st));
+    std::string cerr;
+    const int crc = mcp::comm_allreduce_u64(d_ctr_final, (size_t)n_ctr + 1u, st, cerr);
+    (void)hipStreamSynchronize(st);
+    mcp_free_result(out);
+    if (crc) return fail(crc, cerr);
+    return fail(MCP_ERR_CANCELLED, "cancelled by host");
+  }
   if (cancelled) {
     (void)hipStreamSynchronize(st);
     mcp_free_result(out);
@@ -562,12 +642,20 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   }
 
   // results
-  unsigned long long* d_ctr_final = d_ctr + (size_t)copy_stride * mcp::CTR_COPIES;
   DEV_TRY(mcp::launch_reduce_counters(d_ctr, copy_stride, n_ctr, d_ctr_final, st));
+  if (pool) {  // THE collective of the path: sum over ranks, in HBM, on the launch stream (RCCL over xGMI)
+    std::string cerr;
+    const int crc = mcp::comm_allreduce_u64(d_ctr_final, (size_t)n_ctr + 1u, st, cerr);
+    if (crc) {
+      (void)hipStreamSynchronize(st);
+      mcp_free_result(out);
+      return fail(crc, cerr);
+    }
+  }
   std::vector<uint16_t> h_pinned;
   uint64_t* h_ctr = nullptr;
-  DEV_TRY(ar.get_pinned(1, (size_t)n_ctr * sizeof(uint64_t), (void**)&h_ctr));
-  DEV_TRY(hipMemcpyAsync(h_ctr, d_ctr_final, (size_t)n_ctr * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  DEV_TRY(ar.get_pinned(1, ((size_t)n_ctr + 1u) * sizeof(uint64_t), (void**)&h_ctr));
+  DEV_TRY(hipMemcpyAsync(h_ctr, d_ctr_final, ((size_t)n_ctr + 1u) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   if (per_sim) {
     out->uncorrected = host_alloc<uint8_t>(cells * nt);
     out->corrected = host_alloc<uint8_t>(cells * nt);
@@ -621,6 +709,10 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     return MCP_OK;
   }
   DEV_TRY(hipStreamSynchronize(st));
+  if (pool && h_ctr[n_ctr] != 0) {  // some rank's progress callback cancelled: partial results are discarded everywhere
+    mcp_free_result(out);
+    return fail(MCP_ERR_CANCELLED, "cancelled by host (on another rank of the communicator)");
+  }
   std::memcpy(out->counters, h_ctr, (size_t)n_ctr * sizeof(uint64_t));
   if ((mle || glmm) && per_sim)  // pinned_components: bit k = diagonal variance component k pinned at 0 (spec.rs:566-573)
     for (size_t i = 0; i < cells; ++i)

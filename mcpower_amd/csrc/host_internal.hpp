@@ -44,4 +44,15 @@ uint32_t total_posthoc_contrasts(const mcp_spec* spec);
 int build_crit_rows_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint32_t n_fit, TukeyMemo* memo,
                          std::vector<double>& out, std::string& err);
 
+
+// host_comm.cpp: the RCCL communicator of this process (one process per GPU) and the counter all-reduce
+void shard_range(uint64_t n_total, uint32_t rank, uint32_t world, uint64_t* offset, uint64_t* count);
+bool comm_active();
+int comm_device();
+int comm_rank();
+int comm_world();
+int comm_unique_id(mcp_comm_id* out, int device, std::string& err);
+int comm_init(int rank, int world, const mcp_comm_id* id, int device, std::string& err);
+int comm_destroy(std::string& err);
+
 }  // namespace mcp

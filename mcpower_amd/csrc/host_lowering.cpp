@@ -10,6 +10,7 @@
 // batch.rs:2334-2407 (critical-value tables).
 #include <cmath>
 #include <limits>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -752,6 +753,11 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (prm.glmm_nagq > 1) gauss_hermite_normal(prm.glmm_nagq, prm.glmm_gz, prm.glmm_gw);
     prm.glmm_hessian = spec->wald_se == MCP_WALD_SE_HESSIAN ? 1u : 0u;
     prm.glmm_keep = prm.keep_mask[0];  // every column, or the test_formula subset (flag combination 0: nothing excluded)
+    prm.glmm_pirls_cap = 60;  // = oracle GG_PIRLS_ITERS; the diagnostic knob below only ever lowers it, so that a test can
+    if (const char* cap = std::getenv("MCP_DEBUG_GLMM_PIRLS_CAP")) {  // drive every evaluation into the cap-exit branch
+      const long v = std::strtol(cap, nullptr, 10);
+      if (v >= 1 && v <= 60) prm.glmm_pirls_cap = (uint32_t)v;
+    }
     if (!(prm.glmm_keep & 1u)) return unsupported("intercept-free test_formula fit of a clustered GLM");
     for (uint32_t t = 0; t <= spec->cluster.n_extra_groupings; ++t) {
       const mcp_re_slopes& sl = t == 0 ? spec->cluster.slopes : spec->cluster.extra[t - 1].slopes;

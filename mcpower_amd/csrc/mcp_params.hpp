@@ -192,6 +192,7 @@ struct SimParams {
   uint32_t glmm_hessian;             // clustered GLM: Wald SE from the finite-difference Hessian (spec.wald_se)
   uint32_t glmm_active;              // Glm estimator + cluster: the random-intercept GLMM kernel
   uint32_t glmm_keep;                // fitted columns of the clustered GLM: all, or the test_formula subset
+  uint32_t glmm_pirls_cap;           // joint-mode kernel: Fisher steps per evaluation (60; MCP_DEBUG_GLMM_PIRLS_CAP lowers it in tests)
 
   // staged pipeline: design tile [P columns: x1..x_{P-1}, y][max_n][tile_sims] f32
   float* tile;

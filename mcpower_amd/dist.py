@@ -6,8 +6,15 @@ which runs `single_core_find_power` per worker and pools raw counters with
 `ports/wasm/src/seeds.ts:98-103`).  Here rank r of W takes the contiguous slice
 [r*S/W, (r+1)*S/W) of sim_ids with the SAME base_seed (so the union is bit-identical to a
 single-device run, unlike the browser pool which re-seeds per worker), and the only exchange
-on the data path is ONE all-reduce (sum) of the counter vector -- RCCL over xGMI when the
-process group's backend is "nccl", gloo in the CPU tests.
+on the data path is ONE all-reduce (sum) of the counter vector.
+
+The product form of that collective lives behind the C ABI (`mcp_comm_init` + `MCP_ALLREDUCE_COUNTERS`,
+`csrc/host_comm.cpp`): `ncclAllReduce(sum, uint64)` over RCCL / xGMI on the device-resident vector, on the launch
+stream, before the call's single device-to-host copy -- no torch, no host bounce.  This module is the thin caller:
+`init_comm` carries the 128-byte rendezvous id over the host's control plane (a `torch.distributed` process group of
+any backend) and `run_batch_sharded` sets the option.  The `allreduce_counters*` functions below pool HOST counter
+blocks through a torch process group instead; they exist for the gloo rehearsals on GPU-less boxes (tests) and as a
+fallback when a caller already holds host counters.
 """
 from __future__ import annotations
 
@@ -17,10 +24,24 @@ import numpy as np
 
 
 def shard_range(n_sims: int, rank: int, world: int) -> Tuple[int, int]:
-    """(offset, count) of rank's contiguous replicate slice; slices partition [0, n_sims)."""
+    """(offset, count) of rank's contiguous replicate slice; slices partition [0, n_sims).
+    Same rule as `mcp_shard_range` (host_comm.cpp); kept in Python so GPU-less callers need no library."""
     lo = n_sims * rank // world
     hi = n_sims * (rank + 1) // world
     return lo, hi - lo
+
+
+def init_comm(rank: int, world: int, group=None) -> None:
+    """Bring up the C-ABI RCCL communicator of this process (`set_device` first): rank 0 creates the rendezvous id,
+    the process group -- control plane only, any backend -- broadcasts its 128 bytes, every rank joins."""
+    import torch.distributed as dist
+
+    from . import engine
+
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(rank, world, box[0])
 
 
 def allreduce_counters(counters: np.ndarray, group=None) -> np.ndarray:
@@ -82,10 +103,15 @@ def wilson_ci(k: int, n: int):
 
 
 def run_batch_sharded(spec, sample_sizes, n_sims: int, base_seed: int, *, rank: int, world: int, group=None, **kw):
-    """Each rank runs its slice on its own GPU (counters-only), then one all-reduce pools the counts.
+    """Each rank runs its slice on its own GPU (counters-only); the counts are pooled by the ONE all-reduce.
+    With a C-ABI communicator of this world (`init_comm`) the collective runs inside the call, on the device;
+    otherwise the host counter blocks are pooled through the torch process group.
     Returns (pooled_counters, local BatchResult)."""
     from . import engine
 
     off, cnt = shard_range(n_sims, rank, world)
+    if engine.comm_world() == world:
+        local = engine.run_batch(spec, sample_sizes, cnt, base_seed, per_sim=False, sim_offset=off, allreduce=True, **kw)
+        return local.counters, local
     local = engine.run_batch(spec, sample_sizes, cnt, base_seed, per_sim=False, sim_offset=off, **kw)
     return allreduce_counters(local.counters, group), local

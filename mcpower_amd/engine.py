@@ -22,7 +22,9 @@ EXPORTS = (
     "mcp_abi_version", "mcp_last_error", "mcp_set_device", "mcp_device_count", "mcp_run_batch", "mcp_free_result",
     "mcp_build_crit_table", "mcp_t_ppf", "mcp_norm_ppf", "mcp_chi2_ppf", "mcp_f_ppf", "mcp_generate_design",
     "mcp_fit_design", "mcp_icdf_probe", "mcp_run_batch_submit", "mcp_run_batch_collect",
+    "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_comm_rank", "mcp_comm_world", "mcp_shard_range",
 )
+COMM_ID_BYTES = 128
 _lib = None
 
 
@@ -55,6 +57,9 @@ def lib() -> C.CDLL:
                                            C.c_uint64, C.POINTER(S.CRunOptions), C.POINTER(C.c_uint64)]
         L.mcp_run_batch_collect.restype = C.c_int
         L.mcp_run_batch_collect.argtypes = [C.c_uint64, C.POINTER(S.CBatchResult)]
+        L.mcp_comm_unique_id.argtypes = [C.c_void_p]
+        L.mcp_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.mcp_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         for name, n in (("mcp_t_ppf", 2), ("mcp_norm_ppf", 1), ("mcp_chi2_ppf", 2), ("mcp_f_ppf", 3)):
             getattr(L, name).restype = C.c_double
             getattr(L, name).argtypes = [C.c_double] * n
@@ -78,21 +83,58 @@ def set_device(index: int) -> None:
     _check(lib().mcp_set_device(int(index)))
 
 
+def comm_unique_id() -> bytes:
+    """`mcp_comm_unique_id`: the 128-byte rendezvous id of a new communicator (rank 0 creates it, the host's own
+    channel -- a file, a TCP store, torch.distributed's object broadcast -- carries it to the other ranks)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().mcp_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
+
+
+def comm_init(rank: int, world: int, comm_id: bytes) -> None:
+    """`mcp_comm_init` (collective): join the RCCL communicator on the device selected with `set_device`."""
+    if len(comm_id) != COMM_ID_BYTES:
+        raise ValueError(f"communicator id must be {COMM_ID_BYTES} bytes")
+    buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id)
+    _check(lib().mcp_comm_init(int(rank), int(world), C.cast(buf, C.c_void_p)))
+
+
+def comm_destroy() -> None:
+    _check(lib().mcp_comm_destroy())
+
+
+def comm_rank() -> int:
+    return int(lib().mcp_comm_rank())
+
+
+def comm_world() -> int:
+    return int(lib().mcp_comm_world())
+
+
+def shard_range(n_sims_total: int, rank: int, world: int):
+    """`mcp_shard_range`: (offset, count) of rank's contiguous replicate slice [r*S/W, (r+1)*S/W)."""
+    off, cnt = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().mcp_shard_range(C.c_uint64(n_sims_total), int(rank), int(world), C.byref(off), C.byref(cnt)))
+    return int(off.value), int(cnt.value)
+
+
 def run_batch(spec: "S.SimulationSpec | S.LoweredSpec", sample_sizes: Sequence[int], n_sims: int, base_seed: int,
               sink: Optional[Callable[[int, int], bool]] = None, *, per_sim: bool = True, stat_capture: bool = False,
-              staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0) -> S.BatchResult:
+              staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0,
+              allreduce: bool = False) -> S.BatchResult:
     """`run_batch(spec, sample_sizes, n_sims, base_seed, sink)` (batch.rs:130).
 
     `sink(current, total) -> bool` is `ProgressSink::report` (return False to cancel -> EngineError Cancelled).
     Keyword extras: `per_sim=False` returns only the additive counters (reduced form for 1e7-replicate runs),
     `sim_offset` makes this call the shard [sim_offset, sim_offset + n_sims) of a larger run,
-    `staged=True` selects the generator -> HBM design tile -> fit pipeline instead of the fused kernel.
+    `staged=True` selects the generator -> HBM design tile -> fit pipeline instead of the fused kernel,
+    `allreduce=True` pools the counters over the process's RCCL communicator inside the call (`comm_init`).
     """
     low = spec if isinstance(spec, S.LoweredSpec) else spec.to_c()  # a marshalled spec may be reused across calls
     ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
     opts = S.CRunOptions()
     opts.flags = (S.WANT_PER_SIM if per_sim else 0) | (S.WANT_STAT_CAPTURE if stat_capture else 0) | (
-        S.PIPELINE_STAGED if staged else 0)
+        S.PIPELINE_STAGED if staged else 0) | (S.ALLREDUCE_COUNTERS if allreduce else 0)
     opts.chunk_sims = int(chunk_sims)
     opts.sim_offset = int(sim_offset)
     opts.hip_stream = hip_stream or None
@@ -127,14 +169,15 @@ class PendingBatch:
 
 
 def submit_batch(spec: "S.SimulationSpec | S.LoweredSpec", sample_sizes: Sequence[int], n_sims: int, base_seed: int, *,
-                 staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0) -> PendingBatch:
+                 staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0,
+                 allreduce: bool = False) -> PendingBatch:
     """Enqueue a counters-only `run_batch` and return without waiting: up to four batches may be in flight per
     host thread, executing in order on one stream, so the host work of the next batch hides behind the kernels
     of the previous one.  Collect on the same thread."""
     low = spec if isinstance(spec, S.LoweredSpec) else spec.to_c()
     ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
     opts = S.CRunOptions()
-    opts.flags = S.PIPELINE_STAGED if staged else 0
+    opts.flags = (S.PIPELINE_STAGED if staged else 0) | (S.ALLREDUCE_COUNTERS if allreduce else 0)
     opts.chunk_sims = int(chunk_sims)
     opts.sim_offset = int(sim_offset)
     opts.hip_stream = hip_stream or None

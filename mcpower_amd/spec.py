@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Distribution(enum.IntEnum):  # engine_contract::Distribution
@@ -265,6 +265,7 @@ class CBatchResult(C.Structure):
         ("counters", _pu64), ("layout", CCounterLayout),
         ("device_ms", C.c_double), ("kernel_ms", C.c_double), ("aux_kernel_ms", C.c_double),
         ("n_kernel_launches", C.c_uint32), ("_pad", C.c_uint32),
+        ("kernel_begin_ms", C.c_double), ("kernel_end_ms", C.c_double),
     ]
 
 
@@ -275,6 +276,7 @@ class CRunOptions(C.Structure):
 WANT_PER_SIM = 0x1
 WANT_STAT_CAPTURE = 0x2
 PIPELINE_STAGED = 0x4
+ALLREDUCE_COUNTERS = 0x8  # pool the counters over the process's RCCL communicator inside the call
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p)
 
@@ -543,6 +545,8 @@ class BatchResult:
     kernel_ms: float = 0.0
     aux_kernel_ms: float = 0.0
     n_kernel_launches: int = 0
+    kernel_begin_ms: float = 0.0           # first / last dominant-kernel launch of the call, ms since the host thread's
+    kernel_end_ms: float = 0.0             # first call: overlapping batches -> take the union of these intervals
 
     def counter(self, name: str, width: int = 1) -> np.ndarray:
         """(n_ss, width) block of the additive counters, e.g. counter('k_unc', n_targets)."""
@@ -583,4 +587,6 @@ def result_from_c(r: CBatchResult) -> BatchResult:
         kernel_ms=r.kernel_ms,
         aux_kernel_ms=r.aux_kernel_ms,
         n_kernel_launches=r.n_kernel_launches,
+        kernel_begin_ms=r.kernel_begin_ms,
+        kernel_end_ms=r.kernel_end_ms,
     )

@@ -26,6 +26,11 @@
 #define GG_THETA_ZERO 1e-6
 #define GG_PIRLS_ITERS 60
 
+/* test hook: tests lower the Fisher-step cap (here and, through MCP_DEBUG_GLMM_PIRLS_CAP, in the kernel) to drive every
+ * evaluation into the cap-exit branch, where the modes move once more after the last factor was formed */
+static int gg_pirls_cap = GG_PIRLS_ITERS;
+void mcpo_set_glmm_general_pirls_cap(int cap) { gg_pirls_cap = (cap >= 1 && cap <= GG_PIRLS_ITERS) ? cap : GG_PIRLS_ITERS; }
+
 typedef struct gg_model {
   int fam;
   uint32_t n, ld, p, nt, nth, R;
@@ -96,7 +101,7 @@ static double gg_deviance(gg_model* m, const double* par) {
   memset(u, 0, sizeof(double) * R);
   double pd_prev = INFINITY, dev = 0.0, logdet = 0.0, uu = 0.0;
   double un[GG_MAX_R], tv[GG_MAX_R];
-  for (int it = 0; it < GG_PIRLS_ITERS; ++it) {
+  for (int it = 0; it < gg_pirls_cap; ++it) {
     memset(m->M, 0, sizeof(double) * R * R);
     memset(m->r, 0, sizeof(double) * R);
     dev = 0.0;

@@ -112,6 +112,9 @@ int mcpo_glmm_general_fit(int family, const float* x, const float* y, uint32_t n
                           double* vars_out, uint8_t* converged, uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval,
                           uint32_t mode);
 
+/* test hook: Fisher-step cap of fit_glmm_general.c (default 60 = GG_PIRLS_ITERS; out-of-range values restore it) */
+void mcpo_set_glmm_general_pirls_cap(int cap);
+
 /* ---- GLMM with random slopes on the primary grouping (fit_glmm_slopes.c): q = 1 + slopes <= 3 ---- */
 int mcpo_glmm_slopes_fit(int family, const float* x, const float* y, const uint32_t* cluster_ids, uint32_t n, uint32_t ld,
                          uint32_t p, uint32_t n_clusters, uint32_t q, const uint32_t* slope_cols, const double* theta_start,

@@ -20,11 +20,33 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libmcp_oracle.so")
 _lib = None
 
 
+PORTABLE_CFLAGS = "-O2 -march=x86-64-v3 -ffp-contract=off"   # oracle/Makefile: the build that travels to the GPU box
+NATIVE_CFLAGS = "-O3 -march=native -ffp-contract=off"          # the timed CPU baseline, built ON the timing host
+_cflags = PORTABLE_CFLAGS
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds)."""
     if force or not os.path.exists(_LIB_PATH):
         subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
     return _LIB_PATH
+
+
+def use_native_build() -> str:
+    """Rebuild the oracle `-O3 -march=native` on THIS host (the flags SURVEY 8(d) names for the timed CPU baseline) and
+    bind it for the rest of the process.  Same IEEE arithmetic (no fast-math, no contraction): the tests' portable build
+    and this one agree bit for bit; only `bench.py`'s cpu_baseline leg calls this.  Returns the flags in effect."""
+    global _lib, _LIB_PATH, _cflags
+    out = os.path.join(_HERE, "_build", "libmcp_oracle_native.so")
+    r = subprocess.run(["make", "-C", _HERE, "OUT=_build/libmcp_oracle_native.so",
+                        f"CFLAGS={NATIVE_CFLAGS} -fPIC -std=gnu11 -Wall -Wextra -pthread"], capture_output=True, text=True)
+    if r.returncode == 0 and os.path.exists(out):
+        _LIB_PATH, _lib, _cflags = out, None, NATIVE_CFLAGS
+    return _cflags
+
+
+def cflags() -> str:
+    return _cflags
 
 
 def lib() -> C.CDLL:
@@ -55,6 +77,7 @@ def lib() -> C.CDLL:
         L.mcpo_marginal_uniform.restype = C.c_double
         L.mcpo_marginal_uniform.argtypes = [C.c_double] * 3
         L.mcpo_last_error.restype = C.c_char_p
+        L.mcpo_set_glmm_general_pirls_cap.argtypes = [C.c_int]
         L.mcpo_run_batch.restype = C.c_int
         L.mcpo_run_batch.argtypes = [C.POINTER(S.CSpec), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.POINTER(S.CRunOptions), C.c_uint32, C.POINTER(S.CBatchResult)]
@@ -415,3 +438,8 @@ def run_batch(spec: S.SimulationSpec, sample_sizes, n_sims: int, base_seed: int,
         return S.result_from_c(res)
     finally:
         lib().mcpo_free_result(C.byref(res))
+
+
+def set_glmm_general_pirls_cap(cap: int) -> None:
+    """Test hook of fit_glmm_general.c: Fisher steps per evaluation (0 restores the default 60)."""
+    lib().mcpo_set_glmm_general_pirls_cap(int(cap))

@@ -9,6 +9,8 @@ Sources (all data, no code):
   * crates/engine-core/src/critvals.rs:1807-1926           quantile known answers (hand-copied table below)
   * validation/data/<case>.rds + <case>.golden.rds         sim-0 design/outcome bytes (introspect::capture_sim0_data)
                                                            and R lm/glm/lme4 fits of the same bytes
+  * validation/oracle_cells.R:24-95 + data/oracle2_*.rds   six clustered-logistic cells and the reference engine's own
+                                                           find_power power / type-I rates on them (K = 50 000)
 Each per-case fixture stores the *kernel-level* spec the case lowers to
 (contract_adapter.rs column layout: [intercept | continuous | factor dummies |
 interactions]) so tests can rebuild a SimulationSpec
@@ -359,6 +361,61 @@ def make_scenario_goldens():
         json.dump(out, f, indent=1, ensure_ascii=False)
 
 
+# ---------------------------------------------------------------------------
+# 7. Oracle-2: the reference ENGINE's own find_power numbers on six harsh clustered-logistic cells
+#    (validation/oracle_cells.R:24-95 = the cell definitions, data; validation/data/oracle2_<cell>.rds = one frozen row
+#    per cell written by validation/oracle2_power.R:131-136 at K = 50 000: power_hessian_fp / typeI_hessian_fp are
+#    find_power(wald_se = "hessian", n_sims = K, seed = cell seed [+ 2 000 000 for the null model]); power_rx, typeI_rx,
+#    power_hessian, typeI_hessian are per-draw Monte-Carlo rates of the same model over K other seeds)
+# ---------------------------------------------------------------------------
+def make_oracle2():
+    src = open(f"{REF}/validation/oracle_cells.R").read()
+    src = re.sub(r"#[^\n]*", "", src)  # the comments carry no data
+    cells = {}
+    for m in re.finditer(r"(\w+)\s*=\s*list\(\s*label\s*=\s*\"(\w+)\"(.*?)\n  \)", src, re.S):
+        body = m.group(3)
+
+        def num(key, text=body):
+            mm = re.search(key + r"\s*=\s*(-?[0-9.]+)L?", text)
+            return float(mm.group(1)) if mm else None
+
+        eff = re.search(r'effects\s*=\s*"(\w+)=([0-9.]+)"', body)
+        cell = {
+            "formula": re.search(r'formula\s*=\s*"([^"]+)"', body).group(1),
+            "target_term": eff.group(1), "beta_star": float(eff.group(2)),
+            "baseline_probability": num("baseline_probability"), "icc": num("ICC"),
+            "n_clusters": int(num("n_clusters", body[body.index("cluster = list"):])),
+            "cluster_size": int(num("cluster_size")), "n": int(num(r"\bn")), "seed": int(num("seed")),
+            "slopes": [], "extra": [],
+        }
+        sl = re.search(r"slopes\s*=\s*list\(list\((.*?)\)\)", body, re.S)
+        if sl:
+            cell["slopes"].append({"column": int(num("column", sl.group(1))), "variance": num("variance", sl.group(1)),
+                                   "corr_with_intercept": num("corr_with_intercept", sl.group(1)), "corr_with": []})
+        ex = re.search(r"extra\s*=\s*list\(list\((.*?)\)\)", body, re.S)
+        if ex:
+            kind = re.search(r'kind\s*=\s*"(\w+)"', ex.group(1)).group(1)
+            cell["extra"].append({"kind": kind, "n_clusters": int(num("n_clusters", ex.group(1))),
+                                  "tau_squared": num("tau_squared", ex.group(1))})
+        cells[m.group(2)] = cell
+    assert sorted(cells) == sorted(["few6_int", "few8_slope", "few10_crossed", "hiICC_int", "smallclust", "boundary"]), cells.keys()
+    out = {"source": "validation/oracle_cells.R:24-95 (cells), validation/data/oracle2_<cell>.rds (frozen rows of "
+                     "validation/oracle2_power.R at K = 50 000); null-model seed offset 2 000 000 (oracle2_power.R:135-136)",
+           "k": 50000, "null_seed_offset": 2000000, "cells": {}}
+    for name, cell in cells.items():
+        row = to_py(read_rds(f"{REF}/validation/data/oracle2_{name}.rds"))
+        frozen = {}
+        for k, v in row.items():
+            v0 = np.asarray(v).reshape(-1)[0]
+            frozen[k] = str(v0) if isinstance(v0, (str, np.str_)) else float(v0)
+        assert int(frozen["n"]) == cell["n"] and int(frozen["n_clusters"]) == cell["n_clusters"] and \
+            abs(frozen["ICC"] - cell["icc"]) < 1e-12 and int(frozen["cluster_size"]) == cell["cluster_size"], name
+        out["cells"][name] = {"cell": cell, "frozen": frozen}
+    with open(os.path.join(HERE, "oracle2.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("oracle2.json:", {k: (v["frozen"]["power_hessian_fp"], v["frozen"]["typeI_hessian_fp"]) for k, v in out["cells"].items()})
+
+
 if __name__ == "__main__":
     make_rng_kat()
     make_cases()
@@ -366,3 +423,4 @@ if __name__ == "__main__":
     make_crossings()
     make_scenario_goldens()
     make_mixed_cases()
+    make_oracle2()

@@ -29,13 +29,64 @@ def test_library_exports_every_declared_symbol(engine):
     assert L.mcp_abi_version() == S.ABI_VERSION
 
 
-def test_struct_sizes_are_stable():
+def test_ctypes_mirror_matches_the_header_field_by_field(tmp_path):
+    """sizeof / offsetof of every struct of include/mcpower_hip.h, from the C compiler, against the ctypes mirror
+    (mcpower_amd/spec.py): a drift in either fails here, field by field."""
     import ctypes as C
-    # guards the ctypes mirror against silent layout drift (sizes from the C compiler: tests/test_abi_sizes)
-    assert C.sizeof(S.CRunOptions) == 24
-    assert C.sizeof(S.CCounterLayout) == 64
-    assert C.sizeof(S.CCluster) == 368 and C.sizeof(S.CReSlopes) == 104 and C.sizeof(S.CGrouping) == 120
-    assert C.sizeof(S.CSpec) % 8 == 0
+    import subprocess
+    mirror = {"mcp_spec": S.CSpec, "mcp_batch_result": S.CBatchResult, "mcp_run_options": S.CRunOptions,
+              "mcp_counter_layout": S.CCounterLayout, "mcp_cluster": S.CCluster, "mcp_re_slopes": S.CReSlopes,
+              "mcp_grouping": S.CGrouping, "mcp_scenario": S.CScenario}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mcpower_hip.h"', 'int main(void) {']
+    for cname, cls in mirror.items():
+        lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, *_ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  printf("mcp_comm_id sizeof %zu\\n", sizeof(mcp_comm_id));', '  return 0;', '}']
+    src = tmp_path / "abi_table.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi_table"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True, capture_output=True)
+    table = {}
+    for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n"):
+        if ln:
+            t, f, v = ln.split()
+            table[(t, f)] = int(v)
+    n_fields = 0
+    for cname, cls in mirror.items():
+        assert C.sizeof(cls) == table[(cname, "sizeof")], cname
+        for fname, *_ in cls._fields_:
+            assert getattr(cls, fname).offset == table[(cname, fname)], (cname, fname)
+            n_fields += 1
+    assert n_fields > 120 and table[("mcp_comm_id", "sizeof")] == 128
+    # every member the header declares is mirrored (count the declarators of each struct body)
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mcpower_hip.h")).read(), flags=re.S)
+    for cname, cls in mirror.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, flags=re.S).group(1)
+        declared = sum(len(stmt.split(",")) for stmt in body.split(";") if stmt.strip())
+        assert declared == len(cls._fields_), (cname, declared, len(cls._fields_))
+
+
+def test_comm_entry_points_fail_loudly_without_a_device(engine):
+    """The communicator needs its MI355X: on a GPU-less box every device-touching call reports MCP_ERR_DEVICE, the
+    argument checks still run first, and the host-only sharding rule works."""
+    with pytest.raises(S.EngineError) as e:
+        engine.comm_init(2, 2, bytes(128))
+    assert e.value.status == S.Status.InvalidSpec and "[0, world)" in str(e.value)
+    if engine.device_count() == 0:
+        for call in (engine.comm_unique_id, lambda: engine.comm_init(0, 1, bytes(128))):
+            with pytest.raises(S.EngineError) as e:
+                call()
+            assert e.value.status == S.Status.Device and "no CPU fallback" in str(e.value)
+        with pytest.raises(S.EngineError) as e:
+            engine.run_batch(spec_c2a(), [200], 16, BASE_SEED, per_sim=False, allreduce=True)
+        assert e.value.status == S.Status.InvalidSpec and "communicator" in str(e.value)
+    engine.comm_destroy()  # no-op without a communicator
+    assert engine.comm_rank() == -1 and engine.comm_world() == 0
+    assert engine.shard_range(10, 0, 3) == (0, 3) and engine.shard_range(10, 2, 3) == (6, 4)
+    with pytest.raises(S.EngineError):
+        engine.shard_range(10, 3, 3)
 
 
 def test_crit_table_matches_oracle(engine, oracle):

@@ -94,6 +94,32 @@ def test_glmm_with_extra_groupings_matches_oracle(name, n_sims, engine, oracle):
     _compare(dev, ora, n_sims, stat, ora.stat_capture, slack=2)
 
 
+@pytest.mark.parametrize("link", ["logit", "poisson"])
+def test_glmm_extra_groupings_cap_exit_of_the_fisher_loop(link, engine, oracle, monkeypatch):
+    """Every evaluation is driven into the Fisher-step cap (lowered to 4 on both sides: MCP_DEBUG_GLMM_PIRLS_CAP for
+    the kernel, mcpo_set_glmm_general_pirls_cap for the oracle).  On that exit the modes move once more AFTER the last
+    factor of I + A'WA was formed, so the Wald tail's weights -- recomputed at the final modes, as
+    oracle/fit_glmm_general.c:275-287 does -- differ from the last Fisher step's: the branch a converged loop never
+    takes.  Statistics must still agree, and must differ from the uncapped fit (the knob took effect)."""
+    spec, _, a, low = load_case("glmm_slope_crossed")
+    if link == "poisson":
+        spec.outcome_kind = S.OutcomeKind.Count
+        spec.effect_sizes = [0.5, 0.15]
+        spec.cluster.tau_squared = 0.10
+    spec.scenario.truth_start = True
+    free, stat_free = engine.run_batch_st_capture(spec, [low["n"]], 12, BASE_SEED)
+    monkeypatch.setenv("MCP_DEBUG_GLMM_PIRLS_CAP", "4")
+    oracle.set_glmm_general_pirls_cap(4)
+    try:
+        dev, stat = engine.run_batch_st_capture(spec, [low["n"]], 12, BASE_SEED)
+        ora = oracle.run_batch(spec, [low["n"]], 12, BASE_SEED, n_threads=8, stat_capture=True)
+    finally:
+        oracle.set_glmm_general_pirls_cap(0)
+    _compare(dev, ora, 12, stat, ora.stat_capture, slack=2)
+    both = (dev.converged[:, 0] == 1) & (free.converged[:, 0] == 1)
+    assert both.sum() >= 6 and not np.allclose(stat[both], stat_free[both], rtol=1e-9, atol=0)
+
+
 @pytest.mark.parametrize("link", ["logit", "probit", "poisson"])
 def test_glmm_extra_groupings_under_a_scenario_preset(link, engine, oracle):
     """General data path + heavy-tailed random effects + one ICC jitter per grouping; nested grouping on a two-point
