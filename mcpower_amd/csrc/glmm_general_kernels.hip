@@ -33,7 +33,6 @@ constexpr int QW = 64;
 constexpr uint32_t GLMM_MAX_EVAL = 30000;
 constexpr double GLMM_THETA_MAX = 32.0;
 constexpr double GLMM_THETA_ZERO = 1e-6;
-constexpr int GLMM_PIRLS_ITERS = 60;
 constexpr double GLMM_NEAR_ZERO = 1e-30;
 constexpr int GLMM_ROW = 20;  // simplex row stride (d = n_theta + P <= 12 + 6)
 constexpr uint32_t GG_MAX_TERMS = 3;
@@ -43,7 +42,7 @@ typedef __attribute__((address_space(3))) float gdf;
 typedef __attribute__((address_space(3))) uint16_t gdu;
 
 struct GlmmLds {
-  gdd *eta0, *wrow, *res, *M, *u, *r, *un, *C, *T, *av, *simplex, *fv, *tail;
+  gdd *eta0, *wrow, *res, *M, *u, *ut, *r, *un, *C, *T, *av, *simplex, *fv, *tail;
   uint32_t ao[GG_MAX_TERMS];  // plane of term t's first entry in av (planes of n_pad rows)
   gdf *design, *draws;
   gdu* lvl;          // level of a row in extra term t at lvl[(t - 1) * n_pad + i]
@@ -297,7 +296,10 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
     for (int c = 1; c < P; ++c) e += (double)m.design[(size_t)(c - 1) * n_pad + i] * beta[c];
     m.eta0[i] = e;
   }
-  for (uint32_t a = lane; a < R; a += QW) m.u[a] = 0.0;
+  for (uint32_t a = lane; a < R; a += QW) {
+    m.u[a] = 0.0;
+    m.ut[a] = 0.0;
+  }
   gq_sync();
   for (uint32_t i = lane; i < n; i += QW)
     for (uint32_t t = 0; t < nterms; ++t) {
@@ -308,21 +310,24 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         if ((uint32_t)b < prm.lmg_q[t]) m.av[(size_t)(m.ao[t] + (uint32_t)b) * n_pad + i] = a[b];
     }
   gq_sync();
-  double pd_prev = __builtin_inf(), dev = 0.0, logdet = 0.0, uu = 0.0;
+  // joint conditional modes by Fisher scoring with step halving (oracle/fit_glmm_general.c): m.u, the factor in m.M, dev,
+  // uu and logdet belong to the ACCEPTED point, m.ut is the trial; a trial whose penalised deviance is not below the
+  // accepted one's is pulled half-way back to it (and costs one row sweep, no factorisation)
+  double pd_acc = __builtin_inf(), dev = 0.0, logdet = 0.0, uu = 0.0;
   bool ok = true;
   const int pirls_cap = (int)prm.glmm_pirls_cap;  // GLMM_PIRLS_ITERS unless the diagnostic knob lowered it
   for (int it = 0; it < pirls_cap; ++it) {
-    // ---- lane = row: weight, working residual, deviance at the current modes ----
+    // ---- lane = row: weight, working residual, deviance at the trial modes ----
     double devp = 0.0;
     for (uint32_t i = lane; i < n; i += QW) {
       double au = 0.0;
       for (uint32_t t = 0; t < nterms; ++t) {
         double a[3];
         const uint32_t l = gg_row_term<P>(prm, m, t, i, n_pad, a);
-        const gdd* ut = m.u + m.off[t] + l * prm.lmg_q[t];
-        au += a[0] * ut[0];
-        if (prm.lmg_q[t] > 1u) au += a[1] * ut[1];
-        if (prm.lmg_q[t] > 2u) au += a[2] * ut[2];
+        const gdd* utp = m.ut + m.off[t] + l * prm.lmg_q[t];
+        au += a[0] * utp[0];
+        if (prm.lmg_q[t] > 1u) au += a[1] * utp[1];
+        if (prm.lmg_q[t] > 2u) au += a[2] * utp[2];
       }
       const double e0 = m.eta0[i];
       double w, wz, dv;
@@ -331,7 +336,25 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
       m.res[i] = wz - w * e0;  // w (z - eta0)
       devp += dv;
     }
-    dev = gq_wave_sum(devp);
+    const double devt = gq_wave_sum(devp);
+    double uup = 0.0;
+    for (uint32_t a = lane; a < R; a += QW) uup += m.ut[a] * m.ut[a];
+    const double uut = gq_wave_sum(uup);
+    const double pd = devt + uut, tol = 1e-13 * (__builtin_fabs(pd) + 1.0);
+    if (!(pd <= pd_acc + tol)) {  // worse than the accepted point (or not finite): halve the step
+      bool stuck_t = true, stuck_a = true;
+      for (uint32_t a = lane; a < R; a += QW) {
+        const double tv = m.ut[a], av = m.u[a], half = 0.5 * (tv + av);
+        stuck_t = stuck_t && (half == tv);
+        stuck_a = stuck_a && (half == av);
+        m.ut[a] = half;
+      }
+      stuck_t = __ballot(!stuck_t) == 0ull;
+      stuck_a = __ballot(!stuck_a) == 0ull;
+      gq_sync();
+      if (stuck_t || stuck_a) break;
+      continue;  // m.M still holds the accepted point's factor
+    }
     for (uint32_t e = lane; e < R * RS; e += QW) m.M[e] = 0.0;
     gq_sync();
     // ---- lane = level of term t: the columns of I + A'WA (and the entries of A'W(z - eta0)) that level owns ----
@@ -441,31 +464,26 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         m.r[a] = 0.0;
       }
     }
-    double uup = 0.0;
-    for (uint32_t a = lane; a < R; a += QW) uup += m.u[a] * m.u[a];
-    uu = gq_wave_sum(uup);
     gq_sync();
-    const double pd = dev + uu;
     ok = gg_chol(m.M, R, RS, m.off[1], prm.lmg_q[0], lane, m.un, logdet);
     if (!ok) break;
-    if (it > 0 && __builtin_fabs(pd - pd_prev) <= 1e-13 * (__builtin_fabs(pd) + 1.0)) break;
+    const bool conv = __builtin_fabs(pd_acc - pd) <= tol;  // pd_acc = inf on the first pass: never
+    for (uint32_t a = lane; a < R; a += QW) m.u[a] = m.ut[a];  // accept
+    dev = devt;
+    uu = uut;
+    pd_acc = pd;
+    gq_sync();
+    if (conv) break;
     gg_forward(m.M, R, RS, m.off[1], prm.lmg_q[0], m.r, 1u, 1u, lane);
     gg_backward(m.M, R, RS, m.off[1], prm.lmg_q[0], m.r, m.un, lane);
     bool same = true;
-    for (uint32_t a = lane; a < R; a += QW) {
-      double v = m.un[a];
-      const double uo = m.u[a];
-      if (it > 0 && pd > pd_prev) v = 0.5 * (uo + v);
-      same = same && (v == uo);
-      m.un[a] = v;
-    }
+    for (uint32_t a = lane; a < R; a += QW) same = same && (m.un[a] == m.u[a]);
     same = __ballot(!same) == 0ull;
-    pd_prev = pd;
     if (same) break;
-    gq_sync();
-    for (uint32_t a = lane; a < R; a += QW) m.u[a] = m.un[a];
+    for (uint32_t a = lane; a < R; a += QW) m.ut[a] = m.un[a];
     gq_sync();
   }
+  if (!(pd_acc < __builtin_inf())) ok = false;  // not even the prior modes evaluate
   gq_sync();
   const double total = dev + uu + logdet;
   return (ok && total < __builtin_inf() && total > -__builtin_inf()) ? total : __builtin_inf();
@@ -624,6 +642,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     m.res = q; q += n_pad;
     m.M = q; q += (size_t)m.R * m.RS;
     m.u = q; q += m.R;
+    m.ut = q; q += m.R;
     m.r = q; q += m.R;
     m.un = q; q += m.R;
     m.C = q; q += (size_t)m.R * P;
@@ -948,8 +967,6 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
 #pragma unroll
       for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]) - gq_wave_sum(dd[i]);
     }
-    bool singular = false;
-    for (uint32_t k = 0; k < nth; ++k) singular = singular || (((m.diag_mask >> k) & 1u) && x0[k] < GLMM_THETA_ZERO);
     double Lx[P][P];
     // lower Cholesky factor of a packed precision matrix over the kept columns; a dropped column is an identity row /
     // column: the kept block factors as the gathered system
@@ -982,14 +999,17 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
       return fok;
     };
     ok = factor(A, Lx) && ok;
-    if (prm.glmm_hessian && ok && !(singular)) {
-      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp); a singular fit, or a block that does not factor, keeps "rx"
+    if (prm.glmm_hessian && ok) {
+      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp) over the FREE covariance parameters and beta (a pinned diagonal is
+      // an even point of the deviance and drops out); a block that does not factor keeps "rx"
+      uint32_t th_free = 0u;
+      for (uint32_t k = 0; k < nth; ++k) th_free |= (((m.diag_mask >> k) & 1u) && x0[k] < GLMM_THETA_ZERO) ? 0u : (1u << k);
       auto fdev = [&](gdd* pt) -> double {
         uint32_t scratch = 0;
         return glmm_f<P>(prm, m, pt, lane, n, ncl, n_pad, keep, scratch);
       };
       const uint32_t nth_h = nth, d_h = nth_h + (uint32_t)__popc(keep);
-      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane)) {
+      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane, th_free)) {
         double Ah[P * (P + 1) / 2], Lh[P][P];
         const gdd* Hs = m.simplex + GLMM_ROW;
         int idx = 0;
@@ -1151,7 +1171,7 @@ size_t glmm_general_lds_bytes(const SimParams& prm) {
   for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) nd += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
   size_t na = 0;
   for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) na += prm.lmg_q[t];
-  const size_t dbl = (3 + na) * n_pad + R * RS + 3 * R + R * P + 28 + (dmax + 4) * GLMM_ROW + ((dmax + 2) & ~(size_t)1) + 8;
+  const size_t dbl = (3 + na) * n_pad + R * RS + 4 * R + R * P + 28 + (dmax + 4) * GLMM_ROW + ((dmax + 2) & ~(size_t)1) + 8;
   size_t so = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) so += (size_t)prm.lmg_levels[t] + 2;
   const size_t flt = P * n_pad + ((nd + 1) & ~(size_t)1) + 2 * ((prm.lmg_n_terms - 1) * n_pad / 2 + 2) + (so + 3) / 2 + 1 +

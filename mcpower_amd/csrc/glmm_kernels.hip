@@ -34,7 +34,7 @@ constexpr int QW = 64;
 constexpr uint32_t GLMM_MAX_EVAL = 8000;
 constexpr double GLMM_THETA_MAX = 32.0;
 constexpr double GLMM_THETA_ZERO = 1e-6;
-constexpr int GLMM_PIRLS_ITERS = 40;
+constexpr int GLMM_PIRLS_ITERS = 60;
 constexpr double GLMM_NEAR_ZERO = 1e-30;
 constexpr int GLMM_ROW = 10;  // simplex row stride (d = P + 1 <= 9)
 
@@ -89,33 +89,44 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
     const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
     const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
     const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
-    double u = 0.0, pd_prev = __builtin_inf(), sw = 0.0, dev = 0.0;
+    // conditional mode by Fisher scoring with step halving (lme4's PIRLS; oracle/fit_glmm.c): a trial point whose
+    // penalised deviance is not below the accepted point's is pulled half-way back to it -- an undamped step 2-cycles
+    // on clusters far from their prior (15 events of 20 at a 10 % baseline).  (u, sw, dev) = the accepted point
+    double u = 0.0, sw = 0.0, dev = 0.0, ut = 0.0, pd_acc = __builtin_inf();
     if (first < last) {
       for (int it = 0; it < GLMM_PIRLS_ITERS; ++it) {
-        double swz = 0.0;
-        sw = 0.0;
-        dev = 0.0;
+        double swz = 0.0, swt = 0.0, devt = 0.0;
         for (uint32_t i = first + sub * step; i < last; i += step << ls) {
           const double e0 = m.eta0[i];
           double w, wz, d;
-          fam_eval(fam, e0 + theta * u, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, d);
-          sw += w;
+          fam_eval(fam, e0 + theta * ut, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, d);
+          swt += w;
           swz += wz - w * e0;  // w (z - eta0)
-          dev += d;
+          devt += d;
         }
         for (uint32_t o = 1u; o < (1u << ls); o <<= 1) {
-          sw += __shfl_xor(sw, (int)o);
+          swt += __shfl_xor(swt, (int)o);
           swz += __shfl_xor(swz, (int)o);
-          dev += __shfl_xor(dev, (int)o);
+          devt += __shfl_xor(devt, (int)o);
         }
-        const double pd = dev + u * u;
-        if (it > 0 && __builtin_fabs(pd - pd_prev) <= 1e-13 * (__builtin_fabs(pd) + 1.0)) break;
-        double un = theta * swz / (theta * theta * sw + 1.0);
-        if (it > 0 && pd > pd_prev) un = 0.5 * (u + un);
-        pd_prev = pd;
+        const double pd = devt + ut * ut, tol = 1e-13 * (__builtin_fabs(pd) + 1.0);
+        if (!(pd <= pd_acc + tol)) {  // worse than the accepted point (or not finite): halve the step
+          const double half = 0.5 * (ut + u);
+          if (half == ut || half == u) break;
+          ut = half;
+          continue;
+        }
+        const bool conv = __builtin_fabs(pd_acc - pd) <= tol;  // pd_acc = inf on the first pass: never
+        u = ut;
+        sw = swt;
+        dev = devt;
+        pd_acc = pd;
+        if (conv) break;
+        const double un = theta * swz / (theta * theta * swt + 1.0);
         if (un == u) break;
-        u = un;
+        ut = un;
       }
+      if (!(pd_acc < __builtin_inf())) dev = __builtin_inf();  // not even the prior mode evaluates
       double term = dev + u * u + log(theta * theta * sw + 1.0);
       if (prm.glmm_nagq > 1u) {
         // adaptive Gauss-Hermite (lme4 glmerAGQ): the k-point rule centred at the mode, scaled by the conditional sd,
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_kernel(const SimParam
         return glmm_f<P>(prm, m, pt, lane, n, ncl, n_pad, keep, scratch);
       };
       const uint32_t nth_h = 1u, d_h = nth_h + (uint32_t)__popc(keep);
-      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane)) {
+      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane, 1u)) {
         double Ah[P * (P + 1) / 2], Lh[P][P];
         const gdd* Hs = m.simplex + GLMM_ROW;
         int idx = 0;

@@ -37,7 +37,7 @@ constexpr int QW = 64;
 constexpr uint32_t GLMM_MAX_EVAL = 12000;
 constexpr double GLMM_THETA_MAX = 32.0;
 constexpr double GLMM_THETA_ZERO = 1e-6;
-constexpr int GLMM_PIRLS_ITERS = 40;
+constexpr int GLMM_PIRLS_ITERS = 60;
 constexpr double GLMM_NEAR_ZERO = 1e-30;
 constexpr int GLMM_ROW = 16;  // simplex row stride (d = Q (Q + 1) / 2 + P <= 14)
 
@@ -108,17 +108,20 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
 #pragma unroll
       for (int dd = 0; dd < Q; ++dd) Lm[b][dd] = b == dd ? 1.0 : 0.0;
     }
-    double pd_prev = __builtin_inf(), dev = 0.0, logdet = 0.0;
+    // Fisher scoring with step halving (oracle/fit_glmm_slopes.c): (u, Lm, dev, logdet) belong to the ACCEPTED point,
+    // ut is the trial; a trial whose penalised deviance is not below the accepted one's is pulled half-way back
+    double pd_acc = __builtin_inf(), dev = 0.0, logdet = 0.0, ut[Q];
+#pragma unroll
+    for (int b = 0; b < Q; ++b) ut[b] = 0.0;
     if (first < last) {
       for (int it = 0; it < GLMM_PIRLS_ITERS; ++it) {
-        double M[Q][Q], r[Q];
+        double M[Q][Q], r[Q], devt = 0.0;
 #pragma unroll
         for (int b = 0; b < Q; ++b) {
           r[b] = 0.0;
 #pragma unroll
           for (int dd = 0; dd < Q; ++dd) M[b][dd] = 0.0;
         }
-        dev = 0.0;
         for (uint32_t i = first + sub * step; i < last; i += step << ls) {
           double z[Q], a[Q], au = 0.0;
           z[0] = 1.0;
@@ -131,12 +134,12 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
             for (int dd = 0; dd < Q; ++dd)
               if (dd >= b) sacc += T[dd][b] * z[dd];
             a[b] = sacc;
-            au += sacc * u[b];
+            au += sacc * ut[b];
           }
           const double e0 = m.eta0[i];
           double w, wz, dv;
           fam_eval(fam, e0 + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
-          dev += dv;
+          devt += dv;
           const double res = wz - w * e0;  // w (z - eta0)
 #pragma unroll
           for (int b = 0; b < Q; ++b) {
@@ -147,7 +150,7 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
           }
         }
         for (uint32_t o = 1u; o < (1u << ls); o <<= 1) {
-          dev += __shfl_xor(dev, (int)o);
+          devt += __shfl_xor(devt, (int)o);
 #pragma unroll
           for (int b = 0; b < Q; ++b) {
             r[b] += __shfl_xor(r[b], (int)o);
@@ -160,10 +163,22 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
 #pragma unroll
         for (int b = 0; b < Q; ++b) {
           M[b][b] += 1.0;
-          uu += u[b] * u[b];
+          uu += ut[b] * ut[b];
         }
-        const double pd = dev + uu;
-        bool cok = true;  // lower Cholesky of I + A'WA
+        const double pd = devt + uu, tol = 1e-13 * (__builtin_fabs(pd) + 1.0);
+        if (!(pd <= pd_acc + tol)) {  // worse than the accepted point (or not finite): halve the step
+          bool stuck_t = true, stuck_a = true;
+#pragma unroll
+          for (int b = 0; b < Q; ++b) {
+            const double half = 0.5 * (ut[b] + u[b]);
+            stuck_t = stuck_t && (half == ut[b]);
+            stuck_a = stuck_a && (half == u[b]);
+            ut[b] = half;
+          }
+          if (stuck_t || stuck_a) break;
+          continue;
+        }
+        bool cok = true;  // lower Cholesky of I + A'WA at the point about to be accepted
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
           double dj = M[j][j];
@@ -186,7 +201,12 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         logdet = 0.0;
 #pragma unroll
         for (int b = 0; b < Q; ++b) logdet += 2.0 * log(Lm[b][b]);
-        if (it > 0 && __builtin_fabs(pd - pd_prev) <= 1e-13 * (__builtin_fabs(pd) + 1.0)) break;
+        const bool conv = __builtin_fabs(pd_acc - pd) <= tol;  // pd_acc = inf on the first pass: never
+#pragma unroll
+        for (int b = 0; b < Q; ++b) u[b] = ut[b];
+        dev = devt;
+        pd_acc = pd;
+        if (conv) break;
         double un[Q], t[Q];
 #pragma unroll
         for (int b = 0; b < Q; ++b) {
@@ -206,15 +226,12 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         }
         bool same = true;
 #pragma unroll
-        for (int b = 0; b < Q; ++b) {
-          if (it > 0 && pd > pd_prev) un[b] = 0.5 * (u[b] + un[b]);
-          same = same && (un[b] == u[b]);
-        }
-        pd_prev = pd;
+        for (int b = 0; b < Q; ++b) same = same && (un[b] == u[b]);
         if (same) break;
 #pragma unroll
-        for (int b = 0; b < Q; ++b) u[b] = un[b];
+        for (int b = 0; b < Q; ++b) ut[b] = un[b];
       }
+      if (!(pd_acc < __builtin_inf())) ok = false;  // not even the prior mode evaluates
       double uu = 0.0;
 #pragma unroll
       for (int b = 0; b < Q; ++b) uu += u[b] * u[b];
@@ -665,9 +682,6 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
     }
 #pragma unroll
     for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]);
-    bool singular = false;
-#pragma unroll
-    for (uint32_t k = 0; k < NTH; ++k) singular = singular || (glmm_is_diag<Q>(k) && th[k] < GLMM_THETA_ZERO);
     double Lx[P][P];
     // lower Cholesky factor of a packed precision matrix over the kept columns; a dropped column is an identity row /
     // column: the kept block factors as the gathered system
@@ -700,14 +714,19 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
       return fok;
     };
     ok = factor(A, Lx) && ok;
-    if (prm.glmm_hessian && ok && !(singular)) {
-      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp); a singular fit, or a block that does not factor, keeps "rx"
+    if (prm.glmm_hessian && ok) {
+      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp) over the FREE covariance parameters and beta: a pinned diagonal is
+      // an even point of the deviance and drops out, the coupling with the other parameters (what "rx" ignores) stays;
+      // a block that does not factor keeps "rx"
+      uint32_t th_free = 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < NTH; ++k) th_free |= (glmm_is_diag<Q>(k) && th[k] < GLMM_THETA_ZERO) ? 0u : (1u << k);
       auto fdev = [&](gdd* pt) -> double {
         uint32_t scratch = 0;
         return glmm_f<P, Q>(prm, m, pt, lane, n, ncl, n_pad, keep, scratch);
       };
       const uint32_t nth_h = NTH, d_h = nth_h + (uint32_t)__popc(keep);
-      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane)) {
+      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane, th_free)) {
         double Ah[P * (P + 1) / 2], Lh[P][P];
         const gdd* Hs = m.simplex + GLMM_ROW;
         int idx = 0;

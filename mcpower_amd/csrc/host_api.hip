@@ -785,8 +785,6 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
   if (rc) return fail(rc, err);
   if (prm.between_mask)
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: design capture with cluster-level (between) predictors");
-  if (prm.lmg_active)  // the capture kernel draws the primary random intercept only
-    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: design capture with random slopes / extra groupings");
   if (n_sims == 0) return MCP_OK;
   hipStream_t st = nullptr;
   rc = ensure_device(&st, nullptr);
@@ -828,7 +826,8 @@ int mcp_generate_design(const mcp_spec* spec, uint32_t max_n, uint32_t n_sims, u
     const uint32_t K = spec->n_non_factor;
     double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr, *d_scen_tau = nullptr;
     uint32_t* d_scen_meta = nullptr;
-    if (spec->cluster.present) HIP_TRY(ar.get(S_SCEN_TAU, (size_t)n_sims * sizeof(double), (void**)&d_scen_tau));
+    if (spec->cluster.present)  // realised tau^2 per replicate: the primary grouping, then each extra grouping
+      HIP_TRY(ar.get(S_SCEN_TAU, (size_t)n_sims * (1u + spec->cluster.n_extra_groupings) * sizeof(double), (void**)&d_scen_tau));
     prm.scen_tau_sq = d_scen_tau;
     HIP_TRY(ar.get(S_SCEN_L, (size_t)(K * (K + 1) / 2 + 1) * n_sims * sizeof(double), (void**)&d_scen_L));
     HIP_TRY(ar.get(S_SCEN_META, (size_t)n_sims * sizeof(uint32_t), (void**)&d_scen_meta));

@@ -9,12 +9,26 @@
 // entries: nth theta then the fitted coefficients); rows 1 .. d hold H, row d + 3 the stencil point.  On success the
 // lower triangle of S / 2, S = H_bb - H_bt H_tt^-1 H_tb, sits at H[nth + r][nth + c] and the function returns true;
 // false when a block does not factor (the caller keeps the "rx" covariance, as vcov.merMod falls back).
+// theta_free: bit k set = covariance parameter k takes part.  A diagonal pinned at 0 is left out: it sits at an even
+// point of the deviance (flipping the sign of a column of Lambda only relabels u), so its cross-derivatives vanish and
+// the beta block is the same without it -- its row / column become identity (exact zeros in every later sum: the
+// free parameters go through the operation sequence of the compacted system the oracle factors).
 template <class F>
-__device__ __noinline__ bool glmm_fd_hessian_schur(F& f, gdd* sx, uint32_t row, uint32_t nth, uint32_t d, double fx, uint32_t lane) {
+__device__ __noinline__ bool glmm_fd_hessian_schur(F& f, gdd* sx, uint32_t row, uint32_t nth, uint32_t d, double fx, uint32_t lane,
+                                                   uint32_t theta_free) {
   const double dl = 1e-4;
   gdd* pt = sx + (size_t)row * (d + 3u);
   gdd* H = sx + row;  // H[a][b] at H[a * row + b]
+  auto is_free = [&](uint32_t k) -> bool { return k >= nth || ((theta_free >> k) & 1u); };
   for (uint32_t a = 0; a < d; ++a) {
+    if (!is_free(a)) {
+      gq_sync();
+      if (lane < d) {
+        H[(size_t)a * row + lane] = lane == a ? 1.0 : 0.0;
+        H[(size_t)lane * row + a] = lane == a ? 1.0 : 0.0;
+      }
+      continue;
+    }
     double fadd = 0.0, fsub = 0.0;
     for (int q = 0; q < 2; ++q) {
       gq_sync();
@@ -26,6 +40,7 @@ __device__ __noinline__ bool glmm_fd_hessian_schur(F& f, gdd* sx, uint32_t row, 
     }
     if (lane == 0u) H[(size_t)a * row + a] = fadd / (dl * dl) - 2.0 * fx / (dl * dl) + fsub / (dl * dl);
     for (uint32_t b = 0; b < a; ++b) {
+      if (!is_free(b)) continue;  // that row / column is already identity
       double acc = 0.0;  // f++ - f+- - f-+ + f--, summed in that order
       for (int q = 0; q < 4; ++q) {
         gq_sync();

@@ -19,6 +19,7 @@
 #include "mcp_device.hpp"
 #include "mcp_params.hpp"
 #include "mcp_rows.hpp"
+#include "mcp_lmg_row.hpp"
 #include "mcp_suff.hpp"
 
 #pragma clang fp contract(off)
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void design_capture_kernel(const SimParams* 
     for (int r = 0; r < 4; ++r) {
       const uint32_t rr = 4u * ctr + r;
       double u_re = 0.0;
-      if (prm.has_cluster) {
+      if (prm.has_cluster && !prm.lmg_active) {
         const uint32_t cid = prm.cluster_fixed_clusters ? rr % prm.cluster_v : rr / prm.cluster_v;
         double tau_rep = prm.tau;
         if (SCEN && prm.scen_tau_sq) {
@@ -335,7 +336,12 @@ __global__ __launch_bounds__(BLOCK) void design_capture_kernel(const SimParams* 
         u_re = (double)(float)(draw_cluster_effect(prm, k0, k1, cid < prm.n_clusters_max ? cid : 0u) * tau_rep);
       }
       float x[P], y;
-      if (discrete) build_row<P, true, BLOCK, 1, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
+      if (prm.lmg_active) {  // random slopes / extra groupings: the row's effect needs its own columns (slopes)
+        const float e = build_x<P, true, BLOCK, SCEN>(prm, cx, k0, k1, st, r, rr, x, &sl);
+        const double u_gen = lmg_row_effect_redraw<P, SCEN>(prm, k0, k1, lsim, rr, x);
+        if (discrete) finish_row<P, 1, SCEN>(prm, cx, x, e, y, u_gen, &sl);
+        else finish_row<P, 0, SCEN>(prm, cx, x, e, y, u_gen, &sl);
+      } else if (discrete) build_row<P, true, BLOCK, 1, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
       else build_row<P, true, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
 #pragma unroll
       for (int c = 1; c < P; ++c) q[c - 1][r] = x[c];

@@ -27,7 +27,7 @@
 #define GG_PIRLS_ITERS 60
 
 /* test hook: tests lower the Fisher-step cap (here and, through MCP_DEBUG_GLMM_PIRLS_CAP, in the kernel) to drive every
- * evaluation into the cap-exit branch, where the modes move once more after the last factor was formed */
+ * evaluation into the cap-exit branch: the loop then stops on an accepted point that is not converged */
 static int gg_pirls_cap = GG_PIRLS_ITERS;
 void mcpo_set_glmm_general_pirls_cap(int cap) { gg_pirls_cap = (cap >= 1 && cap <= GG_PIRLS_ITERS) ? cap : GG_PIRLS_ITERS; }
 
@@ -97,35 +97,53 @@ static double gg_deviance(gg_model* m, const double* par) {
     for (uint32_t c = 0; c < p; ++c) e += (c == 0 ? 1.0 : (double)m->x[(size_t)c * m->ld + i]) * beta[c];
     m->eta0[i] = e;
   }
+  /* joint conditional modes by Fisher scoring with step halving (see fit_glmm.c): m->u, M = L L', dev, uu, logdet
+   * belong to the ACCEPTED point, ut is the trial; a trial whose penalised deviance is not below the accepted one's is
+   * pulled half-way back to it (the undamped step 2-cycles on levels far from their prior) */
   double* u = m->u;
   memset(u, 0, sizeof(double) * R);
-  double pd_prev = INFINITY, dev = 0.0, logdet = 0.0, uu = 0.0;
-  double un[GG_MAX_R], tv[GG_MAX_R];
+  double pd_acc = INFINITY, dev = 0.0, logdet = 0.0, uu = 0.0;
+  double ut[GG_MAX_R], un[GG_MAX_R], tv[GG_MAX_R];
+  memset(ut, 0, sizeof(double) * R);
   for (int it = 0; it < gg_pirls_cap; ++it) {
     memset(m->M, 0, sizeof(double) * R * R);
     memset(m->r, 0, sizeof(double) * R);
-    dev = 0.0;
+    double devt = 0.0;
     for (uint32_t i = 0; i < m->n; ++i) {
       uint32_t idx[GG_MAX_TERMS * GG_MAX_Q];
       double val[GG_MAX_TERMS * GG_MAX_Q], au = 0.0;
       const uint32_t k = gg_row(m, T, i, idx, val);
-      for (uint32_t a = 0; a < k; ++a) au += val[a] * u[idx[a]];
+      for (uint32_t a = 0; a < k; ++a) au += val[a] * ut[idx[a]];
       double w, zw, dv;
       mcpo_fam_eval(m->fam, m->eta0[i] + au, (double)m->y[i], &w, &zw, &dv);
-      dev += dv;
+      devt += dv;
       const double res = w * (zw - m->eta0[i]);
       for (uint32_t a = 0; a < k; ++a) {
         m->r[idx[a]] += res * val[a];
         for (uint32_t b = 0; b < k; ++b) m->M[(size_t)idx[a] * R + idx[b]] += w * val[a] * val[b];
       }
     }
-    uu = 0.0;
-    for (uint32_t a = 0; a < R; ++a) { m->M[(size_t)a * R + a] += 1.0; uu += u[a] * u[a]; }
-    const double pd = dev + uu;
+    double uut = 0.0;
+    for (uint32_t a = 0; a < R; ++a) { m->M[(size_t)a * R + a] += 1.0; uut += ut[a] * ut[a]; }
+    const double pd = devt + uut, tol = 1e-13 * (fabs(pd) + 1.0);
+    if (!(pd <= pd_acc + tol)) {                     /* worse than the accepted point (or not finite): halve the step */
+      int stuck_t = 1, stuck_a = 1;
+      for (uint32_t a = 0; a < R; ++a) {
+        const double half = 0.5 * (ut[a] + u[a]);
+        if (half != ut[a]) stuck_t = 0;
+        if (half != u[a]) stuck_a = 0;
+        ut[a] = half;
+      }
+      if (stuck_t || stuck_a) break;
+      continue;                                      /* m->L still holds the accepted point's factor */
+    }
     if (gg_chol(m->M, R, m->L)) return INFINITY;
     logdet = 0.0;
     for (uint32_t a = 0; a < R; ++a) logdet += 2.0 * log(m->L[(size_t)a * R + a]);
-    if (it > 0 && fabs(pd - pd_prev) <= 1e-13 * (fabs(pd) + 1.0)) break;
+    const int conv = fabs(pd_acc - pd) <= tol;       /* pd_acc = inf on the first pass: never */
+    memcpy(u, ut, sizeof(double) * R);
+    dev = devt; uu = uut; pd_acc = pd;
+    if (conv) break;
     for (uint32_t a = 0; a < R; ++a) {
       double v = m->r[a];
       for (uint32_t k = 0; k < a; ++k) v -= m->L[(size_t)a * R + k] * tv[k];
@@ -137,14 +155,11 @@ static double gg_deviance(gg_model* m, const double* par) {
       un[a] = v / m->L[(size_t)a * R + (uint32_t)a];
     }
     int same = 1;
-    for (uint32_t a = 0; a < R; ++a) {
-      if (it > 0 && pd > pd_prev) un[a] = 0.5 * (u[a] + un[a]);
-      if (un[a] != u[a]) same = 0;
-    }
-    pd_prev = pd;
+    for (uint32_t a = 0; a < R; ++a) if (un[a] != u[a]) same = 0;
     if (same) break;
-    memcpy(u, un, sizeof(double) * R);
+    memcpy(ut, un, sizeof(double) * R);
   }
+  if (!(pd_acc < INFINITY)) return INFINITY;         /* not even the prior modes evaluate */
   const double total = dev + uu + logdet;
   return isfinite(total) ? total : INFINITY;
 }
@@ -218,7 +233,7 @@ static double gg_dev_cb(void* ctx, double* par) {
   return gg_f((gg_model*)ctx, par, &scratch);
 }
 
-/* mode: MCPO_MODE_HESSIAN selects the finite-difference Hessian Wald covariance (fit_glmm.c); singular fits keep "rx" */
+/* mode: MCPO_MODE_HESSIAN selects the finite-difference Hessian Wald covariance (fit_glmm.c) over the free parameters */
 int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                 const mcpo_re_term* terms, uint32_t n_terms, const double* theta0, const double* beta0,
                                 uint32_t mode, mcpo_gen_fit* f) {
@@ -318,9 +333,10 @@ int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_
   }
   int singular = 0;
   for (uint32_t k = 0; k < m.nth; ++k) if (m.is_diag[k] && par[k] < GG_THETA_ZERO) singular = 1;
-  if (ok && (mode & MCPO_MODE_HESSIAN) && !singular) {
+  (void)singular;
+  if (ok && (mode & MCPO_MODE_HESSIAN)) { /* over the free parameters (fit_glmm_slopes.c): pinned diagonals are even points */
     uint8_t th_free[12];
-    for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = 1;
+    for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = !(m.is_diag[k] && par[k] < GG_THETA_ZERO);
     double lh[MCPO_MAX_P * MCPO_MAX_P];
     if (mcpo_fd_hessian_factor(gg_dev_cb, &m, par, m.nth, p, th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
   }

@@ -21,7 +21,7 @@
 #define GS_MAX_EVAL 12000
 #define GS_THETA_MAX 32.0
 #define GS_THETA_ZERO 1e-6
-#define GS_PIRLS_ITERS 40
+#define GS_PIRLS_ITERS 60
 
 typedef struct gs_model {
   int fam;
@@ -80,10 +80,12 @@ static double gs_deviance(gs_model* m, const double* par) {
     double* Lm = m->Lm + (size_t)c * q * q;
     for (uint32_t b = 0; b < q; ++b) u[b] = 0.0;
     if (lo == hi) { for (uint32_t b = 0; b < q * q; ++b) Lm[b] = b % (q + 1) == 0 ? 1.0 : 0.0; continue; }
-    double pd_prev = INFINITY, dev = 0.0, logdet = 0.0;
+    /* Fisher scoring with step halving (see fit_glmm.c): (u, Lm, dev, logdet) belong to the ACCEPTED point, ut is the
+     * trial; a trial whose penalised deviance is not below the accepted one's is pulled half-way back to it */
+    double pd_acc = INFINITY, dev = 0.0, logdet = 0.0, ut[GS_MAX_Q] = {0};
     for (int it = 0; it < GS_PIRLS_ITERS; ++it) {
       double M[GS_MAX_Q * GS_MAX_Q] = {0}, r[GS_MAX_Q] = {0};
-      dev = 0.0;
+      double devt = 0.0;
       for (uint32_t k = lo; k < hi; ++k) {
         uint32_t i = m->rows[k];
         double z[GS_MAX_Q], a[GS_MAX_Q];
@@ -94,11 +96,11 @@ static double gs_deviance(gs_model* m, const double* par) {
           double s = 0.0;
           for (uint32_t d = b; d < q; ++d) s += T[d][b] * z[d];
           a[b] = s;
-          au += s * u[b];
+          au += s * ut[b];
         }
         double w, zw, dv;
         mcpo_fam_eval(m->fam, m->eta0[i] + au, (double)m->y[i], &w, &zw, &dv);
-        dev += dv;
+        devt += dv;
         const double res = w * (zw - m->eta0[i]);
         for (uint32_t b = 0; b < q; ++b) {
           r[b] += res * a[b];
@@ -107,12 +109,26 @@ static double gs_deviance(gs_model* m, const double* par) {
       }
       for (uint32_t b = 0; b < q; ++b) { M[b * q + b] += 1.0; for (uint32_t d = b + 1; d < q; ++d) M[b * q + d] = M[d * q + b]; }
       double uu = 0.0;
-      for (uint32_t b = 0; b < q; ++b) uu += u[b] * u[b];
-      const double pd = dev + uu;
+      for (uint32_t b = 0; b < q; ++b) uu += ut[b] * ut[b];
+      const double pd = devt + uu, tol = 1e-13 * (fabs(pd) + 1.0);
+      if (!(pd <= pd_acc + tol)) {                   /* worse than the accepted point (or not finite): halve the step */
+        int stuck_t = 1, stuck_a = 1;
+        for (uint32_t b = 0; b < q; ++b) {
+          const double half = 0.5 * (ut[b] + u[b]);
+          if (half != ut[b]) stuck_t = 0;
+          if (half != u[b]) stuck_a = 0;
+          ut[b] = half;
+        }
+        if (stuck_t || stuck_a) break;
+        continue;
+      }
       if (gs_chol(M, q, Lm)) return INFINITY;
       logdet = 0.0;
       for (uint32_t b = 0; b < q; ++b) logdet += 2.0 * log(Lm[b * q + b]);
-      if (it > 0 && fabs(pd - pd_prev) <= 1e-13 * (fabs(pd) + 1.0)) break;
+      const int conv = fabs(pd_acc - pd) <= tol;     /* pd_acc = inf on the first pass: never */
+      for (uint32_t b = 0; b < q; ++b) u[b] = ut[b];
+      dev = devt; pd_acc = pd;
+      if (conv) break;
       double un[GS_MAX_Q], t[GS_MAX_Q];
       for (uint32_t b = 0; b < q; ++b) { /* forward, then back substitution */
         double v = r[b];
@@ -125,14 +141,11 @@ static double gs_deviance(gs_model* m, const double* par) {
         un[b] = v / Lm[(uint32_t)b * q + (uint32_t)b];
       }
       int same = 1;
-      for (uint32_t b = 0; b < q; ++b) {
-        if (it > 0 && pd > pd_prev) un[b] = 0.5 * (u[b] + un[b]);
-        if (un[b] != u[b]) same = 0;
-      }
-      pd_prev = pd;
+      for (uint32_t b = 0; b < q; ++b) if (un[b] != u[b]) same = 0;
       if (same) break;
-      for (uint32_t b = 0; b < q; ++b) u[b] = un[b];
+      for (uint32_t b = 0; b < q; ++b) ut[b] = un[b];
     }
+    if (!(pd_acc < INFINITY)) return INFINITY;       /* not even the prior mode evaluates */
     double uu = 0.0;
     for (uint32_t b = 0; b < q; ++b) uu += u[b] * u[b];
     total += dev + uu + logdet;
@@ -328,9 +341,14 @@ int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint
   }
   int singular = 0;
   for (uint32_t k = 0; k < m.nth; ++k) if (is_diag[k] && par[k] < GS_THETA_ZERO) singular = 1;
-  if (ok && (mode & MCPO_MODE_HESSIAN) && !singular) { /* a singular fit, or a block that does not factor, keeps "rx" */
+  (void)singular;
+  if (ok && (mode & MCPO_MODE_HESSIAN)) {
+    /* the stencil runs over the FREE covariance parameters and beta: a diagonal pinned at 0 sits at an even point of the
+     * deviance (flipping the sign of a column of Lambda only relabels u), so its cross-derivatives vanish and leaving it
+     * out changes nothing in the beta block; the coupling with the remaining parameters is what "rx" ignores.  A block
+     * that does not factor keeps "rx". */
     uint8_t th_free[6];
-    for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = 1;
+    for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = !(is_diag[k] && par[k] < GS_THETA_ZERO);
     gs_cb cb = {&m, is_diag};
     double lh[MCPO_MAX_P * MCPO_MAX_P];
     if (mcpo_fd_hessian_factor(gs_dev_cb, &cb, par, m.nth, p, th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);

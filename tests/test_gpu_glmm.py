@@ -174,7 +174,7 @@ def test_glmm_extra_groupings_two_predictors_test_formula_and_counts(engine, ora
 
 def test_glmm_extra_groupings_hessian_wald_se(engine, oracle):
     """Wald SE mode "hessian" through the joint-mode kernel: interior fits get the larger, Hessian-based SE; singular
-    fits keep "rx" (vcov.merMod's fallback); statistics against the oracle at the stencil's amplification (2e-3)."""
+    fits difference over their free parameters (a block that does not factor keeps "rx"); statistics against the oracle at the stencil's amplification (2e-3)."""
     spec, _, a, low = load_case("glmm_slope_crossed")
     spec.cluster.tau_squared = 1.2
     spec.cluster.slopes = [{"column": 0, "variance": 0.6, "corr_with_intercept": 0.2, "corr_with": []}]
@@ -192,8 +192,8 @@ def test_glmm_extra_groupings_hessian_wald_se(engine, oracle):
     assert np.array_equal(dev.converged, rx.converged) and np.array_equal(dev.pinned_components, rx.pinned_components)
     interior = ok & (dev.pinned_components[:, 0] == 0)
     assert interior.sum() >= 4 and np.all(stat[interior] < stat_rx[interior])
-    singular = ok & (dev.pinned_components[:, 0] != 0)
-    assert np.array_equal(stat[singular], stat_rx[singular])
+    singular = ok & (dev.pinned_components[:, 0] != 0)  # the stencil runs over the free parameters: never smaller SEs
+    assert np.all(stat[singular] <= stat_rx[singular])
 
 
 def test_glmm_extra_groupings_reference_capture_and_grid(engine, oracle):
@@ -293,8 +293,8 @@ def test_glmm_hessian_wald_se_matches_oracle(name, engine, oracle):
     assert np.array_equal(dev.converged, rx.converged) and np.array_equal(dev.pinned_components, rx.pinned_components)
     interior = ok & (dev.pinned_components[:, 0] == 0)
     assert np.all(stat[interior] < stat_rx[interior])            # Hessian SEs are the larger ones
-    singular = ok & (dev.pinned_components[:, 0] != 0)
-    assert np.array_equal(stat[singular], stat_rx[singular])     # vcov.merMod's fallback
+    singular = ok & (dev.pinned_components[:, 0] != 0)           # pinned components drop out of the stencil, the coupling
+    assert np.all(stat[singular] <= stat_rx[singular])           # with the free ones stays ("rx" only if H does not factor)
 
 
 # ---- adaptive Gauss-Hermite quadrature (spec.nagq) ----

@@ -547,6 +547,29 @@ def test_c5_grid_sweep_optimistic_matches_oracle(engine, oracle):
     assert (np.diff(ku.astype(np.int64)) >= -25).all() and ku[-1] > 0.99 * 1000
 
 
+@pytest.mark.parametrize("name", ["realistic", "doomer"])
+def test_c5_grid_sweep_under_the_robustness_presets_matches_oracle(name, engine, oracle):
+    """BASELINE configs[4] on the device, preset by preset: the C2b design on the FULL grid N = 50..1000 (20 prefix fits
+    per replicate on shared draws) under the reference bench's frozen realistic / doomer presets
+    (throughput.rs:76-132) -- per-replicate design perturbation, marginal / residual swaps, per-study effects,
+    heteroskedastic scaling.  Decisions equal the oracle's up to the general path's one-ulp band (<= 2 flags of
+    1 200 x 20 x 2), counters within 2, and the counters-only form equals the per-sim one bit for bit."""
+    from helpers import C5_GRID, preset
+    spec = spec_c2b()
+    spec.scenario = preset(name)
+    n_sims = 1200
+    g = engine.run_batch(spec, C5_GRID, n_sims, BASE_SEED)
+    o = oracle.run_batch(spec, C5_GRID, n_sims, BASE_SEED, n_threads=8)
+    assert g.uncorrected.shape == (n_sims, 20, 2)
+    assert (g.uncorrected != o.uncorrected).sum() <= 2 and (g.corrected != o.corrected).sum() <= 2
+    assert np.array_equal(g.converged, o.converged)
+    assert np.abs(g.counters.astype(np.int64) - o.counters.astype(np.int64)).max() <= 2
+    red = engine.run_batch(spec, C5_GRID, n_sims, BASE_SEED, per_sim=False)
+    assert np.array_equal(red.counters, g.counters)
+    ku = g.counter("k_unc", 2)[:, 0].astype(np.int64)
+    assert ku[-1] > ku[0] and (np.diff(ku) >= -40).all()      # power rises along the grid (shared draws: nearly monotone)
+
+
 # ---------------------------------------------------------------------------------------------
 # probit / Poisson GLM families
 # ---------------------------------------------------------------------------------------------

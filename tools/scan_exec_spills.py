@@ -23,7 +23,7 @@ RESTORE = re.compile(r"\ts_or_b64 exec, exec, (s\[\d+:\d+\])")
 RESTORE_MOV = re.compile(r"\ts_mov_b64 exec, (s\[\d+:\d+\])")
 SDEST = re.compile(r"\ts_\w+ (s\[\d+:\d+\]), ")
 SPILL = re.compile(r"\tscratch_store_dword(?:x(\d))? off, (v\[(\d+):(\d+)\]|v(\d+)), .*Folded Spill")
-DEF = re.compile(r"\t(?:v_|ds_read|ds_bpermute|scratch_load|global_load|buffer_load|flat_load)\S* (v\[(\d+):(\d+)\]|v(\d+))\b")
+DEF = re.compile(r"\t(?:v_|ds_read|ds_bpermute|ds_permute|ds_swizzle|scratch_load|global_load|buffer_load|flat_load|global_atomic|ds_add_rtn)\S* (v\[(\d+):(\d+)\]|v(\d+))(?=[,\s])")
 FUNC = re.compile(r"^(_Z\w+):")
 
 
