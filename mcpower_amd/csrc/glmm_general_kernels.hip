@@ -42,7 +42,7 @@ typedef __attribute__((address_space(3))) float gdf;
 typedef __attribute__((address_space(3))) uint16_t gdu;
 
 struct GlmmLds {
-  gdd *eta0, *wrow, *res, *M, *u, *ut, *r, *un, *C, *T, *av, *simplex, *fv, *tail;
+  gdd *eta0, *wrow, *res, *M, *u, *ut, *r, *un, *C, *T, *av, *simplex, *fv, *tail, *lx;
   uint32_t ao[GG_MAX_TERMS];  // plane of term t's first entry in av (planes of n_pad rows)
   gdf *design, *draws;
   gdu* lvl;          // level of a row in extra term t at lvl[(t - 1) * n_pad + i]
@@ -55,6 +55,9 @@ struct GlmmLds {
 };
 
 __device__ __forceinline__ void gq_sync() { __syncthreads(); }
+
+// entry t of a 3-entry table held in registers: constant indices only, so the table never lands in scratch
+__device__ __forceinline__ uint32_t pick3(const uint32_t (&a)[3], uint32_t t) { return t == 0u ? a[0] : (t == 1u ? a[1] : a[2]); }
 
 __device__ __forceinline__ double gq_wave_sum(double v) {
 #pragma unroll
@@ -102,7 +105,7 @@ template <int P>
 __device__ __forceinline__ uint32_t gg_row_term(const SimParams& prm, const GlmmLds& m, uint32_t t, uint32_t i, uint32_t n_pad,
                                                 double (&a)[3]) {
   const uint32_t q = prm.lmg_q[t];
-  const gdd* av = m.av + (size_t)m.ao[t] * n_pad + i;
+  const gdd* av = m.av + (size_t)pick3(m.ao, t) * n_pad + i;
   a[0] = av[0];
   a[1] = q > 1u ? av[n_pad] : 0.0;
   a[2] = q > 2u ? av[2u * n_pad] : 0.0;
@@ -115,7 +118,7 @@ __device__ __forceinline__ uint32_t gg_row_term(const SimParams& prm, const Glmm
 // then divides -- the operation sequence of the plain right-looking loop).  Phase 2: lanes over the (row, column)
 // pairs of the dense block subtract the primary columns' products, ascending.  Phase 3: right-looking on the dense
 // block, lane = row.  log|.| sums the pivots in index order.
-__device__ __noinline__ bool gg_chol(gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, uint32_t lane, gdd* tmp,
+__device__ __forceinline__ bool gg_chol(gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, uint32_t lane, gdd* tmp,
                                      double& logdet) {
   bool ok = true;
   const uint32_t L0 = R0 / q0, Re = R - R0;
@@ -196,7 +199,7 @@ __device__ __noinline__ bool gg_chol(gdd* M, uint32_t R, uint32_t RS, uint32_t R
 
 // L x = b in place (b: nrhs columns, row stride bs): primary blocks by their lanes, the dense rows' products with them
 // in ascending column order, then the dense block column by column -- every entry subtracts in the dot product's order
-__device__ __noinline__ void gg_forward(const gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, gdd* b, uint32_t bs,
+__device__ __forceinline__ void gg_forward(const gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, gdd* b, uint32_t bs,
                                         uint32_t nrhs, uint32_t lane) {
   const uint32_t L0 = R0 / q0;
   gq_sync();
@@ -236,7 +239,7 @@ __device__ __noinline__ void gg_forward(const gdd* M, uint32_t R, uint32_t RS, u
 }
 
 // L' x = t (t in r, consumed; x to un): the dense block from the bottom, then every primary block by its lane
-__device__ __noinline__ void gg_backward(const gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, gdd* r, gdd* un,
+__device__ __forceinline__ void gg_backward(const gdd* M, uint32_t R, uint32_t RS, uint32_t R0, uint32_t q0, gdd* r, gdd* un,
                                          uint32_t lane) {
   for (uint32_t kk = R; kk-- > R0;) {
     gq_sync();
@@ -268,7 +271,7 @@ __device__ __noinline__ void gg_backward(const gdd* M, uint32_t R, uint32_t RS, 
 
 // Laplace deviance at par = (theta vech per term, beta); leaves the modes in m.u and the factor of I + A'WA in m.M
 template <int P>
-__device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
+__device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds& m, const gdd* par, uint32_t lane, uint32_t n,
                                          uint32_t ncl, uint32_t n_pad, uint32_t keep) {
   const uint32_t fam = prm.glm_family, nterms = prm.lmg_n_terms, nth = prm.lmg_n_theta, R = m.R, RS = m.RS;
   const uint32_t cv = prm.cluster_v;
@@ -307,7 +310,7 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
       gg_row_term_compute<P>(prm, m, t, i, n_pad, a);
 #pragma unroll
       for (int b = 0; b < 3; ++b)  // static indices: a[] stays in registers
-        if ((uint32_t)b < prm.lmg_q[t]) m.av[(size_t)(m.ao[t] + (uint32_t)b) * n_pad + i] = a[b];
+        if ((uint32_t)b < prm.lmg_q[t]) m.av[(size_t)(pick3(m.ao, t) + (uint32_t)b) * n_pad + i] = a[b];
     }
   gq_sync();
   // joint conditional modes by Fisher scoring with step halving (oracle/fit_glmm_general.c): m.u, the factor in m.M, dev,
@@ -324,7 +327,7 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
       for (uint32_t t = 0; t < nterms; ++t) {
         double a[3];
         const uint32_t l = gg_row_term<P>(prm, m, t, i, n_pad, a);
-        const gdd* utp = m.ut + m.off[t] + l * prm.lmg_q[t];
+        const gdd* utp = m.ut + pick3(m.off, t) + l * prm.lmg_q[t];
         au += a[0] * utp[0];
         if (prm.lmg_q[t] > 1u) au += a[1] * utp[1];
         if (prm.lmg_q[t] > 2u) au += a[2] * utp[2];
@@ -367,7 +370,7 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
         const uint32_t l = lane / ns, sub = lane % ns;
         double rl[3] = {0.0, 0.0, 0.0}, bl[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
         if (l < nl) {
-          const uint32_t first = (uint32_t)m.lstart[m.so[t] + l], last = (uint32_t)m.lstart[m.so[t] + l + 1u];
+          const uint32_t first = (uint32_t)m.lstart[pick3(m.so, t) + l], last = (uint32_t)m.lstart[pick3(m.so, t) + l + 1u];
           const uint32_t chunk = (last - first + ns - 1u) / ns;
           const uint32_t lo = first + sub * chunk, hi = lo + chunk < last ? lo + chunk : last;
           for (uint32_t s = lo; s < hi; ++s) {
@@ -401,7 +404,7 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
           }
         }
         if (sub == 0u && l < nl) {
-          const uint32_t colbase = m.off[t] + l * q;
+          const uint32_t colbase = pick3(m.off, t) + l * q;
           #pragma unroll
           for (int b = 0; b < 3; ++b)
             if ((uint32_t)b < q) {
@@ -417,11 +420,11 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
       for (uint32_t l = lane; l < nl; l += QW) {
         double rl[3] = {0.0, 0.0, 0.0}, bl[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
         // rows of the level: an arithmetic progression for the primary grouping, the level's slice of the row list else
-        const uint32_t first = t == 0u ? (prm.cluster_fixed_clusters ? l : l * cv) : (uint32_t)m.lstart[m.so[t] + l];
+        const uint32_t first = t == 0u ? (prm.cluster_fixed_clusters ? l : l * cv) : (uint32_t)m.lstart[pick3(m.so, t) + l];
         const uint32_t step = t == 0u ? (prm.cluster_fixed_clusters ? cv : 1u) : 1u;
         const uint32_t last = t == 0u ? (prm.cluster_fixed_clusters ? n : ((l + 1u) * cv < n ? (l + 1u) * cv : n))
-                                      : (uint32_t)m.lstart[m.so[t] + l + 1u];
-        const uint32_t colbase = m.off[t] + l * q;
+                                      : (uint32_t)m.lstart[pick3(m.so, t) + l + 1u];
+        const uint32_t colbase = pick3(m.off, t) + l * q;
         for (uint32_t s = first; s < last; s += step) {
           const uint32_t i = t == 0u ? s : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + s];
           if (i >= n) break;  // ascending within a level: the rest lies past this grid point's sample
@@ -438,7 +441,7 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
           for (uint32_t t2 = t + 1u; t2 < nterms; ++t2) {  // strips against later terms: rows of the later term, my columns
             double a2[3];
             const uint32_t l2 = gg_row_term<P>(prm, m, t2, i, n_pad, a2);
-            const uint32_t q2 = prm.lmg_q[t2], rowbase = m.off[t2] + l2 * q2;
+            const uint32_t q2 = prm.lmg_q[t2], rowbase = pick3(m.off, t2) + l2 * q2;
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2)
 #pragma unroll
@@ -489,124 +492,17 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
   return (ok && total < __builtin_inf() && total > -__builtin_inf()) ? total : __builtin_inf();
 }
 
-template <int P>
-__device__ __forceinline__ double glmm_f(const SimParams& prm, const GlmmLds& m, gdd* x, uint32_t lane, uint32_t n, uint32_t ncl,
-                                         uint32_t n_pad, uint32_t keep, uint32_t& n_eval) {
-  const uint32_t nth = prm.lmg_n_theta;
-  if (lane < nth + (uint32_t)__popc(keep)) {
-    double v = x[lane];
-    if (lane < nth) {
-      if ((m.diag_mask >> lane) & 1u) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
-      else v = v < -GLMM_THETA_MAX ? -GLMM_THETA_MAX : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
-    } else {
-      v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
-    }
-    x[lane] = v;
-  }
-  gq_sync();
-  ++n_eval;
-  return glmm_eval<P>(prm, m, x, lane, n, ncl, n_pad, keep);
-}
-
-// one Nelder-Mead run from simplex row 0 with initial edge `step`; the best point ends in row 0
-template <int P>
-__device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const GlmmLds m, double step, double ftol, double xtol,
-                                                uint32_t lane, uint32_t n, uint32_t ncl, uint32_t n_pad, uint32_t keep,
-                                                uint32_t& n_eval) {
-  const uint32_t d = prm.lmg_n_theta + (uint32_t)__popc(keep);
-  gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe
-  gdd* fv = m.fv;
-  gdd* cen = sx + (size_t)(d + 1u) * GLMM_ROW;
-  gdd* xr = cen + GLMM_ROW;
-  gdd* xe = xr + GLMM_ROW;
-  const double inf = __builtin_inf();
-  const double f0 = glmm_f<P>(prm, m, sx, lane, n, ncl, n_pad, keep, n_eval);
-  if (lane == 0u) fv[0] = f0;
-  for (uint32_t i = 0; i < d; ++i) {
-    gdd* v = sx + (size_t)(i + 1u) * GLMM_ROW;
-    if (lane < d) v[lane] = sx[lane] + (lane == i ? step : 0.0);
-    gq_sync();
-    const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
-    if (lane == 0u) fv[i + 1u] = fi;
-  }
-  gq_sync();
-  while (n_eval < GLMM_MAX_EVAL) {
-    uint32_t lo = 0, hi = 0;
-    for (uint32_t i = 1; i <= d; ++i) {
-      if (fv[i] < fv[lo]) lo = i;
-      if (fv[i] > fv[hi]) hi = i;
-    }
-    uint32_t nh = lo;
-    for (uint32_t i = 0; i <= d; ++i)
-      if (i != hi && fv[i] > fv[nh]) nh = i;
-    double size = 0.0;
-    for (uint32_t i = 0; i <= d; ++i)
-      for (uint32_t k = 0; k < d; ++k) {
-        const double dd = __builtin_fabs(sx[(size_t)i * GLMM_ROW + k] - sx[(size_t)lo * GLMM_ROW + k]);
-        size = dd > size ? dd : size;
-      }
-    if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
-    const double flo = fv[lo], fhi = fv[hi], fnh = fv[nh];
-    gq_sync();
-    if (lane < d) {
-      double s = 0.0;
-      for (uint32_t i = 0; i <= d; ++i)
-        if (i != hi) s += sx[(size_t)i * GLMM_ROW + lane];
-      const double c = s / (double)d;
-      cen[lane] = c;
-      xr[lane] = c + (c - sx[(size_t)hi * GLMM_ROW + lane]);
-    }
-    gq_sync();
-    const double fr = glmm_f<P>(prm, m, xr, lane, n, ncl, n_pad, keep, n_eval);
-    gdd* worst = sx + (size_t)hi * GLMM_ROW;
-    if (fr < flo) {
-      if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
-      gq_sync();
-      const double fe = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
-      if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
-      if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
-    } else if (fr < fnh) {
-      if (lane < d) worst[lane] = xr[lane];
-      if (lane == 0u) fv[hi] = fr;
-    } else {
-      const bool outside = fr < fhi;
-      if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
-      gq_sync();
-      const double fc = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
-      if (fc < (outside ? fr : fhi)) {
-        if (lane < d) worst[lane] = xe[lane];
-        if (lane == 0u) fv[hi] = fc;
-      } else {
-        for (uint32_t i = 0; i <= d; ++i) {
-          if (i == lo) continue;
-          gdd* v = sx + (size_t)i * GLMM_ROW;
-          if (lane < d) v[lane] = sx[(size_t)lo * GLMM_ROW + lane] + 0.5 * (v[lane] - sx[(size_t)lo * GLMM_ROW + lane]);
-          gq_sync();
-          const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
-          if (lane == 0u) fv[i] = fi;
-          gq_sync();
-        }
-      }
-    }
-    gq_sync();
-  }
-  uint32_t lo = 0;
-  for (uint32_t i = 1; i <= d; ++i)
-    if (fv[i] < fv[lo]) lo = i;
-  const double best = fv[lo];
-  gq_sync();
-  double best_k = 0.0;
-  if (lane < d) best_k = sx[(size_t)lo * GLMM_ROW + lane];
-  gq_sync();
-  if (lane < d) sx[lane] = best_k;
-  gq_sync();
-  return best;
-}
-
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 of every grouping (data_gen.rs:146-161, 1069-1092)
-#include "mcp_glmm_hessian.hpp"
-
+//
+// The fit of one grid point is ONE loop around ONE inlined evaluation of the Laplace deviance: the bounded Nelder-Mead
+// runs with their restarts, the boundary snaps, the final evaluation, the "rx" covariance and the finite-difference
+// Hessian stencil are states of a wave-uniform machine that hands the next point to that single site.  No function is
+// called: nothing is spilled around calls, the register allocator sees the whole kernel (one wave per workgroup: up to
+// 512 VGPRs) and the kernel runs without scratch.  (The call-structured version spent 1 072 B / lane of scratch and
+// wrote 36 GB per 4 000 fits of it; worse, hipcc placed a spill of live constants inside an `if (lane == 0)` region in
+// front of a call -- stored under EXEC = lane 0, reloaded under full EXEC: DESIGN.md section 5.)  The sequence of
+// evaluated points and every floating-point operation are those of oracle/fit_glmm_general.c.
 template <int P, bool SCEN>
 __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_q[];
@@ -626,6 +522,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     m.R = prm.lmg_levels[0] * prm.lmg_q[0] + prm.lmg_R;
     m.RS = m.R | 1u;
     uint32_t nd = 0, dm = 0, k = 0;
+#pragma unroll
     for (uint32_t t = 0; t < GG_MAX_TERMS; ++t) {
       m.off[t] = t == 0u ? 0u : prm.lmg_levels[0] * prm.lmg_q[0] + prm.lmg_roff[t];
       m.doff[t] = nd;
@@ -649,6 +546,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     m.T = q; q += 28;
     {
       uint32_t na = 0;
+#pragma unroll
       for (uint32_t t = 0; t < GG_MAX_TERMS; ++t) {
         m.ao[t] = na;
         if (t < nterms) na += prm.lmg_q[t];
@@ -658,6 +556,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     m.simplex = q; q += (size_t)(dmax + 4u) * GLMM_ROW;
     m.fv = q; q += (dmax + 2u) & ~1u;
     m.tail = q; q += 8;
+    m.lx = q; q += 36;  // P x P factor of the Wald precision (P <= 6)
     gdf* f = (gdf*)q;
     m.design = f; f += (size_t)P * n_pad;
     m.draws = f; f += (nd + 1u) & ~1u;
@@ -666,6 +565,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     m.lstart = (gdu*)f;
     {
       uint32_t so = 0;
+#pragma unroll
       for (uint32_t t = 0; t < GG_MAX_TERMS; ++t) {
         m.so[t] = so;
         if (t >= 1u && t < nterms) so += prm.lmg_levels[t] + 2u;
@@ -683,7 +583,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
   };
   for (uint32_t t = 0; t < nterms; ++t) {
     const uint32_t q = prm.lmg_q[t], nl = prm.lmg_levels[t];
-    gdf* ux = m.draws + m.doff[t];
+    gdf* ux = m.draws + pick3(m.doff, t);
     double tau_t = prm.lmg_tau[t];
     if (SCEN && prm.scen_tau_sq) {  // realised tau per grouping (ICC jitter, data_gen.rs:1069-1092)
       const double t2 = prm.scen_tau_sq[(size_t)t * prm.scen_stride + lsim];
@@ -692,37 +592,60 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     for (uint32_t c = lane; c < nl; c += QW) ux[(size_t)c * q] = (float)(re_draw(prm.lmg_seq[2u * t] + c) * tau_t);
     gq_sync();
     if (q > 1u) {
-      double lt[9];
+      // 3 x 3 frame with constant indices (entries beyond q stay 0): the factor lives in registers, not in scratch
+      double lt[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) lt[i][j] = 0.0;
       if (!SCEN) {
-        for (uint32_t i = 0; i < 9u; ++i) lt[i] = prm.lmg_chol[t][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if ((uint32_t)i < q && (uint32_t)j < q) lt[i][j] = prm.lmg_chol[t][(uint32_t)i * q + (uint32_t)j];
       } else {  // chol_lower (data_gen.rs:55-75) of the replicate's own D
         const double tv[3] = {tau_t, prm.lmg_slope_sd[t][0], prm.lmg_slope_sd[t][1]};
-        double dm[9];
-        for (uint32_t i = 0; i < 9u; ++i) lt[i] = 0.0;
-        for (uint32_t i = 0; i < q; ++i)
-          for (uint32_t j = 0; j < q; ++j) dm[i * q + j] = tv[i] * prm.lmg_recorr[t][i * q + j] * tv[j];
-        for (uint32_t j = 0; j < q; ++j) {
-          double diag = dm[j * q + j];
-          for (uint32_t k = 0; k < j; ++k) diag -= lt[j * q + k] * lt[j * q + k];
-          const double ljj = __builtin_sqrt(diag > 0.0 ? diag : 0.0);
-          lt[j * q + j] = ljj;
-          for (uint32_t i = j + 1u; i < q; ++i)
-            if (ljj > 0.0) {
-              double sacc = dm[i * q + j];
-              for (uint32_t k = 0; k < j; ++k) sacc -= lt[i * q + k] * lt[j * q + k];
-              lt[i * q + j] = sacc / ljj;
-            }
-        }
+        double dm[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            dm[i][j] = ((uint32_t)i < q && (uint32_t)j < q) ? tv[i] * prm.lmg_recorr[t][(uint32_t)i * q + (uint32_t)j] * tv[j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if ((uint32_t)j < q) {
+            double diag = dm[j][j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              if (k < j) diag -= lt[j][k] * lt[j][k];
+            const double ljj = __builtin_sqrt(diag > 0.0 ? diag : 0.0);
+            lt[j][j] = ljj;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (i > j && (uint32_t)i < q && ljj > 0.0) {
+                double sacc = dm[i][j];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                  if (k < j) sacc -= lt[i][k] * lt[j][k];
+                lt[i][j] = sacc / ljj;
+              }
+          }
       }
       for (uint32_t c = lane; c < nl; c += QW) {
         double z[3];
         z[0] = tau_t > 0.0 ? (double)ux[(size_t)c * q] / tau_t : 0.0;
-        for (uint32_t j = 1; j < q; ++j) z[j] = re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u) + (j - 1u));
-        for (uint32_t k = 1; k < q; ++k) {
-          double uk = 0.0;
-          for (uint32_t j = 0; j <= k; ++j) uk += lt[k * q + j] * z[j];
-          ux[(size_t)c * q + k] = (float)uk;
-        }
+        z[1] = q > 1u ? re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u)) : 0.0;
+        z[2] = q > 2u ? re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u) + 1u) : 0.0;
+#pragma unroll
+        for (int k = 1; k < 3; ++k)
+          if ((uint32_t)k < q) {
+            double uk = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              if (j <= k) uk += lt[k][j] * z[j];
+            ux[(size_t)c * q + (uint32_t)k] = (float)uk;
+          }
       }
     }
     gq_sync();
@@ -733,7 +656,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
   for (uint32_t t = 1; t < nterms; ++t) {  // counting sort of the rows by level, once per replicate
     const uint32_t nl = prm.lmg_levels[t];
     const gdu* lv = m.lvl + (size_t)(t - 1u) * n_pad;
-    gdu* ls = m.lstart + m.so[t];
+    gdu* ls = m.lstart + pick3(m.so, t);
     for (uint32_t l = lane; l < nl; l += QW) {
       uint32_t cnt = 0;
       for (uint32_t i = 0; i < max_n; ++i) cnt += (uint32_t)lv[i] == l ? 1u : 0u;
@@ -761,7 +684,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     double u_re = (double)m.draws[(size_t)cid * q0];
     for (uint32_t t = 1; t < nterms; ++t) {
       const uint32_t q = prm.lmg_q[t], lv = (uint32_t)m.lvl[(size_t)(t - 1u) * n_pad + rr];
-      const gdf* ux = m.draws + m.doff[t] + (size_t)lv * q;
+      const gdf* ux = m.draws + pick3(m.doff, t) + (size_t)lv * q;
       u_re += (double)ux[0];
       for (uint32_t s2 = 1; s2 < q; ++s2) {
         float xv = 0.0f;
@@ -859,115 +782,18 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
         if ((keep >> c) & 1u) x0[k++] = prm.beta[c];                      // beta starts at the truth, unconditionally
     }
     gq_sync();
-    uint32_t n_eval = 0;
-    double best = glmm_nelder_mead<P>(prm, m, 0.25, 1e-9, 1e-6, lane, n, ncl, n_pad, keep, n_eval);
-    for (int restart = 0; restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
-      const double prev = best;
-      best = glmm_nelder_mead<P>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
-      if (!(prev - best > 1e-8)) break;
-    }
-    double cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
-    for (uint32_t k = 0; k < nth; ++k) {
-      if (!((m.diag_mask >> k) & 1u)) continue;
-      const double th_keep = x0[k];
-      if (th_keep != 0.0 && th_keep <= 1e-4) {  // snap onto the boundary when that costs no deviance
-        gq_sync();
-        if (lane == 0u) x0[k] = 0.0;
-        gq_sync();
-        const double f0 = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
-        if (f0 <= cur + 1e-8) cur = f0;
-        else {
-          gq_sync();
-          if (lane == 0u) x0[k] = th_keep;
-          gq_sync();
-        }
-      }
-    }
-    cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);  // modes and the factor of the final point
-    bool ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
-    // ---- RX'RX = X'WX - C' (I + A'WA)^-1 C, C = A'WX (R x P): weights at the final modes, C folded by its owners ----
-    double A[P * (P + 1) / 2];
-#pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = 0.0;
-    for (uint32_t i = lane; i < n; i += QW) {
-      // weights at the FINAL modes, as oracle/fit_glmm_general.c:275-287: equal to the last Fisher step's whenever the
-      // step loop ended on a convergence test (the modes did not move after that step); when it ran into its
-      // iteration cap the modes moved once more after the factor was formed, and the weights follow them
-      double au = 0.0;
-      for (uint32_t t = 0; t < nterms; ++t) {
-        double a[3];
-        const uint32_t l = gg_row_term<P>(prm, m, t, i, n_pad, a);
-        const gdd* ut = m.u + m.off[t] + l * prm.lmg_q[t];
-        au += a[0] * ut[0];
-        if (prm.lmg_q[t] > 1u) au += a[1] * ut[1];
-        if (prm.lmg_q[t] > 2u) au += a[2] * ut[2];
-      }
-      double w, wz, dv;
-      fam_eval(prm.glm_family, m.eta0[i] + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
-      m.wrow[i] = w;
-      double xd[P];
-      xd[0] = 1.0;
-#pragma unroll
-      for (int r = 1; r < P; ++r) xd[r] = (double)m.design[(size_t)(r - 1) * n_pad + i];
-      int idx = 0;
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) A[idx++] += w * xd[r] * xd[s2];
-    }
-    for (uint32_t e = lane; e < m.R * (uint32_t)P; e += QW) m.C[e] = 0.0;
-    gq_sync();
-    for (uint32_t t = 0; t < nterms; ++t) {
-      const uint32_t q = prm.lmg_q[t], nl = t == 0u ? ncl : prm.lmg_levels[t];
-      for (uint32_t l = lane; l < nl; l += QW) {
-        double cl[3][P];
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-          for (int r = 0; r < P; ++r) cl[b][r] = 0.0;
-        // rows of the level: an arithmetic progression for the primary grouping, the level's slice of the row list else
-        const uint32_t first = t == 0u ? (prm.cluster_fixed_clusters ? l : l * cv) : (uint32_t)m.lstart[m.so[t] + l];
-        const uint32_t step = t == 0u ? (prm.cluster_fixed_clusters ? cv : 1u) : 1u;
-        const uint32_t last = t == 0u ? (prm.cluster_fixed_clusters ? n : ((l + 1u) * cv < n ? (l + 1u) * cv : n))
-                                      : (uint32_t)m.lstart[m.so[t] + l + 1u];
-        for (uint32_t s = first; s < last; s += step) {
-          const uint32_t i = t == 0u ? s : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + s];
-          if (i >= n) break;  // ascending within a level: the rest lies past this grid point's sample
-          double a[3];
-          gg_row_term<P>(prm, m, t, i, n_pad, a);
-          const double w = m.wrow[i];
-#pragma unroll
-          for (int r = 0; r < P; ++r) {
-            const double xr = r == 0 ? 1.0 : (double)m.design[(size_t)(r - 1) * n_pad + i];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) cl[b][r] += w * a[b] * xr;
-          }
-        }
-        const uint32_t base = m.off[t] + l * q;
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          if ((uint32_t)b < q)
-#pragma unroll
-            for (int r = 0; r < P; ++r) m.C[(size_t)(base + b) * P + r] = cl[b][r];
-      }
-    }
-    gq_sync();
-    gg_forward(m.M, m.R, m.RS, m.off[1], prm.lmg_q[0], m.C, (uint32_t)P, (uint32_t)P, lane);  // D = L^-1 C
-    {
-      double dd[P * (P + 1) / 2];
-#pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) dd[i] = 0.0;
-      for (uint32_t a = lane; a < m.R; a += QW) {
-        int idx = 0;
-#pragma unroll
-        for (int r = 0; r < P; ++r)
-#pragma unroll
-          for (int s2 = 0; s2 <= r; ++s2) dd[idx++] += m.C[(size_t)a * P + r] * m.C[(size_t)a * P + s2];
-      }
-#pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]) - gq_wave_sum(dd[i]);
-    }
-    double Lx[P][P];
+    // ---- the fit: a wave-uniform state machine around the single evaluation site ----
+    enum : int { S_NM_BEGIN, S_NM_F0, S_NM_INIT_SETUP, S_NM_INIT_F, S_NM_LOOP, S_NM_FR, S_NM_FE, S_NM_FC, S_NM_SHRINK_SETUP,
+                 S_NM_SHRINK_F, S_NM_END, S_CUR, S_CUR_F, S_SNAP_SETUP, S_SNAP_F, S_FINAL, S_FINAL_F, S_HESS_A,
+                 S_HESS_DIAG_SETUP, S_HESS_DIAG_F, S_HESS_OFF_B, S_HESS_OFF_SETUP, S_HESS_OFF_F, S_HESS_SOLVE, S_DECIDE };
+    const uint32_t d = nth + (uint32_t)__popc(keep);
+    gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe (= the stencil point of the Hessian); rows 1..d hold H later
+    gdd* fv = m.fv;
+    gdd* cen = sx + (size_t)(d + 1u) * GLMM_ROW;
+    gdd* xr = cen + GLMM_ROW;
+    gdd* xe = xr + GLMM_ROW;
+    gdd* Hm = sx + GLMM_ROW;  // H[a][b] at Hm[a * GLMM_ROW + b]
+    const double inf = __builtin_inf(), dl = 1e-4;
     // lower Cholesky factor of a packed precision matrix over the kept columns; a dropped column is an identity row /
     // column: the kept block factors as the gathered system
     auto factor = [&](const double (&Ap)[P * (P + 1) / 2], double (&L)[P][P]) -> bool {
@@ -977,9 +803,9 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
 #pragma unroll
       for (int r = 0; r < P; ++r)
 #pragma unroll
-        for (int s = 0; s <= r; ++s) {
+        for (int s2 = 0; s2 <= r; ++s2) {
           const double v = Ap[idx++];
-          Af[r][s] = (((keep >> r) & 1u) && ((keep >> s) & 1u)) ? v : (r == s ? 1.0 : 0.0);
+          Af[r][s2] = (((keep >> r) & 1u) && ((keep >> s2) & 1u)) ? v : (r == s2 ? 1.0 : 0.0);
         }
 #pragma unroll
       for (int j = 0; j < P; ++j) {
@@ -998,41 +824,427 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
       }
       return fok;
     };
-    ok = factor(A, Lx) && ok;
-    if (prm.glmm_hessian && ok) {
-      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp) over the FREE covariance parameters and beta (a pinned diagonal is
-      // an even point of the deviance and drops out); a block that does not factor keeps "rx"
-      uint32_t th_free = 0u;
-      for (uint32_t k = 0; k < nth; ++k) th_free |= (((m.diag_mask >> k) & 1u) && x0[k] < GLMM_THETA_ZERO) ? 0u : (1u << k);
-      auto fdev = [&](gdd* pt) -> double {
-        uint32_t scratch = 0;
-        return glmm_f<P>(prm, m, pt, lane, n, ncl, n_pad, keep, scratch);
-      };
-      const uint32_t nth_h = nth, d_h = nth_h + (uint32_t)__popc(keep);
-      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane, th_free)) {
-        double Ah[P * (P + 1) / 2], Lh[P][P];
-        const gdd* Hs = m.simplex + GLMM_ROW;
-        int idx = 0;
-        uint32_t kr = 0;
+    auto store_factor = [&](const double (&L)[P][P]) {
+      if (lane == 0u) {
 #pragma unroll
-        for (int r = 0; r < P; ++r) {
-          uint32_t kc = 0;
+        for (int r = 0; r < P; ++r)
 #pragma unroll
-          for (int s = 0; s <= r; ++s) {
-            const bool both = ((keep >> r) & 1u) && ((keep >> s) & 1u);
-            Ah[idx++] = both ? Hs[(size_t)(nth_h + kr) * GLMM_ROW + nth_h + kc] : 0.0;
-            kc += ((keep >> s) & 1u) ? 1u : 0u;
-          }
-          kr += ((keep >> r) & 1u) ? 1u : 0u;
-        }
-        if (factor(Ah, Lh)) {
+          for (int s2 = 0; s2 < P; ++s2) m.lx[r * P + s2] = s2 <= r ? L[r][s2] : 0.0;
+      }
+      gq_sync();
+    };
+    int st = S_NM_BEGIN, run = 0, restart = 0;
+    uint32_t n_eval = 0, vi = 0, lo = 0, hi = 0, snap_k = 0, ha = 0, hb = 0, th_free = 0u;
+    int hq = 0;
+    double nm_step = 0.25, ftol = 1e-9, xtol = 1e-6, best = 0.0, prev = 0.0, cur = 0.0, f = 0.0;
+    double flo = 0.0, fhi = 0.0, fnh = 0.0, fr = 0.0, th_keep = 0.0, fadd = 0.0, fsub = 0.0, hacc = 0.0;
+    bool outside = false, ok = false, count = true;
+    gdd* pt = sx;
+    for (;;) {
+      // ---- advance: consume f (the deviance at pt) and set up the next point, until a state asks for an evaluation ----
+      bool need = false;
+      while (!need && st != S_DECIDE) {
+        switch (st) {
+          case S_NM_BEGIN:  // one bounded Nelder-Mead run from simplex row 0 with initial edge nm_step
+            pt = sx; count = true; need = true; st = S_NM_F0;
+            break;
+          case S_NM_F0:
+            if (lane == 0u) fv[0] = f;
+            vi = 0; st = S_NM_INIT_SETUP;
+            break;
+          case S_NM_INIT_SETUP:
+            if (vi < d) {
+              gdd* v = sx + (size_t)(vi + 1u) * GLMM_ROW;
+              if (lane < d) v[lane] = sx[lane] + (lane == vi ? nm_step : 0.0);
+              gq_sync();
+              pt = v; count = true; need = true; st = S_NM_INIT_F;
+            } else {
+              gq_sync();
+              st = S_NM_LOOP;
+            }
+            break;
+          case S_NM_INIT_F:
+            if (lane == 0u) fv[vi + 1u] = f;
+            ++vi; st = S_NM_INIT_SETUP;
+            break;
+          case S_NM_LOOP: {
+            if (!(n_eval < GLMM_MAX_EVAL)) { st = S_NM_END; break; }
+            lo = 0; hi = 0;
+            for (uint32_t i = 1; i <= d; ++i) {
+              if (fv[i] < fv[lo]) lo = i;
+              if (fv[i] > fv[hi]) hi = i;
+            }
+            uint32_t nh = lo;
+            for (uint32_t i = 0; i <= d; ++i)
+              if (i != hi && fv[i] > fv[nh]) nh = i;
+            double size = 0.0;
+            for (uint32_t i = 0; i <= d; ++i)
+              for (uint32_t k = 0; k < d; ++k) {
+                const double dd = __builtin_fabs(sx[(size_t)i * GLMM_ROW + k] - sx[(size_t)lo * GLMM_ROW + k]);
+                size = dd > size ? dd : size;
+              }
+            if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) { st = S_NM_END; break; }
+            flo = fv[lo]; fhi = fv[hi]; fnh = fv[nh];
+            gq_sync();
+            if (lane < d) {
+              double ssum = 0.0;
+              for (uint32_t i = 0; i <= d; ++i)
+                if (i != hi) ssum += sx[(size_t)i * GLMM_ROW + lane];
+              const double c = ssum / (double)d;
+              cen[lane] = c;
+              xr[lane] = c + (c - sx[(size_t)hi * GLMM_ROW + lane]);
+            }
+            gq_sync();
+            pt = xr; count = true; need = true; st = S_NM_FR;
+          } break;
+          case S_NM_FR: {
+            fr = f;
+            gdd* worst = sx + (size_t)hi * GLMM_ROW;
+            if (fr < flo) {
+              if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
+              gq_sync();
+              pt = xe; count = true; need = true; st = S_NM_FE;
+            } else if (fr < fnh) {
+              if (lane < d) worst[lane] = xr[lane];
+              if (lane == 0u) fv[hi] = fr;
+              gq_sync();
+              st = S_NM_LOOP;
+            } else {
+              outside = fr < fhi;
+              if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
+              gq_sync();
+              pt = xe; count = true; need = true; st = S_NM_FC;
+            }
+          } break;
+          case S_NM_FE: {
+            gdd* worst = sx + (size_t)hi * GLMM_ROW;
+            if (lane < d) worst[lane] = f < fr ? xe[lane] : xr[lane];
+            if (lane == 0u) fv[hi] = f < fr ? f : fr;
+            gq_sync();
+            st = S_NM_LOOP;
+          } break;
+          case S_NM_FC: {
+            gdd* worst = sx + (size_t)hi * GLMM_ROW;
+            if (f < (outside ? fr : fhi)) {
+              if (lane < d) worst[lane] = xe[lane];
+              if (lane == 0u) fv[hi] = f;
+              gq_sync();
+              st = S_NM_LOOP;
+            } else {
+              vi = 0; st = S_NM_SHRINK_SETUP;
+            }
+          } break;
+          case S_NM_SHRINK_SETUP:
+            if (vi <= d && vi == lo) ++vi;
+            if (vi <= d) {
+              gdd* v = sx + (size_t)vi * GLMM_ROW;
+              if (lane < d) v[lane] = sx[(size_t)lo * GLMM_ROW + lane] + 0.5 * (v[lane] - sx[(size_t)lo * GLMM_ROW + lane]);
+              gq_sync();
+              pt = v; count = true; need = true; st = S_NM_SHRINK_F;
+            } else {
+              gq_sync();
+              st = S_NM_LOOP;
+            }
+            break;
+          case S_NM_SHRINK_F:
+            if (lane == 0u) fv[vi] = f;
+            gq_sync();
+            ++vi; st = S_NM_SHRINK_SETUP;
+            break;
+          case S_NM_END: {  // the best vertex to row 0; then the restart schedule of the caller
+            uint32_t bl = 0;
+            for (uint32_t i = 1; i <= d; ++i)
+              if (fv[i] < fv[bl]) bl = i;
+            best = fv[bl];
+            gq_sync();
+            double best_k = 0.0;
+            if (lane < d) best_k = sx[(size_t)bl * GLMM_ROW + lane];
+            gq_sync();
+            if (lane < d) sx[lane] = best_k;
+            gq_sync();
+            bool again;
+            if (run == 0) {
+              run = 1; restart = 0; again = true;
+            } else if (!(prev - best > 1e-8)) {
+              again = false;
+            } else {
+              ++restart; again = true;
+            }
+            if (again && restart < 4 && n_eval < GLMM_MAX_EVAL) {
+              prev = best;
+              nm_step = restart == 0 ? 0.05 : 0.01; ftol = 1e-10; xtol = 1e-7;
+              st = S_NM_BEGIN;
+            } else {
+              st = S_CUR;
+            }
+          } break;
+          case S_CUR:
+            pt = sx; count = true; need = true; st = S_CUR_F;
+            break;
+          case S_CUR_F:
+            cur = f; snap_k = 0; st = S_SNAP_SETUP;
+            break;
+          case S_SNAP_SETUP: {  // snap a near-zero diagonal onto the boundary when that costs no deviance
+            bool found = false;
+            while (snap_k < nth) {
+              if ((m.diag_mask >> snap_k) & 1u) {
+                th_keep = sx[snap_k];
+                if (th_keep != 0.0 && th_keep <= 1e-4) { found = true; break; }
+              }
+              ++snap_k;
+            }
+            if (found) {
+              gq_sync();
+              if (lane == 0u) sx[snap_k] = 0.0;
+              gq_sync();
+              pt = sx; count = true; need = true; st = S_SNAP_F;
+            } else {
+              st = S_FINAL;
+            }
+          } break;
+          case S_SNAP_F:
+            if (f <= cur + 1e-8) cur = f;
+            else {
+              gq_sync();
+              if (lane == 0u) sx[snap_k] = th_keep;
+              gq_sync();
+            }
+            ++snap_k; st = S_SNAP_SETUP;
+            break;
+          case S_FINAL:  // modes and the factor of the final point
+            pt = sx; count = true; need = true; st = S_FINAL_F;
+            break;
+          case S_FINAL_F: {
+            cur = f;
+            ok = cur < inf && n_eval < GLMM_MAX_EVAL;
+            // ---- RX'RX = X'WX - C' (I + A'WA)^-1 C, C = A'WX (R x P): weights at the final modes, C folded by its owners ----
+            double A[P * (P + 1) / 2];
 #pragma unroll
-          for (int r = 0; r < P; ++r)
+            for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = 0.0;
+            for (uint32_t i = lane; i < n; i += QW) {
+              // weights at the FINAL modes, as oracle/fit_glmm_general.c: m.u is the accepted point of the step-halving loop
+              // and the factor in m.M belongs to it on every exit
+              double au = 0.0;
+              for (uint32_t t = 0; t < nterms; ++t) {
+                double a[3];
+                const uint32_t l = gg_row_term<P>(prm, m, t, i, n_pad, a);
+                const gdd* ut = m.u + pick3(m.off, t) + l * prm.lmg_q[t];
+                au += a[0] * ut[0];
+                if (prm.lmg_q[t] > 1u) au += a[1] * ut[1];
+                if (prm.lmg_q[t] > 2u) au += a[2] * ut[2];
+              }
+              double w, wz, dv;
+              fam_eval(prm.glm_family, m.eta0[i] + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
+              m.wrow[i] = w;
+              double xd[P];
+              xd[0] = 1.0;
 #pragma unroll
-            for (int s = 0; s <= r; ++s) Lx[r][s] = Lh[r][s];
+              for (int r = 1; r < P; ++r) xd[r] = (double)m.design[(size_t)(r - 1) * n_pad + i];
+              int idx = 0;
+#pragma unroll
+              for (int r = 0; r < P; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 <= r; ++s2) A[idx++] += w * xd[r] * xd[s2];
+            }
+            for (uint32_t e = lane; e < m.R * (uint32_t)P; e += QW) m.C[e] = 0.0;
+            gq_sync();
+            for (uint32_t t = 0; t < nterms; ++t) {
+              const uint32_t q = prm.lmg_q[t], nl = t == 0u ? ncl : prm.lmg_levels[t];
+              for (uint32_t l = lane; l < nl; l += QW) {
+                double cl[3][P];
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+#pragma unroll
+                  for (int r = 0; r < P; ++r) cl[b][r] = 0.0;
+                // rows of the level: an arithmetic progression for the primary grouping, the level's slice of the row list else
+                const uint32_t first = t == 0u ? (prm.cluster_fixed_clusters ? l : l * cv) : (uint32_t)m.lstart[pick3(m.so, t) + l];
+                const uint32_t step = t == 0u ? (prm.cluster_fixed_clusters ? cv : 1u) : 1u;
+                const uint32_t last = t == 0u ? (prm.cluster_fixed_clusters ? n : ((l + 1u) * cv < n ? (l + 1u) * cv : n))
+                                              : (uint32_t)m.lstart[pick3(m.so, t) + l + 1u];
+                for (uint32_t s2 = first; s2 < last; s2 += step) {
+                  const uint32_t i = t == 0u ? s2 : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + s2];
+                  if (i >= n) break;  // ascending within a level: the rest lies past this grid point's sample
+                  double a[3];
+                  gg_row_term<P>(prm, m, t, i, n_pad, a);
+                  const double w = m.wrow[i];
+#pragma unroll
+                  for (int r = 0; r < P; ++r) {
+                    const double xv = r == 0 ? 1.0 : (double)m.design[(size_t)(r - 1) * n_pad + i];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) cl[b][r] += w * a[b] * xv;
+                  }
+                }
+                const uint32_t base = pick3(m.off, t) + l * q;
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                  if ((uint32_t)b < q)
+#pragma unroll
+                    for (int r = 0; r < P; ++r) m.C[(size_t)(base + b) * P + r] = cl[b][r];
+              }
+            }
+            gq_sync();
+            gg_forward(m.M, m.R, m.RS, m.off[1], prm.lmg_q[0], m.C, (uint32_t)P, (uint32_t)P, lane);  // D = L^-1 C
+            {
+              double dd[P * (P + 1) / 2];
+#pragma unroll
+              for (int i = 0; i < P * (P + 1) / 2; ++i) dd[i] = 0.0;
+              for (uint32_t a = lane; a < m.R; a += QW) {
+                int idx = 0;
+#pragma unroll
+                for (int r = 0; r < P; ++r)
+#pragma unroll
+                  for (int s2 = 0; s2 <= r; ++s2) dd[idx++] += m.C[(size_t)a * P + r] * m.C[(size_t)a * P + s2];
+              }
+#pragma unroll
+              for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]) - gq_wave_sum(dd[i]);
+            }
+            double Lr[P][P];
+            ok = factor(A, Lr) && ok;
+            store_factor(Lr);
+            if (prm.glmm_hessian && ok) {
+              // Wald SE mode "hessian": lme4's deriv12 stencil (delta = 1e-4) over the FREE covariance parameters and beta
+              // (a pinned diagonal is an even point of the deviance and drops out); a block that does not factor keeps "rx"
+              th_free = 0u;
+              for (uint32_t k = 0; k < nth; ++k) th_free |= (((m.diag_mask >> k) & 1u) && sx[k] < GLMM_THETA_ZERO) ? 0u : (1u << k);
+              ha = 0; st = S_HESS_A;
+            } else {
+              st = S_DECIDE;
+            }
+          } break;
+          case S_HESS_A:
+            if (ha >= d) { st = S_HESS_SOLVE; break; }
+            if (ha < nth && !((th_free >> ha) & 1u)) {  // left out: identity row / column
+              gq_sync();
+              if (lane < d) {
+                Hm[(size_t)ha * GLMM_ROW + lane] = lane == ha ? 1.0 : 0.0;
+                Hm[(size_t)lane * GLMM_ROW + ha] = lane == ha ? 1.0 : 0.0;
+              }
+              ++ha;
+              break;
+            }
+            hq = 0; st = S_HESS_DIAG_SETUP;
+            break;
+          case S_HESS_DIAG_SETUP:
+            gq_sync();
+            if (lane < d) xe[lane] = lane == ha ? sx[lane] + (hq ? -dl : dl) : sx[lane];
+            gq_sync();
+            pt = xe; count = false; need = true; st = S_HESS_DIAG_F;
+            break;
+          case S_HESS_DIAG_F:
+            if (hq == 0) fadd = f;
+            else fsub = f;
+            if (++hq < 2) { st = S_HESS_DIAG_SETUP; break; }
+            if (lane == 0u) Hm[(size_t)ha * GLMM_ROW + ha] = fadd / (dl * dl) - 2.0 * cur / (dl * dl) + fsub / (dl * dl);
+            hb = 0; st = S_HESS_OFF_B;
+            break;
+          case S_HESS_OFF_B:
+            while (hb < ha && hb < nth && !((th_free >> hb) & 1u)) ++hb;  // that row / column is already identity
+            if (hb >= ha) { ++ha; st = S_HESS_A; break; }
+            hq = 0; hacc = 0.0; st = S_HESS_OFF_SETUP;
+            break;
+          case S_HESS_OFF_SETUP:
+            gq_sync();
+            if (lane < d) {
+              double v = sx[lane];
+              if (lane == hb) v = v + ((hq & 2) ? -dl : dl);
+              if (lane == ha) v = v + ((hq & 1) ? -dl : dl);
+              xe[lane] = v;
+            }
+            gq_sync();
+            pt = xe; count = false; need = true; st = S_HESS_OFF_F;
+            break;
+          case S_HESS_OFF_F:
+            hacc = hq == 0 ? f : (hq == 3 ? hacc + f : hacc - f);  // f++ - f+- - f-+ + f--, summed in that order
+            if (++hq < 4) { st = S_HESS_OFF_SETUP; break; }
+            if (lane == 0u) {
+              const double h = hacc / (4.0 * dl * dl);
+              Hm[(size_t)ha * GLMM_ROW + hb] = h;
+              Hm[(size_t)hb * GLMM_ROW + ha] = h;
+            }
+            ++hb; st = S_HESS_OFF_B;
+            break;
+          case S_HESS_SOLVE: {  // S / 2, S = H_bb - H_bt H_tt^-1 H_tb, by lane 0; then its factor replaces the "rx" one
+            gq_sync();
+            if (lane == 0u) {
+              bool okh = true;
+              const uint32_t pf = d - nth;
+              for (uint32_t a = 0; a < d; ++a)
+                for (uint32_t b = 0; b < d; ++b) {
+                  const double v = Hm[(size_t)a * GLMM_ROW + b];
+                  okh = okh && (v < __builtin_inf()) && (v > -__builtin_inf());
+                }
+              for (uint32_t j = 0; j < nth; ++j) {  // lower Cholesky of H_tt, in place
+                double dj = Hm[(size_t)j * GLMM_ROW + j];
+                for (uint32_t k = 0; k < j; ++k) dj -= Hm[(size_t)j * GLMM_ROW + k] * Hm[(size_t)j * GLMM_ROW + k];
+                okh = okh && (dj > 0.0);
+                const double ljj = __builtin_sqrt(dj);
+                Hm[(size_t)j * GLMM_ROW + j] = ljj;
+                for (uint32_t i = j + 1u; i < nth; ++i) {
+                  double v = Hm[(size_t)i * GLMM_ROW + j];
+                  for (uint32_t k = 0; k < j; ++k) v -= Hm[(size_t)i * GLMM_ROW + k] * Hm[(size_t)j * GLMM_ROW + k];
+                  Hm[(size_t)i * GLMM_ROW + j] = v / ljj;
+                }
+              }
+              for (uint32_t r = 0; r < pf; ++r)  // Y = Lt^-1 H_tb, over H_tb
+                for (uint32_t i = 0; i < nth; ++i) {
+                  double v = Hm[(size_t)i * GLMM_ROW + nth + r];
+                  for (uint32_t k = 0; k < i; ++k) v -= Hm[(size_t)i * GLMM_ROW + k] * Hm[(size_t)k * GLMM_ROW + nth + r];
+                  Hm[(size_t)i * GLMM_ROW + nth + r] = v / Hm[(size_t)i * GLMM_ROW + i];
+                }
+              for (uint32_t r = 0; r < pf; ++r)
+                for (uint32_t c = 0; c <= r; ++c) {
+                  double v = Hm[(size_t)(nth + r) * GLMM_ROW + nth + c];
+                  for (uint32_t k = 0; k < nth; ++k) v -= Hm[(size_t)k * GLMM_ROW + nth + r] * Hm[(size_t)k * GLMM_ROW + nth + c];
+                  Hm[(size_t)(nth + r) * GLMM_ROW + nth + c] = 0.5 * v;
+                }
+              xe[0] = okh ? 1.0 : 0.0;
+            }
+            gq_sync();
+            const bool okh = xe[0] != 0.0;
+            gq_sync();
+            if (okh) {
+              double Ah[P * (P + 1) / 2], Lh[P][P];
+              int idx = 0;
+              uint32_t kr = 0;
+#pragma unroll
+              for (int r = 0; r < P; ++r) {
+                uint32_t kc = 0;
+#pragma unroll
+                for (int s2 = 0; s2 <= r; ++s2) {
+                  const bool both = ((keep >> r) & 1u) && ((keep >> s2) & 1u);
+                  Ah[idx++] = both ? Hm[(size_t)(nth + kr) * GLMM_ROW + nth + kc] : 0.0;
+                  kc += ((keep >> s2) & 1u) ? 1u : 0u;
+                }
+                kr += ((keep >> r) & 1u) ? 1u : 0u;
+              }
+              if (factor(Ah, Lh)) store_factor(Lh);
+            }
+            st = S_DECIDE;
+          } break;
+          default: st = S_DECIDE; break;
         }
       }
+      if (st == S_DECIDE && !need) break;
+      // ---- the ONE evaluation site: clamp the point onto the bounds, then the Laplace deviance ----
+      if (lane < d) {
+        double v = pt[lane];
+        if (lane < nth) {
+          if ((m.diag_mask >> lane) & 1u) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+          else v = v < -GLMM_THETA_MAX ? -GLMM_THETA_MAX : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+        } else {
+          v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
+        }
+        pt[lane] = v;
+      }
+      gq_sync();
+      n_eval += count ? 1u : 0u;
+      f = glmm_eval<P>(prm, m, pt, lane, n, ncl, n_pad, keep);
     }
+    double Lx[P][P];
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < P; ++s2) Lx[r][s2] = m.lx[r * P + s2];
     bool conv = ok;
     bool at_upper = false;
     uint32_t pinned = 0u;
@@ -1171,7 +1383,7 @@ size_t glmm_general_lds_bytes(const SimParams& prm) {
   for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) nd += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
   size_t na = 0;
   for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) na += prm.lmg_q[t];
-  const size_t dbl = (3 + na) * n_pad + R * RS + 4 * R + R * P + 28 + (dmax + 4) * GLMM_ROW + ((dmax + 2) & ~(size_t)1) + 8;
+  const size_t dbl = (3 + na) * n_pad + R * RS + 4 * R + R * P + 28 + (dmax + 4) * GLMM_ROW + ((dmax + 2) & ~(size_t)1) + 8 + 36;
   size_t so = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) so += (size_t)prm.lmg_levels[t] + 2;
   const size_t flt = P * n_pad + ((nd + 1) & ~(size_t)1) + 2 * ((prm.lmg_n_terms - 1) * n_pad / 2 + 2) + (so + 3) / 2 + 1 +
