@@ -109,7 +109,7 @@ def main():
                     help="capi (default): the collective runs inside the C ABI on RCCL, torch.distributed (gloo) is "
                          "the control plane; nccl: host counter blocks pooled through torch's RCCL process group "
                          "(the round-1 path); gloo: the same through gloo, to rehearse N>1 with several ranks on one GPU")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight per rank (1..4)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight per rank (1..4)")
     args = ap.parse_args()
 
     import torch
@@ -182,14 +182,19 @@ def main():
             acc["pooled"] = pend.wait() if hasattr(pend, "wait") else pend
             acc["pooled_sims"] += float(acc["pooled"][0, acc["last"].layout["n_sims"]])
 
+        t_sub = t_col = 0.0
         tickets = [submit(first + j) for j in range(min(depth, count))]
         issued = len(tickets)
         reduce_in_flight = None
         for i in range(count):
+            ta = time.perf_counter()
             r = tickets.pop(0).collect()
+            tb = time.perf_counter()
             if issued < count:
                 tickets.append(submit(first + issued))
                 issued += 1
+            t_sub += time.perf_counter() - tb
+            t_col += tb - ta
             acc["last"] = r
             acc["kernel_ms"] += r.kernel_ms
             acc["aux_ms"] += r.aux_kernel_ms
@@ -203,6 +208,7 @@ def main():
                 reduce_in_flight = mdist.allreduce_counters_async(r.counters)
         if reduce_in_flight is not None:
             absorb(reduce_in_flight)
+        acc["host_submit_ms"], acc["host_collect_ms"] = 1e3 * t_sub / count, 1e3 * t_col / count
         return acc
 
     def busy_ms(spans):
@@ -218,10 +224,12 @@ def main():
                 cur_e = max(cur_e, e)
         return total + ((cur_e - cur_b) if cur_e is not None else 0.0)
 
-    run_steps(0, args.warmup)
+    # W untimed warm-up steps; every batch slot in flight owns its own device arena, so at least `depth` batches must
+    # have been issued before the timed region or a first-use hipMalloc lands inside it
+    run_steps(0, max(args.warmup, depth))
     barrier()
     t0 = time.perf_counter()
-    acc = run_steps(args.warmup, args.steps)
+    acc = run_steps(max(args.warmup, depth), args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, aux_ms, launches, pooled, r = acc["kernel_ms"], acc["aux_ms"], acc["launches"], acc["pooled"], acc["last"]
@@ -252,7 +260,8 @@ def main():
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": ("1 ncclAllReduce(sum, uint64) of the device-resident counters per step, inside the C ABI"
                                       if capi or world == 1 else f"1 all-reduce(sum) of host counter blocks per step via torch ({args.backend})"),
-                       "batches_in_flight": depth},
+                       "batches_in_flight": depth,
+                       "host_ms_per_step": {"submit": acc["host_submit_ms"], "collect_wait": acc["host_collect_ms"]}},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),
         }
         is_ols = args.workload not in ("c3", "c4", "lmm_slope", "lmm_crossed", "glmm", "glmm_slope", "glmm_crossed")
