@@ -45,6 +45,9 @@ WORKLOADS = {
     "ols_wide": ("spec_ols_wide", 200, 1.4e5, 4 * 200 * 16),      # tuning aid: 4 plain predictors (p=5, no interaction)
     # C3: logistic IRLS n=500 p=4: 2000 draws + ~5 passes x 500 rows x (exp, log1p, 2 div, 18 fma) ~ 5.0e5 ops
     "c3": ("spec_c3", 500, 5.0e5, 4 * 500 * 4),
+    # the reference bench's widest IRLS case (throughput.rs:300-303, :536-541): k = 15, P = 16, n = 200 -- 800 Philox
+    # calls + 3 000 inverse CDFs + ~6 passes x 200 rows x (2 x 152 MAC + exp, log1p, 2 div) ~ 5.2e5 ops
+    "glm_wide": ("spec_glm_wide", 200, 5.2e5, 4 * 200 * 16),
     # C4: random-intercept REML, 30 x 20: 1800 draws + 30 RE draws + one 600-row pass + ~28 objective evaluations
     "c4": ("spec_c4", 600, 1.6e5, 4 * 600 * 3),
     # general mixed models (reference cases lmm_slope_a / lmm_crossed_a, validation/formulas.R:385-470): 960 / 1440
@@ -151,7 +154,7 @@ def main():
     if args.workload.startswith("c5_"):
         spec.scenario = helpers.preset(args.workload[3:])
         ns = helpers.C5_GRID
-    S = args.sims_per_gpu or ({"c3": 100_000, "c4": 10_000, "lmm_slope": 40_000, "lmm_crossed": 40_000, "glmm": 40_000, "glmm_slope": 16_000, "glmm_crossed": 4_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
+    S = args.sims_per_gpu or ({"c3": 100_000, "glm_wide": 100_000, "c4": 10_000, "lmm_slope": 40_000, "lmm_crossed": 40_000, "glmm": 40_000, "glmm_slope": 16_000, "glmm_crossed": 4_000}.get(args.workload, 100_000 if args.workload.startswith("c5_") else 1_000_000))
     staged = args.pipeline == "staged"
 
     def barrier():
@@ -254,8 +257,8 @@ def main():
             "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM', 'glmm_slope': 'GLMM', 'glmm_crossed': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
-                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'glmm_slope': 'logit, Laplace, (1 + x1 | g), 30 clusters x 20', 'glmm_crossed': 'logit, Laplace, (1 + x1 | g) + (1 | item), 24 x 6 levels', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
+            "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'glm_wide': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM', 'glmm_slope': 'GLMM', 'glmm_crossed': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
+                                   f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'glm_wide': 'glm_wide of the reference bench, logit IRLS, 15 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'glmm_slope': 'logit, Laplace, (1 + x1 | g), 30 clusters x 20', 'glmm_crossed': 'logit, Laplace, (1 + x1 | g) + (1 | item), 24 x 6 levels', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": ("1 ncclAllReduce(sum, uint64) of the device-resident counters per step, inside the C ABI"
@@ -264,7 +267,7 @@ def main():
                        "host_ms_per_step": {"submit": acc["host_submit_ms"], "collect_wait": acc["host_collect_ms"]}},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),
         }
-        is_ols = args.workload not in ("c3", "c4", "lmm_slope", "lmm_crossed", "glmm", "glmm_slope", "glmm_crossed")
+        is_ols = args.workload not in ("c3", "glm_wide", "c4", "lmm_slope", "lmm_crossed", "glmm", "glmm_slope", "glmm_crossed")
         is_c5 = args.workload.startswith("c5_")
         if not staged:
             fits_per_launch *= len(ns)  # a replicate on a grid is len(ns) prefix fits (throughput.rs:1111-1113)
@@ -272,7 +275,7 @@ def main():
             # is work / kernel-busy time = per-launch work x mean concurrency / average launch duration
             ach = ops_per_fit * fits_per_launch * concurrency / (avg_launch_ms * 1e-3) / 1e12
             ops_1op = OPS_FMA_AS_ONE.get(args.workload)
-            out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload == "c3" else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"glmm_slopes_kernel<{spec.n_predictors},2>" if args.workload == "glmm_slope" else f"glmm_general_kernel<{spec.n_predictors}>" if args.workload == "glmm_crossed" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
+            out["roofline"] = {"bound": "valu", "kernel": ((f"ols_sim_kernel<{spec.n_predictors},fused>" if spec.n_predictors <= 8 else f"ols_reduced_kernel<{spec.n_predictors}>") if is_ols else (f"glm_sim_kernel<{spec.n_predictors}>" if args.workload in ("c3", "glm_wide") else (f"lmm_general_kernel<{spec.n_predictors}>" if args.workload.startswith("lmm_") else f"glmm_kernel<{spec.n_predictors}>" if args.workload == "glmm" else f"glmm_slopes_kernel<{spec.n_predictors},2>" if args.workload == "glmm_slope" else f"glmm_general_kernel<{spec.n_predictors}>" if args.workload == "glmm_crossed" else f"lmm_prepare_kernel<{spec.n_predictors}> + lmm_optimise_kernel<{spec.n_predictors}>"))),
                                "achieved": ach, "peak": PEAK_VALU_TOPS, "unit": "Top/s", "frac": ach / PEAK_VALU_TOPS,
                                "frac_fma_as_one_op": (ops_1op / ops_per_fit * ach / PEAK_VALU_TOPS) if ops_1op else None,
                                "ops_per_fit_fma_as_one_op": ops_1op,

@@ -274,8 +274,13 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   }
   if (spec->estimator == MCP_EST_OLS && spec->outcome_kind != MCP_OUTCOME_CONTINUOUS)
     return unsupported("OLS on Binary / Count outcomes");
-  if (spec->estimator != MCP_EST_OLS && (P > (uint32_t)MAX_P_WAVE || nt > (uint32_t)MAX_T_WAVE))
-    return unsupported("Glm / Mle with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests");
+  // the IRLS kernel is instantiated up to 16 design columns / tests for unclustered GLMs on the plain data path
+  // (glm_wide_kernels.hip: the reference bench's glm_wide, throughput.rs:300-303); everything else stays at 8
+  const bool glm_plain = spec->estimator == MCP_EST_GLM && !spec->cluster.present;
+  if (glm_plain && (P > (uint32_t)MAX_P || nt > (uint32_t)MAX_T))
+    return unsupported("Glm with more than " + std::to_string(MAX_P) + " design columns or tests");
+  if (spec->estimator != MCP_EST_OLS && !glm_plain && (P > (uint32_t)MAX_P_WAVE || nt > (uint32_t)MAX_T_WAVE))
+    return unsupported("Mle / clustered Glm with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests");
   if (spec->estimator == MCP_EST_GLM) {
     if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS) return unsupported("Glm on a Continuous outcome");
     if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL)
@@ -540,6 +545,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
 
   // ---- general path constants (data_gen.rs:709-776, 990-1093) ----
   prm.scen_active = general ? 1u : 0u;
+  if (general && spec->estimator == MCP_EST_GLM && (P > (uint32_t)MAX_P_WAVE || nt > (uint32_t)MAX_T_WAVE))
+    return unsupported("Glm on the general (scenario) data path with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests");
   prm.scen_optimistic = scenario_is_optimistic(spec->scenario) ? 1u : 0u;
   if (general) {
     const mcp_scenario& sc = spec->scenario;

@@ -66,6 +66,9 @@ typedef __attribute__((address_space(3))) double ldd;
 typedef __attribute__((address_space(3))) float ldf;
 typedef __attribute__((address_space(3))) uint32_t ldu;
 
+// packed lower triangle, by rows: element (i, j <= i); lmg_tri(W, 0) = W (W + 1) / 2 is the size of a W x W triangle
+__device__ __forceinline__ size_t lmg_tri(uint32_t i, uint32_t j) { return (size_t)i * (i + 1u) / 2u + j; }
+
 // LDS map of one replicate (doubles first, then floats)
 struct LmgLds {
   ldd *gzz, *gzw, *gww, *S, *B, *ld, *simplex, *fv, *tm, *misc, *tail, *carry;
@@ -127,13 +130,13 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, co
         double inner = 0.0;
         for (uint32_t d = bi; d < qi; ++d) {
           const uint32_t a = si + d, b = sj + e;
-          const double g = a >= b ? m.gww[(size_t)a * W + b] : m.gww[(size_t)b * W + a];
+          const double g = a >= b ? m.gww[lmg_tri(a, b)] : m.gww[lmg_tri(b, a)];
           inner = i < R ? inner + m.tm[ti * 9u + d * 3u + bi] * g : g;
         }
         acc = j < R ? acc + m.tm[tj * 9u + e * 3u + bj] * inner : inner;
       }
       if (i == j && i < R) acc += 1.0;
-      m.S[(size_t)i * W + j] = acc;
+      m.S[lmg_tri(i, j)] = acc;
     }
   }
   lmg_sync();
@@ -250,9 +253,9 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, co
           if (pi != 0xffffffffu && pi != pj) khi = klo;  // children of different parents never share a row
           else { klo = pj * Q0; khi = klo + Q0; }
         }
-        double sacc = m.S[(size_t)i * W + j];
+        double sacc = m.S[lmg_tri(i, j)];
         for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
-        m.S[(size_t)i * W + j] = sacc;
+        m.S[lmg_tri(i, j)] = sacc;
       }
     }
   }
@@ -263,8 +266,8 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, co
     double vv[2] = {0.0, 0.0};
     uint32_t cntr = 0;
     for (uint32_t i = j + lane; i < W; i += GW) {
-      double v = m.S[(size_t)i * W + j];
-      for (uint32_t k = 0; k < j; ++k) v -= m.S[(size_t)i * W + k] * m.S[(size_t)j * W + k];
+      double v = m.S[lmg_tri(i, j)];
+      for (uint32_t k = 0; k < j; ++k) v -= m.S[lmg_tri(i, k)] * m.S[lmg_tri(j, k)];
       vv[cntr++] = v;
       if (i == j) m.misc[1] = v;
     }
@@ -276,18 +279,18 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, co
     if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; }
     cntr = 0;
     for (uint32_t i = j + lane; i < W; i += GW) {
-      m.S[(size_t)i * W + j] = i == j ? ljj : vv[cntr] / ljj;
+      m.S[lmg_tri(i, j)] = i == j ? ljj : vv[cntr] / ljj;
       ++cntr;
     }
     lmg_sync();
   }
   logdet += log(pd);
-  double pwrss = m.S[(size_t)M * W + M];
-  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[(size_t)M * W + k] * m.S[(size_t)M * W + k];
+  double pwrss = m.S[lmg_tri(M, M)];
+  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[lmg_tri(M, k)] * m.S[lmg_tri(M, k)];
   const double dfr = n_rows - (double)p;
   double lmin = inf, lmax = 0.0;
   for (uint32_t a = 0; a < p; ++a) {
-    const double v = __builtin_fabs(m.S[(size_t)(R + a) * W + R + a]);
+    const double v = __builtin_fabs(m.S[lmg_tri((R + a), R + a)]);
     lmin = v < lmin ? v : lmin;
     lmax = v > lmax ? v : lmax;
   }
@@ -297,9 +300,9 @@ __device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, co
   if (lane == 0u) {
     m.misc[0] = pwrss / dfr;
     for (uint32_t a = 0; a < p; ++a)
-      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[(size_t)(R + a) * W + R + b] : 0.0;
+      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[lmg_tri((R + a), R + b)] : 0.0;
     for (int a = (int)p - 1; a >= 0; --a) {
-      double v = m.S[(size_t)M * W + R + (uint32_t)a];
+      double v = m.S[lmg_tri(M, R + (uint32_t)a)];
       for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[8u + k * 8u + (uint32_t)a] * m.tail[k];
       m.tail[a] = v / m.tail[8u + (uint32_t)a * 8u + (uint32_t)a];
     }
@@ -350,12 +353,12 @@ __device__ __noinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m
       if (di || dropped(j)) {
         acc = i == j ? 1.0 : 0.0;
       } else {
-        const double g = fi >= fj ? m.gww[(size_t)fi * Wf + fj] : m.gww[(size_t)fj * Wf + fi];
+        const double g = fi >= fj ? m.gww[lmg_tri(fi, fj)] : m.gww[lmg_tri(fj, fi)];
         const double inner = i < Rr ? 0.0 + theta_of(ti) * g : g;
         acc = j < Rr ? 0.0 + theta_of(tj) * inner : inner;
         if (i == j && i < Rr) acc += 1.0;
       }
-      m.S[(size_t)i * W + j] = acc;
+      m.S[lmg_tri(i, j)] = acc;
     }
   }
   lmg_sync();
@@ -384,9 +387,9 @@ __device__ __noinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m
   for (uint32_t c = 0; c < L0; ++c) logdet += m.ld[c];
   for (uint32_t i = 0; i < W; ++i)
     for (uint32_t j = lane; j <= i; j += GW) {
-      double sacc = m.S[(size_t)i * W + j];
+      double sacc = m.S[lmg_tri(i, j)];
       for (uint32_t k = 0; k < L0; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
-      m.S[(size_t)i * W + j] = sacc;
+      m.S[lmg_tri(i, j)] = sacc;
     }
   lmg_sync();
   // ---- dense Cholesky over [rest | X]; dropped columns are identities and stay out of the pivot products ----
@@ -394,8 +397,8 @@ __device__ __noinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m
     double vv[2] = {0.0, 0.0};
     uint32_t cntr = 0;
     for (uint32_t i = j + lane; i < W; i += GW) {
-      double v = m.S[(size_t)i * W + j];
-      for (uint32_t k = 0; k < j; ++k) v -= m.S[(size_t)i * W + k] * m.S[(size_t)j * W + k];
+      double v = m.S[lmg_tri(i, j)];
+      for (uint32_t k = 0; k < j; ++k) v -= m.S[lmg_tri(i, k)] * m.S[lmg_tri(j, k)];
       vv[cntr++] = v;
       if (i == j) m.misc[1] = v;
     }
@@ -409,19 +412,19 @@ __device__ __noinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m
     }
     cntr = 0;
     for (uint32_t i = j + lane; i < W; i += GW) {
-      m.S[(size_t)i * W + j] = i == j ? ljj : vv[cntr] / ljj;
+      m.S[lmg_tri(i, j)] = i == j ? ljj : vv[cntr] / ljj;
       ++cntr;
     }
     lmg_sync();
   }
   logdet += log(pd);
-  double pwrss = m.S[(size_t)M * W + M];
-  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[(size_t)M * W + k] * m.S[(size_t)M * W + k];
+  double pwrss = m.S[lmg_tri(M, M)];
+  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[lmg_tri(M, k)] * m.S[lmg_tri(M, k)];
   const double dfr = n_rows - (double)red.p_fit;
   double lmin = inf, lmax = 0.0;
   for (uint32_t a = 0; a < p; ++a) {
     if (!((red.keep >> a) & 1u)) continue;
-    const double v = __builtin_fabs(m.S[(size_t)(Rr + a) * W + Rr + a]);
+    const double v = __builtin_fabs(m.S[lmg_tri((Rr + a), Rr + a)]);
     lmin = v < lmin ? v : lmin;
     lmax = v > lmax ? v : lmax;
   }
@@ -431,9 +434,9 @@ __device__ __noinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m
   if (lane == 0u) {
     m.misc[0] = pwrss / dfr;
     for (uint32_t a = 0; a < p; ++a)
-      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[(size_t)(Rr + a) * W + Rr + b] : 0.0;
+      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[lmg_tri((Rr + a), Rr + b)] : 0.0;
     for (int a = (int)p - 1; a >= 0; --a) {
-      double v = m.S[(size_t)M * W + Rr + (uint32_t)a];
+      double v = m.S[lmg_tri(M, Rr + (uint32_t)a)];
       for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[8u + k * 8u + (uint32_t)a] * m.tail[k];
       m.tail[a] = v / m.tail[8u + (uint32_t)a * 8u + (uint32_t)a];
     }
@@ -587,8 +590,8 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
     ldd* q = (ldd*)lds_d;
     m.gzz = q; q += (size_t)L0 * Q0 * Q0;
     m.gzw = q; q += (size_t)L0 * Q0 * W;
-    m.gww = q; q += (size_t)W * W;
-    m.S = q; q += (size_t)W * W;
+    m.gww = q; q += lmg_tri(W, 0u);  // lower triangles, packed by rows
+    m.S = q; q += lmg_tri(W, 0u);
     m.B = q; q += (size_t)L0 * Q0 * W;
     m.ld = q; q += L0;
     m.simplex = q; q += (size_t)(d + 4u) * LMG_MAX_THETA;
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
     }
   }
   // ---- 3. sufficient statistics, zeroed once and grown over the grid ----
-  for (size_t i = lane; i < (size_t)L0 * Q0 * Q0 + (size_t)L0 * Q0 * W + (size_t)W * W; i += GW) m.gzz[i] = 0.0;  // gzz | gzw | gww are contiguous
+  for (size_t i = lane; i < (size_t)L0 * Q0 * Q0 + (size_t)L0 * Q0 * W + lmg_tri(W, 0u); i += GW) m.gzz[i] = 0.0;  // gzz | gzw | gww are contiguous
   lmg_sync();
 
   uint32_t nzr = 0;  // non-zeros of the rest part of a row
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
       for (uint32_t pr = lane; pr < nz * nz; pr += GW) {
         const uint32_t a = pr / nz, b = pr % nz;
         const uint32_t ia = m.ridx[a], ib = m.ridx[b];
-        if (ib <= ia) m.gww[(size_t)ia * W + ib] = __builtin_fma(m.rval[a], m.rval[b], m.gww[(size_t)ia * W + ib]);
+        if (ib <= ia) m.gww[lmg_tri(ia, ib)] = __builtin_fma(m.rval[a], m.rval[b], m.gww[lmg_tri(ia, ib)]);
       }
       for (uint32_t pr = lane; pr < (uint32_t)Q0 * nz; pr += GW) {
         const uint32_t a = pr / nz, b = pr % nz;

@@ -9,7 +9,7 @@ namespace mcp {
 // LDS bytes of one replicate
 size_t lmg_lds_bytes(const SimParams& prm) {
   const size_t W = prm.lmg_W, L0 = prm.lmg_levels[0], q0 = prm.lmg_q[0], d = prm.lmg_n_theta;
-  size_t dbl = L0 * q0 * q0 + 2 * L0 * q0 * W + L0 + 2 * W * W + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8) +
+  size_t dbl = L0 * q0 * q0 + 2 * L0 * q0 * W + L0 + W * (W + 1) + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8) +
                LMG_MAX_NZ + LMG_MAX_THETA;
   size_t u32 = LMG_MAX_NZ;
   const size_t n_pad = ((size_t)prm.max_n + 3u) & ~(size_t)3u;

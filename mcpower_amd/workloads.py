@@ -170,3 +170,100 @@ def spec_lmm_crossed() -> S.SimulationSpec:
 
 
 C5_GRID = list(range(50, 1001, 50))  # BASELINE C5: N = 50, 100, ..., 1000
+
+
+# ---- the 21 frozen cases of the reference bench (crates/engine-core/src/bin/throughput.rs:268-633) ----
+def _glm_spec(k: int, baseline_p: float) -> S.SimulationSpec:
+    """glm_spec (throughput.rs:224-232): logit outcome, effect_sizes[0] = logit(baseline_p)."""
+    s = base_spec(k)
+    s.outcome_kind = S.OutcomeKind.Binary
+    s.estimator = S.EstimatorSpec.Glm
+    s.intercept = math.log(baseline_p / (1.0 - baseline_p))
+    s.effect_sizes[0] = s.intercept
+    s.max_failed_fraction = 0.25
+    return s
+
+
+def _lme_spec(k: int, n_clusters: int) -> S.SimulationSpec:
+    """lme_spec (throughput.rs:236-247): Mle estimator, fixed cluster count, tau^2 = 0.25 (ICC 0.2)."""
+    s = base_spec(k)
+    s.estimator = S.EstimatorSpec.Mle
+    s.cluster = S.ClusterSpec(sizing=("FixedClusters", n_clusters), tau_squared=0.25)
+    s.max_failed_fraction = 0.25
+    return s
+
+
+def _glmm_spec(k: int, baseline_p: float, n_clusters: int, tau_squared: float) -> S.SimulationSpec:
+    """glmm_spec (throughput.rs:256-266): glm_spec + a random intercept; the Wald SE stays WaldSe::default() = Rx
+    (engine-contract estimator.rs:54-55; the bench comment at throughput.rs:264 predates that default)."""
+    s = _glm_spec(k, baseline_p)
+    s.cluster = S.ClusterSpec(sizing=("FixedClusters", n_clusters), tau_squared=tau_squared)
+    return s
+
+
+def _with(s: S.SimulationSpec, effects: dict, targets=None, slopes=(), extra=()) -> S.SimulationSpec:
+    for i, v in effects.items():
+        s.effect_sizes[i] = v
+    if targets is not None:
+        s.target_indices = list(targets)
+    if s.cluster is not None:
+        s.cluster.slopes = [dict(sl) for sl in slopes]
+        s.cluster.extra_groupings = [dict(g) for g in extra]
+        s.cluster_slope_design_cols = [1 + sl["column"] for sl in s.cluster.slopes]
+    return s
+
+
+def _crossed(n_clusters: int, tau_squared: float) -> dict:
+    return {"relation": {"Crossed": {"n_clusters": n_clusters}}, "tau_squared": tau_squared, "slopes": []}
+
+
+def _nested(n_per_parent: int, tau_squared: float) -> dict:
+    return {"relation": {"NestedWithin": {"n_per_parent": n_per_parent}}, "tau_squared": tau_squared, "slopes": []}
+
+
+_SLOPE_X2 = {"column": 1, "variance": 0.08, "corr_with_intercept": 0.1, "corr_with": [0.2]}
+
+
+def throughput_cases() -> dict:
+    """id -> (spec, n, n_sims): the frozen case grid of the reference's fits/sec bench, same ids, same inputs, in the
+    reference's order (throughput.rs:268-633); its per-case timings are the `off` rows (optimistic scenario)."""
+    def ols_factor_inter():
+        s = base_spec(1)
+        s.n_factor_dummies = 1
+        s.factor_n_levels = [2]
+        s.factor_proportions = [0.5, 0.5]
+        s.interactions = [[1, 2]]
+        s.effect_sizes = [0.0, 0.27, 0.5, 0.3]
+        s.target_indices = [1]
+        return s
+
+    x12 = lambda v: {1: v, 2: v}
+    return {
+        "ols_multi": (_with(base_spec(5), x12(0.18)), 200, 10_000),
+        "ols_wide": (_with(base_spec(15), x12(0.2)), 200, 10_000),
+        "ols_large_n": (_with(base_spec(3), x12(0.037)), 5000, 2_000),
+        "ols_factor_inter": (ols_factor_inter(), 200, 10_000),
+        "glm_multi": (_with(_glm_spec(5, 0.3), x12(0.4)), 200, 10_000),
+        "glm_wide": (_with(_glm_spec(15, 0.3), x12(0.4)), 200, 5_000),
+        "glm_large_n": (_with(_glm_spec(3, 0.3), x12(0.09)), 5000, 1_000),
+        "glm_rare": (_with(_glm_spec(2, 0.05), x12(0.45)), 500, 10_000),
+        "lme_multi": (_with(_lme_spec(5, 20), x12(0.15)), 500, 2_000),
+        "lme_many_clusters": (_with(_lme_spec(3, 100), x12(0.07)), 1000, 1_000),
+        "lme_matched_q1": (_with(_lme_spec(4, 20), x12(0.15)), 480, 1_000),
+        "lmm_crossed": (_with(_lme_spec(4, 20), x12(0.15), extra=[_crossed(12, 0.15)]), 480, 1_000),
+        "lmm_nested": (_with(_lme_spec(4, 20), x12(0.15), extra=[_nested(4, 0.10)]), 480, 1_000),
+        "lmm_crossed_nested": (_with(_lme_spec(4, 10), x12(0.15), extra=[_crossed(6, 0.15), _nested(2, 0.08)]), 480, 1_000),
+        "lmm_slope": (_with(_lme_spec(4, 20), x12(0.15), slopes=[_SLOPE_X1]), 480, 1_000),
+        "lmm_multislope": (_with(_lme_spec(4, 20), x12(0.15), slopes=[_SLOPE_X1, _SLOPE_X2]), 480, 1_000),
+        "glmm_intercept": (_with(_glmm_spec(1, 0.3, 8, 0.822), {1: 0.28}, targets=[1]), 480, 1_000),
+        "glmm_slope": (_with(_glmm_spec(1, 0.3, 8, 0.822), {1: 0.5}, targets=[1], slopes=[_SLOPE_X1]), 480, 1_000),
+        "glmm_crossed": (_with(_glmm_spec(1, 0.3, 8, 0.822), {1: 0.30}, targets=[1], extra=[_crossed(6, 0.49)]), 480, 500),
+        "glmm_nested": (_with(_glmm_spec(1, 0.3, 8, 0.822), {1: 0.30}, targets=[1], extra=[_nested(2, 0.33)]), 480, 500),
+        "glmm_crossed_nested": (_with(_glmm_spec(1, 0.3, 8, 0.822), {1: 0.30}, targets=[1],
+                                      extra=[_crossed(6, 0.49), _nested(2, 0.26)]), 480, 500),
+    }
+
+
+def spec_glm_wide() -> S.SimulationSpec:
+    """`glm_wide` of the reference bench (throughput.rs:300-303): glm_spec(15, 0.3), x1 = x2 = 0.4, P = 16."""
+    return throughput_cases()["glm_wide"][0]
