@@ -196,27 +196,31 @@ template <int P, bool MASKED, bool LOGIT, int MT>
 __device__ __forceinline__ void irls_fit_wide(const SimParams& prm, const float* design, double* wk, double* am, uint32_t n_pad,
                                               uint32_t n, uint32_t lane, uint32_t keep, uint32_t fam_rt, uint32_t nt,
                                               double (&beta)[P], double (&tsq)[MT], double& dev, bool& conv) {
-  constexpr int TRI = P * (P + 1) / 2, NE = TRI + P, EPL = (NE + WAVE - 1) / WAVE;
+  constexpr int TRI = P * (P + 1) / 2, RUN = 3;
   const uint32_t fam = LOGIT ? 0u : fam_rt;
-  // the entries this lane owns: e = lane + 64 k -> (a, b <= a) of the triangle, or (a, rhs)
-  uint32_t ea[EPL], eb[EPL];
-  bool erhs[EPL], eown[EPL];
+  // The runs this wave's lanes own: row a of the triangle cut into runs of RUN consecutive columns b0 .. b0 + len - 1
+  // (the products (w x_a) x_b share w x_a), then the right-hand side as one more row, (w z) x_b over all columns b.
+  // P = 16: 51 + 6 = 57 runs, one per lane.  Column 0 is the LDS column of ones in front of the design.
+  const float* col0 = design - n_pad;
+  uint32_t ra = 0, rb0 = 0, rlen = 0;
+  bool rrhs = false;
+  {
+    uint32_t g = lane;
+    bool found = false;
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    const uint32_t e = lane + (uint32_t)(WAVE * k);
-    eown[k] = e < (uint32_t)NE;
-    erhs[k] = e >= (uint32_t)TRI;
-    uint32_t a = 0;
-    if (erhs[k]) {
-      a = eown[k] ? e - (uint32_t)TRI : 0u;
-      eb[k] = 0u;
-    } else {
-#pragma unroll
-      for (int r = 1; r < P; ++r) a += e >= (uint32_t)(r * (r + 1) / 2) ? 1u : 0u;
-      eb[k] = e - a * (a + 1u) / 2u;
+    for (int r = 0; r <= P; ++r) {
+      const uint32_t rowlen = r < P ? (uint32_t)(r + 1) : (uint32_t)P, ng = (rowlen + RUN - 1u) / RUN;
+      if (!found && g < ng) {
+        found = true;
+        ra = r < P ? (uint32_t)r : 0u;
+        rrhs = r == P;
+        rb0 = RUN * g;
+        rlen = rowlen - rb0 < (uint32_t)RUN ? rowlen - rb0 : (uint32_t)RUN;
+      }
+      g -= found ? 0u : ng;
     }
-    ea[k] = a;
   }
+  static_assert((P * (P + 1) / 2 + P + 2 * (P + 1)) / 3 <= WAVE, "one run per lane");
   dev = __builtin_nan("");
   double dev_prev = __builtin_inf();
   conv = false;
@@ -236,56 +240,53 @@ __device__ __forceinline__ void irls_fit_wide(const SimParams& prm, const float*
       wk[n_pad + i] = wz;
       d += di;
     }
+    if (lane < 3u && n + lane < ((n + 3u) & ~3u)) {  // rows n .. n4 - 1 of the last group of 4: weight 0 (their x stay finite)
+      wk[n + lane] = 0.0;
+      wk[n_pad + n + lane] = 0.0;
+    }
     dev = wave_allreduce_sum(d);
     if (!(dev < __builtin_inf())) break;  // NaN / inf deviance
     const bool done = it > 0 && __builtin_fabs(dev - dev_prev) / (__builtin_fabs(dev) + 0.1) < IRLS_EPS;
     __syncthreads();
-    // ---- 2. entries: X'WX and X'Wz over all rows ----
-    double acc[EPL];
-    const float *ca[EPL], *cb[EPL];
-    bool onea[EPL], oneb[EPL];
+    // ---- 2. runs: X'WX and X'Wz over all rows; rows past n inside the last group of 4 enter with weight 0 ----
+    double acc[RUN];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      acc[k] = 0.0;
-      onea[k] = ea[k] == 0u;
-      oneb[k] = eb[k] == 0u;
-      ca[k] = design + (size_t)(onea[k] ? 0u : ea[k] - 1u) * n_pad;
-      cb[k] = design + (size_t)(oneb[k] ? 0u : eb[k] - 1u) * n_pad;
-    }
-    const uint32_t n4 = n & ~3u;
-    for (uint32_t i = 0; i < n4; i += 4u) {
-      const double2 w01 = *(const double2*)(wk + i), w23 = *(const double2*)(wk + i + 2u);
-      const double2 z01 = *(const double2*)(wk + n_pad + i), z23 = *(const double2*)(wk + n_pad + i + 2u);
-      const double wr[4] = {w01.x, w01.y, w23.x, w23.y}, zr[4] = {z01.x, z01.y, z23.x, z23.y};
-#pragma unroll
-      for (int k = 0; k < EPL; ++k) {
-        const float4 fa = *(const float4*)(ca[k] + i), fb = *(const float4*)(cb[k] + i);
-        const float xa[4] = {fa.x, fa.y, fa.z, fa.w}, xb[4] = {fb.x, fb.y, fb.z, fb.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double va = onea[k] ? 1.0 : (double)xa[r], vb = oneb[k] ? 1.0 : (double)xb[r];
-          // triangle: (w x_a) x_b; right-hand side: x_a (w z) -- the products of the row-owning kernel
-          acc[k] = __builtin_fma(erhs[k] ? va : wr[r] * va, erhs[k] ? zr[r] : vb, acc[k]);
-        }
-      }
-    }
-    for (uint32_t i = n4; i < n; ++i) {
-      const double wi = wk[i], zi = wk[n_pad + i];
-#pragma unroll
-      for (int k = 0; k < EPL; ++k) {
-        const double va = onea[k] ? 1.0 : (double)ca[k][i], vb = oneb[k] ? 1.0 : (double)cb[k][i];
-        acc[k] = __builtin_fma(erhs[k] ? va : wi * va, erhs[k] ? zi : vb, acc[k]);
+    for (int k = 0; k < RUN; ++k) acc[k] = 0.0;
+    {
+      const double* src = wk + (rrhs ? n_pad : 0u);
+      const float* ca = col0 + (size_t)ra * n_pad;
+      const float* cb = col0 + (size_t)rb0 * n_pad;
+      // columns past the run's end alias its first column (their sums are dropped), so every read stays inside the design
+      const uint32_t st1 = rlen > 1u ? n_pad : 0u, st2 = rlen > 2u ? 2u * n_pad : 0u;
+      for (uint32_t i = 0; i < n; i += 4u) {
+        const double2 s01 = *(const double2*)(src + i), s23 = *(const double2*)(src + i + 2u);
+        const float4 fa = *(const float4*)(ca + i);
+        const double wx[4] = {s01.x * (double)fa.x, s01.y * (double)fa.y, s23.x * (double)fa.z, s23.y * (double)fa.w};
+        const float4 f0 = *(const float4*)(cb + i), f1 = *(const float4*)(cb + st1 + i), f2 = *(const float4*)(cb + st2 + i);
+        acc[0] = __builtin_fma(wx[0], (double)f0.x, acc[0]);
+        acc[1] = __builtin_fma(wx[0], (double)f1.x, acc[1]);
+        acc[2] = __builtin_fma(wx[0], (double)f2.x, acc[2]);
+        acc[0] = __builtin_fma(wx[1], (double)f0.y, acc[0]);
+        acc[1] = __builtin_fma(wx[1], (double)f1.y, acc[1]);
+        acc[2] = __builtin_fma(wx[1], (double)f2.y, acc[2]);
+        acc[0] = __builtin_fma(wx[2], (double)f0.z, acc[0]);
+        acc[1] = __builtin_fma(wx[2], (double)f1.z, acc[1]);
+        acc[2] = __builtin_fma(wx[2], (double)f2.z, acc[2]);
+        acc[0] = __builtin_fma(wx[3], (double)f0.w, acc[0]);
+        acc[1] = __builtin_fma(wx[3], (double)f1.w, acc[1]);
+        acc[2] = __builtin_fma(wx[3], (double)f2.w, acc[2]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-      if (eown[k]) {
+    for (int k = 0; k < RUN; ++k) {
+      if ((uint32_t)k < rlen) {
+        const uint32_t bcol = rb0 + (uint32_t)k;
         double v = acc[k];
         if (MASKED) {  // dropped columns: identity rows / columns of X'WX, zeros of X'Wz
-          const bool ka = (keep >> ea[k]) & 1u, kb = (keep >> eb[k]) & 1u;
-          v = erhs[k] ? (ka ? v : 0.0) : ((ka && kb) ? v : (ea[k] == eb[k] ? 1.0 : 0.0));
+          const bool ka = (keep >> ra) & 1u, kb = (keep >> bcol) & 1u;
+          v = rrhs ? (kb ? v : 0.0) : ((ka && kb) ? v : (ra == bcol ? 1.0 : 0.0));
         }
-        am[lane + (uint32_t)(WAVE * k)] = v;
+        am[rrhs ? (uint32_t)TRI + bcol : ra * (ra + 1u) / 2u + bcol] = v;
       }
     }
     __syncthreads();
@@ -300,12 +301,14 @@ __device__ __forceinline__ void irls_fit_wide(const SimParams& prm, const float*
       if (lane > j && lane < (uint32_t)P) MCP_TRI(lane, j) = MCP_TRI(lane, j) * inv_ljj;
       if (lane == j) MCP_TRI(j, j) = inv_ljj;
       __syncthreads();
+      if (!rrhs && ra > j) {
+        const double laj = MCP_TRI(ra, j);
 #pragma unroll
-      for (int k = 0; k < EPL; ++k)
-        if (eown[k] && !erhs[k] && eb[k] > j) {
-          const uint32_t e = lane + (uint32_t)(WAVE * k);
-          am[e] = __builtin_fma(-MCP_TRI(ea[k], j), MCP_TRI(eb[k], j), am[e]);
+        for (int k = 0; k < RUN; ++k) {
+          const uint32_t bcol = rb0 + (uint32_t)k;
+          if ((uint32_t)k < rlen && bcol > j) MCP_TRI(ra, bcol) = __builtin_fma(-laj, MCP_TRI(bcol, j), MCP_TRI(ra, bcol));
         }
+      }
       __syncthreads();
     }
     if (!ok) break;
@@ -389,12 +392,19 @@ __global__ __launch_bounds__(WAVE, MCP_GLM_WAVES) void glm_sim_kernel(const SimP
   const uint32_t out_row = prm.out_base + lsim;
   const uint32_t max_n = prm.max_n;
   const uint32_t n_pad = (max_n + 3u) & ~3u;
-  float* design = lds;                       // P columns x n_pad
-  float* st = lds + (size_t)P * n_pad + lane;  // staging, stride WAVE
-  // wide designs (P > 8): the fit's row weights w | w z (2 n_pad doubles) after the staging area, and the normal
-  // equations (triangle | right-hand side | z^2 of the tests) over the staging area, which is dead once the rows exist
-  double* fit_am = (double*)(lds + (size_t)P * n_pad);
-  double* fit_wk = (double*)(lds + (size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE);
+  // wide designs (P > 8) keep a column of ones in front of the design (irls_fit_wide reads the intercept as column 0),
+  // the fit's row weights w | w z (2 n_pad doubles) after the staging area, and the normal equations (triangle |
+  // right-hand side | z^2 | beta | test solves) over the staging area, which is dead once the rows exist
+  constexpr bool WIDE = P > MAX_P_WAVE;
+  float* design = lds + (WIDE ? n_pad : 0u);  // P columns x n_pad: x1..x_{P-1}, y
+  float* st = design + (size_t)P * n_pad + lane;  // staging, stride WAVE
+  double* fit_am = (double*)(design + (size_t)P * n_pad);
+  double* fit_wk = (double*)(design + (size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE);
+  if (WIDE) {
+    for (uint32_t i = lane; i < n_pad; i += WAVE) lds[i] = 1.0f;
+    // rows max_n .. n_pad - 1 are never generated; the 4-row steps of the fit read them (with weight 0): keep them finite
+    for (uint32_t i = lane; i < (n_pad - max_n) * (uint32_t)P; i += WAVE) design[(size_t)(i / (n_pad - max_n)) * n_pad + max_n + i % (n_pad - max_n)] = 0.0f;
+  }
 
   // ---- generate the replicate into LDS: lane takes Philox blocks lane, lane + 64, ... ----
   RowCtx<P> cx;

@@ -111,8 +111,9 @@ hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t cop
 
 size_t glm_lds_bytes(int P, uint32_t max_n) {  // staging sized for the general path's scratch column too
   const size_t n_pad = (max_n + 3u) & ~3u;
-  // P > 8 (glm_wide_kernels.hip): + the row weights w | w z of irls_fit_wide, 2 n_pad doubles
-  return ((size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE) * sizeof(float) + (P > MAX_P_WAVE ? (size_t)2 * n_pad * sizeof(double) : 0);
+  // P > 8 (glm_wide_kernels.hip): + the column of ones and the row weights w | w z of irls_fit_wide (2 n_pad doubles)
+  return ((size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE) * sizeof(float) +
+         (P > MAX_P_WAVE ? n_pad * sizeof(float) + (size_t)2 * n_pad * sizeof(double) : 0);
 }
 
 template <bool FACTORS, bool RED, bool SCEN, bool LOGIT>

@@ -1,11 +1,11 @@
 // glm_wide_kernels.hip -- the IRLS simulate kernel (glm_impl.hpp) instantiated for WIDE designs, P = 9..16 design columns
 // (the reference bench's `glm_wide = glm_spec(15, 0.3)`, crates/engine-core/src/bin/throughput.rs:300-303): one wavefront
-// per replicate as for P <= 8, the p(p+1)/2 + p + 1 <= 153 accumulators of a pass and the in-register Cholesky factor
-// live in the unified 512-entry register file at one wave per SIMD (the kernel is fully unrolled in P, so only the
-// lower triangles exist).  Three variants: continuous-only logit (the bench shape), and the superset kernel (factors,
-// sparse-factor exclusion, test_formula subsets) for logit and for the run-time family (probit / Poisson).  The general
-// (scenario) data path stays at P <= 8 (its own limit is 6 continuous predictors).
-#define MCP_GLM_WAVES 2  // entry-owning fit (irls_fit_wide): a small live set, keep the allocator at <= 256 registers
+// per replicate as for P <= 8, but the fit is irls_fit_wide (glm_impl.hpp): lanes own runs of entries of the normal
+// equations rather than rows, the factor lives in LDS, and nothing of size P^2 is held in registers (the row-owning fit
+// needs p(p+1)/2 + p + 1 = 153 accumulators per lane at P = 16 and spilled).  Two variants of the superset kernel
+// (factors, sparse-factor exclusion, test_formula subsets): logit, and the run-time family (probit / Poisson).  The
+// general (scenario) data path stays at P <= 8 (its own limit is 6 continuous predictors).
+#define MCP_GLM_WAVES 1  // LDS (design + staging, ~33 KB at n = 200) bounds the occupancy at 4-5 waves per CU anyway
 #include "glm_impl.hpp"
 
 namespace mcp {
@@ -35,9 +35,12 @@ static hipError_t launch_glm_wide_f(int P, const SimParams* d_prm, uint32_t n_si
 
 hipError_t launch_glm_wide(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
                            bool logit, hipStream_t st) {
+  // a wide design always lowers with the reduced-fit tables (host_lowering.cpp: `wide`), so the superset kernel serves
+  // every spec here; the family stays a template argument (the logit arm without the probit / Poisson expansions)
+  (void)factors;
+  (void)reduced;
   if (!logit) return launch_glm_wide_f<true, true, false>(P, d_prm, n_sims, max_n, st);
-  if (factors || reduced) return launch_glm_wide_f<true, true, true>(P, d_prm, n_sims, max_n, st);
-  return launch_glm_wide_f<false, false, true>(P, d_prm, n_sims, max_n, st);
+  return launch_glm_wide_f<true, true, true>(P, d_prm, n_sims, max_n, st);
 }
 
 }  // namespace mcp
