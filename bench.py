@@ -113,6 +113,11 @@ def main():
                          "the control plane; nccl: host counter blocks pooled through torch's RCCL process group "
                          "(the round-1 path); gloo: the same through gloo, to rehearse N>1 with several ranks on one GPU")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight per rank (1..4)")
+    ap.add_argument("--warm-ms", type=float, default=200.0,
+                    help="device warm-up: untimed steps of the same workload are issued after the W warm-up steps until this "
+                         "much wall time has gone into warm-up -- an idle MI355X needs ~50 ms of work to reach its "
+                         "sustained clocks (C2a: 1.07 ms per step after 5 warm-up steps, 0.95 ms after 50; DESIGN.md "
+                         "section 7); 0 = exactly W steps")
     args = ap.parse_args()
 
     import torch
@@ -229,10 +234,37 @@ def main():
 
     # W untimed warm-up steps; every batch slot in flight owns its own device arena, so at least `depth` batches must
     # have been issued before the timed region or a first-use hipMalloc lands inside it
-    run_steps(0, max(args.warmup, depth))
+    n_warm = max(args.warmup, depth)
+    tw = time.perf_counter()
+    run_steps(0, n_warm)
     barrier()
+    first_ms = 1e3 * (time.perf_counter() - tw)
+    if world > 1:
+        tt = torch.tensor([first_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        first_ms = float(tt.item())
+    if args.warm_ms > 0 and first_ms < 10.0 * args.warm_ms:  # (a first block that long has warmed the device by itself)
+        # ... then the same steps, still untimed, until the clocks have ramped.  The first block above also paid the
+        # one-time costs (code-object load, first-use hipMalloc of every batch slot), so the step time is taken from a
+        # second block; every rank must issue the same number of steps (each carries the collective), so the count
+        # comes from the slowest rank
+        tb = time.perf_counter()
+        run_steps(n_warm, depth)
+        barrier()
+        n_warm += depth
+        per_step = 1e3 * (time.perf_counter() - tb) / depth
+        if world > 1:
+            tt = torch.tensor([per_step], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            per_step = float(tt.item())
+        extra = int(min(2000, args.warm_ms / max(per_step, 1e-3)))
+        if extra:
+            run_steps(n_warm, extra)
+            n_warm += extra
+            barrier()
+    warm_ms = 1e3 * (time.perf_counter() - tw)
     t0 = time.perf_counter()
-    acc = run_steps(max(args.warmup, depth), args.steps)
+    acc = run_steps(n_warm, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, aux_ms, launches, pooled, r = acc["kernel_ms"], acc["aux_ms"], acc["launches"], acc["pooled"], acc["last"]
@@ -255,7 +287,8 @@ def main():
         fits_per_launch = S / max(launches / args.steps, 1)
         out = {
             "metric": "replicate-fits/sec", "value": value, "unit": "fits/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "warmup_steps_issued": n_warm, "warmup_ms": warm_ms,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 data plane / f64 fit", "data": "synthetic",
             "config": {"workload": f"{args.workload}: { {'c3': 'GLM', 'glm_wide': 'GLM', 'c4': 'LMM', 'lmm_slope': 'LMM', 'lmm_crossed': 'LMM', 'glmm': 'GLMM', 'glmm_slope': 'GLMM', 'glmm_crossed': 'GLMM'}.get(args.workload, 'OLS') } n={n_obs} p={spec.n_predictors} "
                                    f"({ {'c2a': 'x1,x2,x3 + x1:x2', 'c2b': 'ols_multi, 5 predictors', 'k4': '4 predictors', 'ols_wide': 'ols_wide of the reference bench, 15 predictors', 'c3': 'logit IRLS, 3 predictors', 'glm_wide': 'glm_wide of the reference bench, logit IRLS, 15 predictors', 'c4': 'random-intercept REML, 30 clusters x 20', 'glmm': 'logit, Laplace, (1 | g), 30 clusters x 20', 'glmm_slope': 'logit, Laplace, (1 + x1 | g), 30 clusters x 20', 'glmm_crossed': 'logit, Laplace, (1 + x1 | g) + (1 | item), 24 x 6 levels', 'lmm_slope': 'REML, (1 + x1 | g), 24 clusters x 20', 'lmm_crossed': 'REML, (1 | g) + (1 | item), 20 x 12 levels'}.get(args.workload, 'ols_multi on the grid N=50..1000 (20 fits per replicate), scenario ' + args.workload[3:]) }), "

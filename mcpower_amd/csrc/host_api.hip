@@ -10,6 +10,8 @@
 // MCP_ERR_UNSUPPORTED, and a missing device returns MCP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -57,7 +59,9 @@ int comm_allreduce_u64(unsigned long long* d_words, size_t n, hipStream_t st, st
 namespace {
 
 thread_local std::string g_err;
-int g_device = 0;
+// the device of this process (one process per GPU); set once by mcp_set_device before the first batch, read by every
+// host thread -- arenas, tickets and streams are per thread and rebuilt when it changes
+std::atomic<int> g_device{0};
 
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -112,6 +116,24 @@ struct Arena {
     *out = b.p;
     return hipSuccess;
   }
+  // give everything back to the device the arena was built on (device switch; the slots are grow-only otherwise)
+  void release() {
+    if (device < 0) return;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    if (stream) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipStreamDestroy(stream);
+    }
+    for (Buf& b : slots)
+      if (b.p) (void)hipFree(b.p);
+    for (Buf& b : pinned)
+      if (b.p) (void)hipHostFree(b.p);
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    *this = Arena();
+    if (cur >= 0) (void)hipSetDevice(cur);
+  }
   hipError_t event(size_t i, hipEvent_t* ev) {
     while (events.size() <= i) {
       hipEvent_t e;
@@ -148,15 +170,16 @@ int ensure_device(hipStream_t* st, const mcp_run_options* opts, Arena* extra = n
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     return fail(MCP_ERR_DEVICE, "no HIP device visible: the MI355X path cannot run (there is no CPU fallback)");
-  if (g_device >= n) return fail(MCP_ERR_DEVICE, "selected device index out of range");
-  HIP_TRY(hipSetDevice(g_device));
-  if (g_arena.device != g_device) {
-    g_arena = Arena();
-    g_arena.device = g_device;
+  const int dev = g_device.load();
+  if (dev >= n) return fail(MCP_ERR_DEVICE, "selected device index out of range");
+  HIP_TRY(hipSetDevice(dev));
+  if (g_arena.device != dev) {
+    g_arena.release();
+    g_arena.device = dev;
   }
-  if (extra && extra->device != g_device) {
-    *extra = Arena();
-    extra->device = g_device;
+  if (extra && extra->device != dev) {
+    extra->release();
+    extra->device = dev;
   }
   if (opts && opts->hip_stream) {
     *st = (hipStream_t)opts->hip_stream;
@@ -407,10 +430,14 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   if (chunk > n_sims) chunk = n_sims;
   const uint32_t n_chunks = (n_sims + chunk - 1) / chunk;
 
+  // a failing call may already have queued copies into `out` and kernels on the arena: drain the streams first, so that
+  // nothing in flight still points at host buffers about to be freed or at device buffers the next call reuses
 #define DEV_TRY(expr)                                                                                          \
   do {                                                                                                         \
     hipError_t e_ = (expr);                                                                                    \
     if (e_ != hipSuccess) {                                                                                    \
+      if (st) (void)hipStreamSynchronize(st);                                                                  \
+      if (g_upload_stream) (void)hipStreamSynchronize(g_upload_stream);                                        \
       mcp_free_result(out);                                                                                    \
       return fail(MCP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(e_) + " at " #expr);          \
     }                                                                                                          \
