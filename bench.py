@@ -134,10 +134,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if engine.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    dev_index = local_rank if args.backend != "gloo" else local_rank % engine.device_count()
+    dev_index = local_rank
+    if args.backend == "gloo" or os.environ.get("MCP_BENCH_SHARE_GPU") == "1":
+        dev_index = local_rank % engine.device_count()  # rehearsal of N > 1 on a box with fewer GPUs than ranks
     torch.cuda.set_device(dev_index)
     engine.set_device(dev_index)
     capi = args.backend == "capi" and world > 1
+    comm_fallback = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":  # host blocks through torch's RCCL process group
@@ -147,7 +150,20 @@ def main():
         if capi:
             # the product's communicator: rank 0 creates the id, gloo carries it, every rank joins; mcp_comm_init
             # returns after a one-word all-reduce has crossed the rings, so nothing of the bring-up is timed
-            mdist.init_comm(rank, world)
+            ok = 1
+            try:
+                mdist.init_comm(rank, world)
+            except Exception as e:
+                ok = 0
+                print(f"[bench] rank {rank}: the C-ABI communicator did not come up ({e}); if any rank reports this, "
+                      "every rank pools HOST counter blocks through the gloo group instead", file=sys.stderr, flush=True)
+            agreed = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0:  # all ranks leave the device-side collective together
+                if ok:
+                    engine.comm_destroy()
+                capi = False
+                comm_fallback = True
         else:
             t_init = torch.zeros(1, dtype=torch.int64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t_init)
@@ -295,7 +311,8 @@ def main():
                                    f"{S} replicates per GPU per step, seed 2137",
                        "pipeline": args.pipeline, "parallelism": f"replicate-sharded x{world}",
                        "collective": ("1 ncclAllReduce(sum, uint64) of the device-resident counters per step, inside the C ABI"
-                                      if capi or world == 1 else f"1 all-reduce(sum) of host counter blocks per step via torch ({args.backend})"),
+                                      if capi or world == 1 else f"1 all-reduce(sum) of host counter blocks per step via torch ({'gloo' if args.backend == 'capi' else args.backend})"
+                                      + (" -- FALLBACK: the C-ABI RCCL communicator did not come up on every rank (stderr)" if comm_fallback else "")),
                        "batches_in_flight": depth,
                        "host_ms_per_step": {"submit": acc["host_submit_ms"], "collect_wait": acc["host_collect_ms"]}},
             "power_last_step": (k_unc / n_pool).round(5).tolist(),

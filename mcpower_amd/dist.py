@@ -38,9 +38,18 @@ def init_comm(rank: int, world: int, group=None) -> None:
 
     from . import engine
 
-    box = [engine.comm_unique_id() if rank == 0 else None]
+    box, err = [None], None
+    if rank == 0:
+        try:
+            box[0] = engine.comm_unique_id()
+        except Exception as e:  # the other ranks are waiting in the broadcast: tell them before raising
+            err = e
     if world > 1:
         dist.broadcast_object_list(box, src=0, group=group)
+    if err is not None:
+        raise err
+    if box[0] is None:
+        raise RuntimeError("rank 0 could not create the RCCL rendezvous id")
     engine.comm_init(rank, world, box[0])
 
 
