@@ -172,10 +172,12 @@ def test_product_does_not_reference_the_oracle():
 
 
 def test_design_capture_refuses_structures_it_does_not_draw(engine):
-    """mcp_generate_design twins capture_sim0_data with the primary random intercept only: anything it would
-    silently leave out of the outcome is refused (host-side check, no device needed)."""
+    """mcp_generate_design twins capture_sim0_data including random slopes and extra groupings (tests/test_gpu_goldens.py);
+    what it would silently leave out of the outcome -- cluster-level (between) predictors -- is refused (host-side
+    check, no device needed)."""
     from helpers import load_case
     spec = load_case("lmm_slope_a")[0]
+    spec.between_var_indices = [1]
     with pytest.raises(S.EngineError) as e:
         engine.generate_design(spec, 100, 1, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "design capture" in str(e.value)
