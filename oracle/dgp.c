@@ -22,6 +22,7 @@
  * Unsupported (returns MCP_ERR_UNSUPPORTED): uploaded-data marginals,
  * bootstrap frame maps.
  */
+#include <pthread.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,11 +43,12 @@ static const double SQRT3 = 1.7320508075688772;
 /* ---- t(3) PPF table (marginals/t3.rs:44-96) -------------------------------- */
 #define T3_RES 2048
 static double g_t3[T3_RES];
-static int g_t3_ready = 0;
+static pthread_once_t g_t3_once = PTHREAD_ONCE_INIT;
 static const double T3_MIN = 0.00121, T3_MAX = 0.99879;
 
-static void t3_build(void) {
-  if (g_t3_ready) return;
+/* built once per process, by whichever replicate thread asks first: the unguarded lazy build it replaces let two
+ * threads of one batch fill and rescale the table concurrently (found by tests/test_fuzz_parity.py) */
+static void t3_build_once(void) {
   double denom = (double)(T3_RES - 1);
   for (int i = 0; i < T3_RES; ++i) {
     double p = T3_MIN + (T3_MAX - T3_MIN) * (double)i / denom;
@@ -62,8 +64,9 @@ static void t3_build(void) {
   }
   double sd = sqrt(m2 - m1 * m1);
   for (int i = 0; i < T3_RES; ++i) g_t3[i] /= sd;
-  g_t3_ready = 1;
 }
+
+static void t3_build(void) { pthread_once(&g_t3_once, t3_build_once); }
 
 static double t3_lookup(double pct) {
   double p = pct < T3_MIN ? T3_MIN : (pct > T3_MAX ? T3_MAX : pct);

@@ -26,9 +26,13 @@ _cflags = PORTABLE_CFLAGS
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (seconds)."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    """Compile the oracle with gcc (seconds).  `make` is always consulted -- it rebuilds only when a source is newer
+    than the library -- so an edited restatement can never be checked against a stale binary."""
+    if force:
+        subprocess.run(["make", "-C", _HERE, "clean"], capture_output=True)
+    r = subprocess.run(["make", "-C", _HERE], capture_output=True, text=True)
+    if r.returncode != 0 and not os.path.exists(_LIB_PATH):
+        raise RuntimeError("oracle build failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
     return _LIB_PATH
 
 

@@ -1,0 +1,129 @@
+"""Seeded random `SimulationSpec`s for the device-vs-oracle sweep (tests/test_fuzz_parity.py): every family of the path
+(OLS / GLM logit, probit, Poisson / random-intercept LMM / clustered GLM), with correlated predictors, factors,
+interactions, target subsets, multiplicity corrections, ragged grids and the scenario presets, drawn from one integer."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from mcpower_amd import spec as S
+from mcpower_amd.workloads import preset
+
+FAMILIES = ("ols", "ols_scen", "logit", "probit", "poisson", "glm_scen", "lme", "lme_scen", "glmm", "ols_general", "ols_posthoc")
+
+
+def _correlation(rng, k):
+    if k == 1:
+        return [1.0]
+    a = rng.normal(size=(k, k))
+    c = a @ a.T + k * np.eye(k)
+    d = 1.0 / np.sqrt(np.diag(c))
+    c = c * d[:, None] * d[None, :]
+    c = 0.5 * c + 0.5 * np.eye(k)          # moderate correlations, comfortably positive definite
+    np.fill_diagonal(c, 1.0)
+    return c.flatten().tolist()
+
+
+def random_spec(seed: int, family: str):
+    """-> (spec, sample_sizes, n_sims, exact): `exact` = the device must reproduce the oracle's flags bit for bit."""
+    rng = np.random.default_rng(1_000_003 * (1 + FAMILIES.index(family)) + seed)
+    scen = family.endswith("_scen")
+    clustered = family in ("lme", "lme_scen", "glmm")
+    k = int(rng.integers(1, 4 if clustered else 6))
+    n_fac = int(rng.integers(0, 2 if clustered or family == "glmm" else 3))
+    if family == "glmm":
+        k, n_fac = int(rng.integers(1, 3)), 0
+    levels = [int(rng.integers(2, 5)) for _ in range(n_fac)]
+    dummies = sum(l - 1 for l in levels)
+    max_p = 8 if family != "ols" else 12
+    while 1 + k + dummies > max_p - 1 and levels:
+        levels.pop()
+        dummies = sum(l - 1 for l in levels)
+    n_fac = len(levels)
+    cols = k + dummies
+    owner = [-1] * k + [f for f, l in enumerate(levels) for _ in range(l - 1)]   # factor owning each design column
+    inter = []
+    for _ in range(int(rng.integers(0, 3)) if family != "glmm" else 0):
+        if 1 + cols + len(inter) >= max_p or cols < 2:
+            break
+        a, b = sorted(int(v) for v in rng.choice(cols, size=2, replace=False))
+        if owner[a] >= 0 and owner[a] == owner[b]:
+            continue                               # two dummies of one factor: the product is identically zero
+        if [a + 1, b + 1] not in inter:
+            inter.append([a + 1, b + 1])
+    p = 1 + cols + len(inter)
+    props = []
+    for l in levels:
+        w = rng.uniform(0.6, 1.4, size=l)
+        props += (w / w.sum()).tolist()
+    effects = rng.uniform(-0.35, 0.35, size=p).round(3).tolist()
+    effects[0] = 0.0
+    n_t = int(rng.integers(1, p))
+    targets = sorted(int(v) for v in rng.choice(np.arange(1, p), size=n_t, replace=False))
+    s = S.SimulationSpec(
+        n_non_factor=k, n_factor_dummies=dummies, correlation=_correlation(rng, k),
+        var_types=[S.Distribution.Normal] * k, var_params=[0.0] * k, factor_n_levels=levels, factor_proportions=props,
+        factor_sampled=[None] * n_fac, effect_sizes=effects, target_indices=targets, interactions=inter,
+        correction_method=S.CorrectionMethod(int(rng.integers(0, 4))), report_overall=bool(rng.integers(0, 2)),
+        max_failed_fraction=1.0,
+    )
+    if n_fac and family in ("ols", "logit", "poisson") and rng.integers(0, 2):
+        s.factor_min_level_count = int(rng.integers(2, 8))
+    if family in ("logit", "probit", "poisson", "glm_scen", "glmm"):
+        s.estimator = S.EstimatorSpec.Glm
+        s.outcome_kind = S.OutcomeKind.Count if family == "poisson" else S.OutcomeKind.Binary
+        if family == "probit":
+            s.link = S.LinkKind.Probit
+        base = float(rng.uniform(0.4, 1.2)) if family == "poisson" else math.log(rng.uniform(0.25, 0.6) / 0.5) / 1.5
+        s.intercept = s.effect_sizes[0] = round(base, 3)
+    sizes = sorted({int(v) for v in rng.integers(40, 400, size=int(rng.integers(1, 4)))})
+    n_sims = 384
+    if clustered:
+        s.estimator = S.EstimatorSpec.Glm if family == "glmm" else S.EstimatorSpec.Mle
+        n_cl = int(rng.integers(6, 21))
+        if rng.integers(0, 2):
+            s.cluster = S.ClusterSpec(sizing=("FixedClusters", n_cl), tau_squared=round(float(rng.uniform(0.05, 0.6)), 3))
+            sizes = sorted({n_cl * int(v) for v in rng.integers(5, 16, size=int(rng.integers(1, 3)))})
+        else:
+            per = int(rng.integers(5, 16))
+            s.cluster = S.ClusterSpec(sizing=("FixedSize", per), tau_squared=round(float(rng.uniform(0.05, 0.6)), 3))
+            sizes = sorted({per * int(v) for v in rng.integers(6, 21, size=int(rng.integers(1, 3)))})
+        s.scenario = S.ScenarioPerturbations(name="optimistic", truth_start=bool(rng.integers(0, 2)))
+        n_sims = 48 if family == "glmm" else 192
+    if scen:
+        s.scenario = preset("realistic" if rng.integers(0, 2) else "doomer")
+        if family == "lme_scen":
+            s.scenario.lme = S.LmeScenarioPerturbations(random_effect_dist=S.ResidualDist.HighKurtosis,
+                                                        random_effect_df=float(rng.integers(4, 12)), icc_noise_sd=0.1)
+        n_sims = min(n_sims, 192)
+    if family == "ols_general":   # user-specified marginals, residual shape, heteroskedastic residuals, contrast pairs
+        kinds = [S.Distribution.Normal, S.Distribution.Binary, S.Distribution.RightSkewed, S.Distribution.LeftSkewed,
+                 S.Distribution.HighKurtosis, S.Distribution.Uniform]
+        s.var_types = [kinds[int(rng.integers(0, len(kinds)))] for _ in range(k)]
+        s.var_params = [round(float(rng.uniform(0.25, 0.75)), 2) if t == S.Distribution.Binary else 0.0 for t in s.var_types]
+        if rng.integers(0, 2):
+            s.residual_dist = S.ResidualDist(int(rng.integers(1, 5)))
+            s.residual_pinned = True
+            s.scenario = S.ScenarioPerturbations(name="custom", residual_df=float(rng.integers(4, 12)))
+        if rng.integers(0, 2):
+            s.heteroskedasticity_driver = int(rng.integers(1, k + 1))
+            s.scenario.heteroskedasticity_ratio = float(rng.choice([2.0, 3.0]))
+            s.scenario.name = "custom"
+        if len(targets) >= 2 and rng.integers(0, 2):
+            s.contrast_pairs = [(targets[0], targets[-1])]
+    if family == "ols_posthoc":
+        if not levels:                     # the family needs a factor: one 3-level factor after the continuous block
+            levels, dummies = [3], 2
+            s.n_factor_dummies, s.factor_n_levels, s.factor_proportions, s.factor_sampled = 2, [3], [0.5, 0.3, 0.2], [None]
+            s.interactions = []
+            s.effect_sizes = rng.uniform(-0.35, 0.35, size=1 + k + 2).round(3).tolist()
+            s.effect_sizes[0] = 0.0
+            s.target_indices = [1]
+        first = 1 + k                      # design columns of factor 0's dummies
+        s.posthoc = [S.PosthocSpec(0, list(range(first, first + levels[0] - 1)))]
+        s.factor_min_level_count = int(rng.integers(0, 6))
+        if rng.integers(0, 2):
+            s.scenario = S.ScenarioPerturbations(name="custom", sampled_factor_proportions=True)
+    exact = family in ("ols", "logit", "probit", "poisson", "ols_posthoc")
+    return s, sizes, n_sims, exact
