@@ -10,7 +10,7 @@ import numpy as np
 from mcpower_amd import spec as S
 from mcpower_amd.workloads import preset
 
-FAMILIES = ("ols", "ols_scen", "logit", "probit", "poisson", "glm_scen", "lme", "lme_scen", "glmm", "ols_general", "ols_posthoc")
+FAMILIES = ("ols", "ols_scen", "logit", "probit", "poisson", "glm_scen", "lme", "lme_scen", "glmm", "ols_general", "ols_posthoc", "lmm_general", "glmm_general")
 
 
 def _correlation(rng, k):
@@ -125,5 +125,49 @@ def random_spec(seed: int, family: str):
         s.factor_min_level_count = int(rng.integers(0, 6))
         if rng.integers(0, 2):
             s.scenario = S.ScenarioPerturbations(name="custom", sampled_factor_proportions=True)
+    if family in ("lmm_general", "glmm_general"):
+        return _mixed_general(rng, family)
     exact = family in ("ols", "logit", "probit", "poisson", "ols_posthoc")
     return s, sizes, n_sims, exact
+
+
+def _mixed_general(rng, family):
+    """Random slopes on the primary grouping and / or one extra grouping crossed with or nested in it (the general
+    mixed-model kernels), continuous predictors only; the clustered GLM also draws its Wald SE mode and, with a random
+    intercept alone, the quadrature order."""
+    glmm = family == "glmm_general"
+    k = int(rng.integers(1, 3 if glmm else 4))
+    effects = [0.0] + rng.uniform(0.1, 0.4, size=k).round(3).tolist()
+    s = S.SimulationSpec(
+        n_non_factor=k, correlation=_correlation(rng, k), var_types=[S.Distribution.Normal] * k, var_params=[0.0] * k,
+        effect_sizes=effects, target_indices=list(range(1, k + 1)), max_failed_fraction=1.0,
+        correction_method=S.CorrectionMethod(int(rng.integers(0, 4))),
+        estimator=S.EstimatorSpec.Glm if glmm else S.EstimatorSpec.Mle,
+    )
+    if glmm:
+        s.outcome_kind = S.OutcomeKind.Binary
+        s.intercept = s.effect_sizes[0] = round(math.log(rng.uniform(0.3, 0.5) / 0.5), 3)
+    n_cl = int(rng.integers(8, 17))
+    per = int(rng.integers(10, 21))
+    shape = int(rng.integers(0, 4))   # 0 slope, 1 crossed, 2 nested, 3 slope + crossed
+    slopes, extra, atom = [], [], n_cl
+    if shape in (0, 3):
+        slopes = [{"column": 0, "variance": round(float(rng.uniform(0.05, 0.2)), 3),
+                   "corr_with_intercept": round(float(rng.uniform(-0.3, 0.4)), 2), "corr_with": []}]
+    if shape in (1, 3):
+        n2 = int(rng.integers(4, 9))
+        extra = [{"relation": {"Crossed": {"n_clusters": n2}}, "tau_squared": round(float(rng.uniform(0.05, 0.3)), 3), "slopes": []}]
+        atom = n_cl * n2
+    if shape == 2:
+        npp = int(rng.integers(2, 4))
+        extra = [{"relation": {"NestedWithin": {"n_per_parent": npp}}, "tau_squared": round(float(rng.uniform(0.05, 0.3)), 3), "slopes": []}]
+        atom = n_cl * npp
+    tau2 = round(float(rng.uniform(0.3, 0.9) if glmm else rng.uniform(0.1, 0.5)), 3)
+    s.cluster = S.ClusterSpec(sizing=("FixedClusters", n_cl), tau_squared=tau2, slopes=slopes, extra_groupings=extra)
+    s.cluster_slope_design_cols = [1 + sl["column"] for sl in slopes]
+    s.extra_slope_cols = [[] for _ in extra]
+    s.scenario = S.ScenarioPerturbations(name="optimistic", truth_start=bool(rng.integers(0, 2)))
+    n = atom * max(1, round(n_cl * per / atom))
+    if glmm:
+        s.wald_se = S.WaldSe(int(rng.integers(0, 2)))
+    return s, [n], 32 if glmm else 64, False
