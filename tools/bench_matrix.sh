@@ -9,6 +9,7 @@ run --workload c2a --steps 20 --warmup 5 --depth 1
 run --workload c2b --steps 20 --warmup 5
 run --workload ols_wide --steps 10 --warmup 2
 run --workload c3 --steps 20 --warmup 5
+run --workload glm_wide --steps 10 --warmup 3
 run --workload c4 --steps 20 --warmup 5
 run --workload c4 --steps 20 --warmup 5 --sims-per-gpu 1000000
 run --workload c5_optimistic --steps 10 --warmup 2
