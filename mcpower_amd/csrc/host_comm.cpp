@@ -39,6 +39,14 @@ Rccl g_rccl;
 ncclComm_t g_comm = nullptr;
 int g_rank = -1, g_world = 0, g_comm_device = -1;
 unsigned long long* g_warm = nullptr;  // one device word: the bring-up all-reduce of comm_init
+// Every collective of the communicator is issued on ONE stream, in call order: a batch's launch stream hands over with
+// an event, the all-reduce runs on g_comm_stream, a second event hands back.  Batches in flight launch on their own
+// streams (host_api.hip); RCCL would accept collectives of one communicator from several streams, but a single issue
+// stream makes the order of the rings the order of the calls on every rank by construction.
+hipStream_t g_comm_stream = nullptr;
+constexpr int COMM_EVENTS = 16;  // > batches in flight per process; an event pair is reused COMM_EVENTS / 2 calls later
+hipEvent_t g_comm_ev[COMM_EVENTS] = {};
+unsigned g_comm_ev_next = 0;
 
 bool load_rccl(std::string& err) {
   if (g_rccl.handle) return true;
@@ -89,6 +97,17 @@ bool load_rccl(std::string& err) {
   return true;
 }
 
+void release_comm_stream() {  // caller holds g_mu
+  for (hipEvent_t& e : g_comm_ev) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  if (g_comm_stream) (void)hipStreamDestroy(g_comm_stream);
+  g_comm_stream = nullptr;
+  if (g_warm) (void)hipFree(g_warm);
+  g_warm = nullptr;
+}
+
 std::string rccl_msg(const char* what, ncclResult_t rc) {
   return std::string("RCCL error at ") + what + ": " + g_rccl.error_string(rc);
 }
@@ -122,9 +141,19 @@ int comm_allreduce_u64(unsigned long long* d_words, size_t n, hipStream_t st, st
     err = "invalid spec: MCP_ALLREDUCE_COUNTERS without a communicator (call mcp_comm_init first)";
     return MCP_ERR_INVALID_SPEC;
   }
-  const ncclResult_t rc = g_rccl.all_reduce(d_words, d_words, n, ncclUint64, ncclSum, g_comm, st);
+  hipEvent_t ev_in = g_comm_ev[g_comm_ev_next], ev_out = g_comm_ev[g_comm_ev_next + 1];
+  g_comm_ev_next = (g_comm_ev_next + 2u) % COMM_EVENTS;
+  if (hipEventRecord(ev_in, st) != hipSuccess || hipStreamWaitEvent(g_comm_stream, ev_in, 0) != hipSuccess) {
+    err = "HIP error: cannot hand the counters over to the communicator's stream";
+    return MCP_ERR_DEVICE;
+  }
+  const ncclResult_t rc = g_rccl.all_reduce(d_words, d_words, n, ncclUint64, ncclSum, g_comm, g_comm_stream);
   if (rc != ncclSuccess) {
     err = rccl_msg("ncclAllReduce", rc);
+    return MCP_ERR_DEVICE;
+  }
+  if (hipEventRecord(ev_out, g_comm_stream) != hipSuccess || hipStreamWaitEvent(st, ev_out, 0) != hipSuccess) {
+    err = "HIP error: cannot hand the pooled counters back to the launch stream";
     return MCP_ERR_DEVICE;
   }
   return MCP_OK;
@@ -179,19 +208,21 @@ int comm_init(int rank, int world, const mcp_comm_id* id, int device, std::strin
   // bring the rings up now (the first collective of a communicator builds its channels over xGMI), so that the first
   // batch of the caller does not pay for it; also proves the world agrees before any batch is enqueued
   unsigned long long one = 1ull, back = 0ull;
-  bool ok = hipMalloc((void**)&g_warm, sizeof one) == hipSuccess &&
-            hipMemcpy(g_warm, &one, sizeof one, hipMemcpyHostToDevice) == hipSuccess;
+  bool ok = hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < COMM_EVENTS; ++i) ok = hipEventCreateWithFlags(&g_comm_ev[i], hipEventDisableTiming) == hipSuccess;
+  g_comm_ev_next = 0;
+  ok = ok && hipMalloc((void**)&g_warm, sizeof one) == hipSuccess &&
+       hipMemcpy(g_warm, &one, sizeof one, hipMemcpyHostToDevice) == hipSuccess;
   if (ok) {
-    rc = g_rccl.all_reduce(g_warm, g_warm, 1, ncclUint64, ncclSum, comm, nullptr);
-    ok = rc == ncclSuccess && hipStreamSynchronize(nullptr) == hipSuccess &&
+    rc = g_rccl.all_reduce(g_warm, g_warm, 1, ncclUint64, ncclSum, comm, g_comm_stream);
+    ok = rc == ncclSuccess && hipStreamSynchronize(g_comm_stream) == hipSuccess &&
          hipMemcpy(&back, g_warm, sizeof back, hipMemcpyDeviceToHost) == hipSuccess;
   }
   if (!ok || back != (unsigned long long)world) {
     err = !ok ? std::string("the bring-up all-reduce of the communicator failed")
               : std::string("the bring-up all-reduce returned ") + std::to_string(back) + " for a world of " + std::to_string(world);
     (void)g_rccl.comm_destroy(comm);
-    if (g_warm) (void)hipFree(g_warm);
-    g_warm = nullptr;
+    release_comm_stream();
     return MCP_ERR_DEVICE;
   }
   g_comm = comm;
@@ -211,8 +242,7 @@ int comm_destroy(std::string& err) {
   g_rank = -1;
   g_world = 0;
   g_comm_device = -1;
-  if (g_warm) (void)hipFree(g_warm);
-  g_warm = nullptr;
+  release_comm_stream();
   if (rc != ncclSuccess) {
     err = rccl_msg("ncclCommDestroy", rc);
     return MCP_ERR_DEVICE;
