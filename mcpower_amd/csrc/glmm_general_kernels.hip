@@ -38,6 +38,7 @@ constexpr int GLMM_ROW = 20;  // simplex row stride (d = n_theta + P <= 12 + 6)
 constexpr uint32_t GG_MAX_TERMS = 3;
 
 typedef __attribute__((address_space(3))) double gdd;
+#include "mcp_stationary.hpp"  // MCP_STAT_H / MCP_STAT_TOL; the probes run as states of the machine below
 typedef __attribute__((address_space(3))) float gdf;
 typedef __attribute__((address_space(3))) uint16_t gdu;
 
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     gq_sync();
     // ---- the fit: a wave-uniform state machine around the single evaluation site ----
     enum : int { S_NM_BEGIN, S_NM_F0, S_NM_INIT_SETUP, S_NM_INIT_F, S_NM_LOOP, S_NM_FR, S_NM_FE, S_NM_FC, S_NM_SHRINK_SETUP,
-                 S_NM_SHRINK_F, S_NM_END, S_CUR, S_CUR_F, S_SNAP_SETUP, S_SNAP_F, S_FINAL, S_FINAL_F, S_HESS_A,
+                 S_NM_SHRINK_F, S_NM_END, S_STAT_SETUP, S_STAT_FP, S_STAT_FM, S_CUR, S_CUR_F, S_SNAP_SETUP, S_SNAP_F, S_FINAL, S_FINAL_F, S_HESS_A,
                  S_HESS_DIAG_SETUP, S_HESS_DIAG_F, S_HESS_OFF_B, S_HESS_OFF_SETUP, S_HESS_OFF_F, S_HESS_SOLVE, S_DECIDE };
     const uint32_t d = nth + (uint32_t)__popc(keep);
     gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe (= the stencil point of the Hessian); rows 1..d hold H later
@@ -834,9 +835,22 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
       gq_sync();
     };
     int st = S_NM_BEGIN, run = 0, restart = 0;
-    uint32_t n_eval = 0, vi = 0, lo = 0, hi = 0, snap_k = 0, ha = 0, hb = 0, th_free = 0u;
+    uint32_t n_eval = 0, vi = 0, lo = 0, hi = 0, snap_k = 0, ha = 0, hb = 0, th_free = 0u, stat_k = 0;
     int hq = 0;
-    double nm_step = 0.25, ftol = 1e-9, xtol = 1e-6, best = 0.0, prev = 0.0, cur = 0.0, f = 0.0;
+    double nm_step = 0.25, ftol = 1e-10, xtol = 1e-7, best = 0.0, prev = 0.0, cur = 0.0, f = 0.0;
+    double stat_h = 0.0, stat_fp = 0.0;
+    bool stat_one = false;
+    // a rejected stationarity check (mcp_stationary.hpp: the same probes, here as three states) takes the restart loop
+    auto stat_reject = [&]() {
+      run = 1; restart = 0;
+      if (n_eval < GLMM_MAX_EVAL) {
+        prev = best;
+        nm_step = 0.05; ftol = 1e-10; xtol = 1e-7;
+        st = S_NM_BEGIN;
+      } else {
+        st = S_CUR;
+      }
+    };
     double flo = 0.0, fhi = 0.0, fnh = 0.0, fr = 0.0, th_keep = 0.0, fadd = 0.0, fsub = 0.0, hacc = 0.0;
     bool outside = false, ok = false, count = true;
     gdd* pt = sx;
@@ -962,10 +976,12 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
             gq_sync();
             if (lane < d) sx[lane] = best_k;
             gq_sync();
+            if (run == 0) {  // first run: restarts only for a point the stationarity check rejects
+              stat_k = 0; st = S_STAT_SETUP;
+              break;
+            }
             bool again;
-            if (run == 0) {
-              run = 1; restart = 0; again = true;
-            } else if (!(prev - best > 1e-8)) {
+            if (!(prev - best > 1e-8)) {
               again = false;
             } else {
               ++restart; again = true;
@@ -977,6 +993,41 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
             } else {
               st = S_CUR;
             }
+          } break;
+          case S_STAT_SETUP: {  // probe +h along coordinate stat_k (the single probe of a parameter pinned at 0)
+            if (!(best < inf && best > -inf)) { stat_reject(); break; }
+            if (stat_k >= d) { st = S_CUR; break; }
+            gq_sync();
+            const double pk = sx[stat_k];
+            const bool bounded = stat_k < nth && ((m.diag_mask >> stat_k) & 1u);
+            stat_h = MCP_STAT_H;
+            stat_one = bounded && pk == 0.0;
+            if (!stat_one && bounded && pk < stat_h) stat_h = pk;
+            if (lane < d) xe[lane] = lane == stat_k ? (stat_one ? stat_h : sx[lane] + stat_h) : sx[lane];
+            gq_sync();
+            pt = xe; count = true; need = true; st = S_STAT_FP;
+          } break;
+          case S_STAT_FP:
+            stat_fp = f;
+            if (stat_one) {
+              if (!(f >= best - MCP_STAT_TOL)) stat_reject();
+              else { ++stat_k; st = S_STAT_SETUP; }
+              break;
+            }
+            gq_sync();
+            if (lane < d) xe[lane] = lane == stat_k ? sx[lane] - stat_h : sx[lane];
+            gq_sync();
+            pt = xe; count = true; need = true; st = S_STAT_FM;
+            break;
+          case S_STAT_FM: {
+            const double fp = stat_fp, fm = f;
+            bool rej = !(fp < inf && fp > -inf && fm < inf && fm > -inf) || fp < best - MCP_STAT_TOL || fm < best - MCP_STAT_TOL;
+            if (!rej) {
+              const double gk = (fp - fm) / (2.0 * stat_h), Hk = (fp - 2.0 * best + fm) / (stat_h * stat_h);
+              rej = Hk > 0.0 ? !(gk * gk <= 2.0 * MCP_STAT_TOL * Hk) : !(__builtin_fabs(fp - fm) <= 2.0 * MCP_STAT_TOL);
+            }
+            if (rej) stat_reject();
+            else { ++stat_k; st = S_STAT_SETUP; }
           } break;
           case S_CUR:
             pt = sx; count = true; need = true; st = S_CUR_F;

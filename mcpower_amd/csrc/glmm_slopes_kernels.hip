@@ -385,6 +385,7 @@ __device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const Glmm
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
 #include "mcp_glmm_hessian.hpp"
+#include "mcp_stationary.hpp"
 
 template <int P, int Q, bool SCEN>
 __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const SimParams* __restrict__ pp) {
@@ -564,8 +565,14 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
     }
     gq_sync();
     uint32_t n_eval = 0;
-    double best = glmm_nelder_mead<P, Q>(prm, m, 0.25, 1e-9, 1e-6, lane, n, ncl, n_pad, keep, n_eval);
-    for (int restart = 0; restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
+    double best = glmm_nelder_mead<P, Q>(prm, m, 0.25, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
+    // restarts only for a point the stationarity check rejects (mcp_stationary.hpp)
+    uint32_t lower0 = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < NTH; ++k) lower0 |= glmm_is_diag<Q>(k) ? (1u << k) : 0u;
+    auto fprobe = [&](gdd* pt) -> double { return glmm_f<P, Q>(prm, m, pt, lane, n, ncl, n_pad, keep, n_eval); };
+    const bool stationary = mixed_stationary(fprobe, m.simplex, (uint32_t)GLMM_ROW, NTH + (uint32_t)__popc(keep), lower0, best, lane);
+    for (int restart = 0; !stationary && restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
       const double prev = best;
       best = glmm_nelder_mead<P, Q>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
       if (!(prev - best > 1e-8)) break;

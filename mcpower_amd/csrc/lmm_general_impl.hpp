@@ -572,6 +572,8 @@ __device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLd
   return best;
 }
 
+#include "mcp_stationary.hpp"
+
 // SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
 // heteroskedastic residuals) plus the LME knobs -- random-effect shape, one ICC jitter per grouping
 template <int P, int Q0, bool SCEN>
@@ -878,8 +880,13 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
         x0[lane] = v;
       }
       lmg_sync();
-      double best = lmg_nelder_mead<Q0, false>(prm, m, 0.25, 1e-9, 1e-6, lane, n_rows, red, n_eval);
-      for (int restart = 0; restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
+      double best = lmg_nelder_mead<Q0, false>(prm, m, 0.25, 1e-10, 1e-7, lane, n_rows, red, n_eval);
+      // restarts (they guard against a collapsed simplex) only for a point the stationarity check rejects (mcp_stationary.hpp)
+      uint32_t lower0 = 0u;
+      for (uint32_t k = 0; k < d; ++k) lower0 |= lmg_is_diag(prm, k) ? (1u << k) : 0u;
+      auto fprobe = [&](ldd* pt) -> double { return lmg_f<Q0, false>(prm, m, pt, lane, n_rows, red, n_eval); };
+      const bool stationary = mixed_stationary(fprobe, m.simplex, (uint32_t)LMG_MAX_THETA, d, lower0, best, lane);
+      for (int restart = 0; !stationary && restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
         const double prev = best;
         best = lmg_nelder_mead<Q0, false>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, red, n_eval);
         if (!(prev - best > 1e-8)) break;
@@ -918,8 +925,10 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
         x0[lane] = v;
       }
       lmg_sync();
-      double best = lmg_nelder_mead<Q0, true>(prm, m, 0.25, 1e-9, 1e-6, lane, n_rows, red, n_eval);
-      for (int restart = 0; restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
+      double best = lmg_nelder_mead<Q0, true>(prm, m, 0.25, 1e-10, 1e-7, lane, n_rows, red, n_eval);
+      auto fprobe = [&](ldd* pt) -> double { return lmg_f<Q0, true>(prm, m, pt, lane, n_rows, red, n_eval); };
+      const bool stationary = mixed_stationary(fprobe, m.simplex, (uint32_t)LMG_MAX_THETA, nterms, (1u << nterms) - 1u, best, lane);
+      for (int restart = 0; !stationary && restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
         const double prev = best;
         best = lmg_nelder_mead<Q0, true>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, red, n_eval);
         if (!(prev - best > 1e-8)) break;

@@ -332,6 +332,12 @@ static double glmm_dev_cb(void* ctx, double* par) {
   return glmm_f((glmm_model*)ctx, par, &scratch);
 }
 
+typedef struct glmm_count_cb { glmm_model* m; uint32_t* n_eval; } glmm_count_cb;
+static double glmm_probe_cb(void* ctx, double* par) {  /* a probe of the stationarity check: counted like any evaluation */
+  glmm_count_cb* c = (glmm_count_cb*)ctx;
+  return glmm_f(c->m, par, c->n_eval);
+}
+
 /* fit from the start (theta0, beta0); fills f (beta, lower Cholesky factor of RX'RX, sigma_sq = 1) */
 static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, uint32_t mode, mcpo_gen_fit* f) {
   const uint32_t p = m->p, d = p + 1;
@@ -340,8 +346,12 @@ static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, uin
   for (uint32_t c = 0; c < p; ++c) par[1 + c] = beta0 ? beta0[c] : 0.0;
   memset(f, 0, sizeof *f);
   uint32_t n_eval = 0;
-  double best = glmm_nelder_mead(m, par, 0.25, 1e-9, 1e-6, &n_eval);
-  for (int restart = 0; restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
+  double best = glmm_nelder_mead(m, par, 0.25, 1e-10, 1e-7, &n_eval);
+  /* restarts (they guard against a collapsed simplex) only for a point the stationarity check rejects (oracle_internal.h) */
+  uint8_t lower0[GLMM_MAX_DIM] = {1};
+  glmm_count_cb probe = {m, &n_eval};
+  const int stationary = mcpo_stationary(glmm_probe_cb, &probe, par, d, lower0, best);
+  for (int restart = 0; !stationary && restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
     double prev = best;
     best = glmm_nelder_mead(m, par, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, &n_eval);
     if (!(prev - best > 1e-8)) break;

@@ -233,6 +233,12 @@ static double gg_dev_cb(void* ctx, double* par) {
   return gg_f((gg_model*)ctx, par, &scratch);
 }
 
+typedef struct gg_count_cb { gg_model* m; uint32_t* n_eval; } gg_count_cb;
+static double gg_probe_cb(void* ctx, double* par) {  /* a probe of the stationarity check: counted like any evaluation */
+  gg_count_cb* c = (gg_count_cb*)ctx;
+  return gg_f(c->m, par, c->n_eval);
+}
+
 /* mode: MCPO_MODE_HESSIAN selects the finite-difference Hessian Wald covariance (fit_glmm.c) over the free parameters */
 int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                 const mcpo_re_term* terms, uint32_t n_terms, const double* theta0, const double* beta0,
@@ -266,8 +272,13 @@ int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_
   for (uint32_t c = 0; c < p; ++c) par[m.nth + c] = beta0 ? beta0[c] : 0.0;
   memset(f, 0, sizeof *f);
   uint32_t n_eval = 0;
-  double best = gg_nelder_mead(&m, par, 0.25, 1e-9, 1e-6, &n_eval);
-  for (int restart = 0; restart < 4 && n_eval < GG_MAX_EVAL; ++restart) {
+  double best = gg_nelder_mead(&m, par, 0.25, 1e-10, 1e-7, &n_eval);
+  /* restarts only for a point the stationarity check rejects (oracle_internal.h) */
+  uint8_t lower0[GG_MAX_DIM] = {0};
+  for (uint32_t k = 0; k < m.nth; ++k) lower0[k] = m.is_diag[k];
+  gg_count_cb probe = {&m, &n_eval};
+  const int stationary = mcpo_stationary(gg_probe_cb, &probe, par, m.nth + p, lower0, best);
+  for (int restart = 0; !stationary && restart < 4 && n_eval < GG_MAX_EVAL; ++restart) {
     double prev = best;
     best = gg_nelder_mead(&m, par, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, &n_eval);
     if (!(prev - best > 1e-8)) break;

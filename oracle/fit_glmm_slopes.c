@@ -224,7 +224,11 @@ static double gs_nelder_mead(gs_model* m, const uint8_t* is_diag, double* x0, do
   return fv[lo];
 }
 
-typedef struct gs_cb { gs_model* m; const uint8_t* is_diag; } gs_cb;
+typedef struct gs_cb { gs_model* m; const uint8_t* is_diag; uint32_t* n_eval; } gs_cb;
+static double gs_probe_cb(void* ctx, double* par) {  /* a probe of the stationarity check: counted like any evaluation */
+  gs_cb* c = (gs_cb*)ctx;
+  return gs_f(c->m, c->is_diag, par, c->n_eval);
+}
 static double gs_dev_cb(void* ctx, double* par) {
   uint32_t scratch = 0;
   gs_cb* c = (gs_cb*)ctx;
@@ -265,8 +269,13 @@ int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint
   for (uint32_t c = 0; c < p; ++c) par[m.nth + c] = beta0 ? beta0[c] : 0.0;
   memset(f, 0, sizeof *f);
   uint32_t n_eval = 0;
-  double best = gs_nelder_mead(&m, is_diag, par, 0.25, 1e-9, 1e-6, &n_eval);
-  for (int restart = 0; restart < 4 && n_eval < GS_MAX_EVAL; ++restart) {
+  double best = gs_nelder_mead(&m, is_diag, par, 0.25, 1e-10, 1e-7, &n_eval);
+  /* restarts only for a point the stationarity check rejects (oracle_internal.h) */
+  uint8_t lower0[GS_MAX_DIM] = {0};
+  for (uint32_t k = 0; k < m.nth; ++k) lower0[k] = is_diag[k];
+  gs_cb probe = {&m, is_diag, &n_eval};
+  const int stationary = mcpo_stationary(gs_probe_cb, &probe, par, m.nth + p, lower0, best);
+  for (int restart = 0; !stationary && restart < 4 && n_eval < GS_MAX_EVAL; ++restart) {
     double prev = best;
     best = gs_nelder_mead(&m, is_diag, par, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, &n_eval);
     if (!(prev - best > 1e-8)) break;
@@ -349,7 +358,7 @@ int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint
      * that does not factor keeps "rx". */
     uint8_t th_free[6];
     for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = !(is_diag[k] && par[k] < GS_THETA_ZERO);
-    gs_cb cb = {&m, is_diag};
+    gs_cb cb = {&m, is_diag, NULL};
     double lh[MCPO_MAX_P * MCPO_MAX_P];
     if (mcpo_fd_hessian_factor(gs_dev_cb, &cb, par, m.nth, p, th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
   }

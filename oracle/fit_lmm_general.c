@@ -273,6 +273,13 @@ static double gen_f(gen_model* m, const uint8_t* is_diag, double* th, gen_eval* 
   return e->ok ? e->dev : INFINITY;
 }
 
+typedef struct gen_count_cb { gen_model* m; const uint8_t* is_diag; uint32_t* n_eval; } gen_count_cb;
+static double gen_probe_cb(void* ctx, double* th) {  /* a probe of the stationarity check: counted like any evaluation */
+  gen_count_cb* c = (gen_count_cb*)ctx;
+  gen_eval e;
+  return gen_f(c->m, c->is_diag, th, &e, c->n_eval);
+}
+
 /* one Nelder-Mead run from x0 with initial edge `step`; returns the best value, x0 <- best point */
 static double gen_nelder_mead(gen_model* m, const uint8_t* is_diag, double* x0, double step, double ftol, double xtol,
                               uint32_t* n_eval) {
@@ -343,8 +350,11 @@ static void gen_minimise(gen_model* m, const double* theta_start, mcpo_gen_fit* 
   }
   memset(f, 0, sizeof *f);
   uint32_t n_eval = 0;
-  double best = gen_nelder_mead(m, is_diag, th, 0.25, 1e-9, 1e-6, &n_eval);
-  for (int restart = 0; restart < 4 && n_eval < GEN_MAX_EVAL; ++restart) { /* restarts guard against a collapsed simplex */
+  double best = gen_nelder_mead(m, is_diag, th, 0.25, 1e-10, 1e-7, &n_eval);
+  /* restarts guard against a collapsed simplex: taken only for a point the stationarity check rejects (oracle_internal.h) */
+  gen_count_cb probe = {m, is_diag, &n_eval};
+  const int stationary = mcpo_stationary(gen_probe_cb, &probe, th, d, is_diag, best);
+  for (int restart = 0; !stationary && restart < 4 && n_eval < GEN_MAX_EVAL; ++restart) {
     double prev = best;
     best = gen_nelder_mead(m, is_diag, th, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, &n_eval);
     if (!(prev - best > 1e-8)) break;

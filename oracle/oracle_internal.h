@@ -2,6 +2,8 @@
 #ifndef MCP_ORACLE_INTERNAL_H
 #define MCP_ORACLE_INTERNAL_H
 #include <stdint.h>
+#include <math.h>
+#include <string.h>
 #include "mcp_oracle.h"
 
 #define MCPO_MAX_K 16      /* continuous predictors */
@@ -72,6 +74,43 @@ int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_
 typedef double (*mcpo_dev_fn)(void* ctx, double* par);
 int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t nth, uint32_t p, const uint8_t* theta_free,
                            double fx, double* l_out);
+
+/* Stationarity check of a simplex result; it replaces the unconditional restart of the four mixed-model optimisers
+ * (a restart re-shrinks a fresh simplex from 0.05 to the tolerance: ~160 evaluations that, in 2 000 of 2 000 replicates
+ * of the reference bench's glmm_intercept, moved no decision).  Central differences of the objective along every
+ * coordinate with lme4's deriv12 step h = 1e-4 (h = par_k for a bounded parameter closer than that to 0, the single
+ * probe +h for one pinned AT 0): the point is accepted when no probe is lower than f0 by more than 1e-8 and the Newton
+ * decrease g^2 / (2 H) each coordinate predicts stays below 1e-8 -- the same 1e-8 the restart loop calls "no progress".
+ * 2 d evaluations.  A rejected point takes the restart loop as before.  lower0[k] != 0: parameter k is bounded below
+ * by 0 (a diagonal of the covariance template).  Probes are issued k ascending, +h then -h. */
+#define MCPO_STAT_H 1e-4
+#define MCPO_STAT_TOL 1e-8
+#define MCPO_STAT_MAX_DIM 32
+static inline int mcpo_stationary(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t d, const uint8_t* lower0, double f0) {
+  double x[MCPO_STAT_MAX_DIM];
+  if (d > MCPO_STAT_MAX_DIM || !isfinite(f0)) return 0;
+  for (uint32_t k = 0; k < d; ++k) {
+    double h = MCPO_STAT_H;
+    const int bounded = lower0 && lower0[k];
+    memcpy(x, par, sizeof(double) * d);
+    if (bounded && par[k] == 0.0) {
+      x[k] = h;
+      const double fp = fn(ctx, x);
+      if (!(fp >= f0 - MCPO_STAT_TOL)) return 0;
+      continue;
+    }
+    if (bounded && par[k] < h) h = par[k];
+    x[k] = par[k] + h;
+    const double fp = fn(ctx, x);
+    memcpy(x, par, sizeof(double) * d);
+    x[k] = par[k] - h;
+    const double fm = fn(ctx, x);
+    if (!(isfinite(fp) && isfinite(fm)) || fp < f0 - MCPO_STAT_TOL || fm < f0 - MCPO_STAT_TOL) return 0;
+    const double g = (fp - fm) / (2.0 * h), H = (fp - 2.0 * f0 + fm) / (h * h);
+    if (H > 0.0 ? !(g * g <= 2.0 * MCPO_STAT_TOL * H) : !(fabs(fp - fm) <= 2.0 * MCPO_STAT_TOL)) return 0;
+  }
+  return 1;
+}
 
 int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint32_t* ids, uint32_t n, uint32_t ld,
                              uint32_t p, uint32_t ncl, uint32_t q, const uint32_t* slope_cols, const double* theta0,
