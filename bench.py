@@ -53,14 +53,14 @@ WORKLOADS = {
     # general mixed models (reference cases lmm_slope_a / lmm_crossed_a, validation/formulas.R:385-470): 960 / 1440
     # draws + ~300 / ~180 criterion evaluations of ~700 / ~1500 flops (block Cholesky of the penalised normal equations)
     # clustered logistic (reference case glmm_intercept, formulas.R:1092-1100): 1 230 draws + ~300 evaluations of the
-    # Laplace deviance, each ~6 Fisher-scoring sweeps over the 600 rows (exp, log1p, ~25 flops per row)
-    "glmm": ("spec_glmm", 600, 4.5e7, 4 * 600 * 2),
+    # Laplace deviance (~180 since the stationarity check replaced the unconditional restart), each ~6 Fisher-scoring sweeps over the 600 rows (exp, log1p, ~25 flops per row)
+    "glmm": ("spec_glmm", 600, 2.6e7, 4 * 600 * 2),   # ~177 evaluations since the stationarity check (305 before)
     # ... with a random slope (reference case glmm_slope, formulas.R): ~900 evaluations, 2 x 2 penalised systems per cluster
-    "glmm_slope": ("spec_glmm_slope", 600, 1.6e8, 4 * 600 * 2),
+    "glmm_slope": ("spec_glmm_slope", 600, 9.6e7, 4 * 600 * 2),   # ~400 evaluations (664 before)
     # ... and a crossed grouping (reference case glmm_slope_crossed, formulas.R:1130-1140): 54 random effects, joint modes
-    "glmm_crossed": ("spec_glmm_crossed", 480, 1.2e9, 4 * 480 * 2),
-    "lmm_slope": ("spec_lmm_slope", 480, 2.6e5, 4 * 480 * 2),
-    "lmm_crossed": ("spec_lmm_crossed", 480, 3.4e5, 4 * 480 * 3),
+    "glmm_crossed": ("spec_glmm_crossed", 480, 7.4e8, 4 * 480 * 2),
+    "lmm_slope": ("spec_lmm_slope", 480, 1.6e5, 4 * 480 * 2),
+    "lmm_crossed": ("spec_lmm_crossed", 480, 2.0e5, 4 * 480 * 3),
     # C5: C2b design on the grid N = 50..1000 (20 prefix fits per replicate on shared draws) under the three
     # frozen scenario presets; ops per FIT = (6000 draws x 47 + 2 x 28000 MAC + 20 solves x 600) / 20 fits
     "c5_optimistic": ("spec_c2b", 1000, 1.75e4, 4 * 1000 * 6 // 20),
