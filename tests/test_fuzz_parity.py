@@ -1,5 +1,7 @@
 """Seeded random specs over every family of the path (tests/fuzz_specs.py): the oracle runs them and the host lowering
 accepts them (CPU); the device reproduces the oracle's decisions replicate by replicate through the C ABI (GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,7 +9,7 @@ from fuzz_specs import FAMILIES, random_spec
 from helpers import BASE_SEED
 from mcpower_amd import spec as S
 
-SEEDS = range(40)
+SEEDS = range(int(os.environ.get("MCP_FUZZ_SEEDS", "40")))  # a one-off deeper sweep: MCP_FUZZ_SEEDS=400
 FLAGS = ("uncorrected", "corrected", "converged", "overall", "joint_unc", "boundary_hit", "factor_excluded", "pinned_components",
          "posthoc_unc", "posthoc_cor")
 
