@@ -6,7 +6,7 @@
 // parameter closer than that to 0; the single probe +h for one pinned AT 0); the point is accepted when no probe is
 // lower than f0 by more than 1e-8 and the Newton decrease g^2 / (2 H) each coordinate predicts stays below 1e-8 -- the
 // 1e-8 the restart loop calls "no progress".  2 d evaluations; a rejected point takes the restart loop as before.
-// Same probes in the same order (k ascending, +h then -h) as mcpo_stationary (oracle/oracle_internal.h).
+// Same probes in the same order (k ascending, +h then -h) as the checker restates them (oracle/oracle_internal.h).
 // Included inside namespace mcp by each kernel file, after its LDS pointer typedefs (like mcp_glmm_hessian.hpp).
 #pragma once
 
