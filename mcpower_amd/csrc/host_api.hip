@@ -27,7 +27,7 @@ hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool
 hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims, bool scen, hipStream_t st);
 hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
 hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
-hipError_t launch_scenario_design(const SimParams* d_prm, uint32_t n_sims, hipStream_t st);
+hipError_t launch_scenario_design(const SimParams* d_prm, uint32_t n_sims, hipStream_t st, uint32_t* d_hist = nullptr);
 hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, hipStream_t st);
 hipError_t launch_ols_fit_provided(int P, const float* design, const float* outcome, uint32_t n_fits, uint32_t n,
                                    double* beta, double* se, double* tsq, double* rss, double* sst, uint8_t* conv,
@@ -81,7 +81,7 @@ struct Arena {
     void* p = nullptr;
     size_t cap = 0;
   };
-  Buf slots[30];
+  Buf slots[32];
   Buf pinned[2];  // host staging: [0] the upload blob, [1] the counters coming back
   hipStream_t stream = nullptr;
   std::vector<hipEvent_t> events;
@@ -164,7 +164,7 @@ thread_local Ticket g_tickets[MAX_IN_FLIGHT];
 thread_local hipStream_t g_upload_stream = nullptr;  // a batch in flight uploads its tables beside the running kernel
 thread_local hipEvent_t g_epoch = nullptr;           // recorded once per host thread: origin of kernel_begin_ms / kernel_end_ms
 
-enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS, S_PINNED, S_TAU_HAT };
+enum Slot { S_PRM = 0, S_CRIT, S_LEVELS, S_COUNTERS, S_UNC, S_COR, S_CONV, S_OVERALL, S_STAT, S_TILE, S_MISC0, S_MISC1, S_BOUNDARY, S_JOINT, S_SCEN_L, S_SCEN_META, S_SCEN_BETA, S_T3, S_PH_UNC, S_PH_COR, S_FX, S_CRIT_RED, S_RED_ROW, S_SCEN_TAU, S_UPLOAD_NORMAL, S_UPLOAD_DATA, S_LMM_REC, S_LMM_FLAGS, S_PINNED, S_TAU_HAT, S_SCEN_HIST, S_SCEN_PERM };
 
 int ensure_device(hipStream_t* st, const mcp_run_options* opts, Arena* extra = nullptr) {
   int n = 0;
@@ -511,7 +511,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   const bool scen = prm.scen_active;
   const int flavor = scen ? 2 : (spec->n_factors > 0 ? 1 : 0);
   double *d_scen_L = nullptr, *d_scen_beta = nullptr, *d_t3 = nullptr, *d_scen_tau = nullptr;
-  uint32_t* d_scen_meta = nullptr;
+  uint32_t *d_scen_meta = nullptr, *d_scen_hist = nullptr, *d_scen_perm = nullptr;
   if (scen) {
     const uint32_t K = spec->n_non_factor;
     if (spec->cluster.present)  // realised tau^2 per replicate: the primary grouping, then each extra grouping
@@ -523,6 +523,11 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
       const std::vector<double> t3 = mcp::build_t3_table();
       DEV_TRY(ar.get(S_T3, t3.size() * sizeof(double), (void**)&d_t3));
       DEV_TRY(hipMemcpy(d_t3, t3.data(), t3.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    // the lane-per-replicate fused kernel runs the replicates of a launch grouped by transform class
+    if (!glm && !reduced && !staged && spec->n_non_factor <= 6u) {
+      DEV_TRY(ar.get(S_SCEN_HIST, (mcp::SCEN_CLASSES + 1u) * sizeof(uint32_t), (void**)&d_scen_hist));
+      DEV_TRY(ar.get(S_SCEN_PERM, (size_t)chunk * sizeof(uint32_t), (void**)&d_scen_perm));
     }
   }
   double *d_up_normal = nullptr, *d_up_data = nullptr;
@@ -586,6 +591,8 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   prm.tile_sims = chunk;
   prm.scen_L = d_scen_L;
   prm.scen_meta = d_scen_meta;
+  prm.scen_hist = d_scen_hist;
+  prm.scen_perm = d_scen_perm;
   prm.scen_beta = d_scen_beta;
   prm.scen_tau_sq = d_scen_tau;
   prm.scen_stride = chunk;
@@ -613,7 +620,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     DEV_TRY(ar.event(2 + c * ev_per_chunk, &e0));
     DEV_TRY(ar.event(3 + c * ev_per_chunk, &e1));
     if (staged || glm || reduced) DEV_TRY(ar.event(4 + c * ev_per_chunk, &e2));
-    if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st));
+    if (scen) DEV_TRY(mcp::launch_scenario_design(d_prm + c, h_prm[c].n_sims, st, d_scen_hist));
     DEV_TRY(hipEventRecord(e0, st));
     if (glm) {
       if (glmm_general) DEV_TRY(mcp::launch_glmm_general((int)P, d_prm + c, h_prm[c].n_sims, mcp::glmm_general_lds_bytes(prm), scen, st));

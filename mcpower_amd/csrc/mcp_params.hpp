@@ -27,6 +27,7 @@ constexpr int CTR_COPIES = 256;
 constexpr int LMG_MAX_TERMS = 3;   // primary + MCP_MAX_EXTRA_GROUPINGS
 constexpr int LMG_MAX_SLOPES = 2;  // MCP_MAX_RE_SLOPES
 constexpr int LMG_MAX_THETA = 12;
+constexpr uint32_t SCEN_CLASSES = 8192;  // transform class of a replicate: 6 + 6 marginal bits, 1 residual bit
 
 struct SimParams {
   uint64_t base_seed;
@@ -123,6 +124,10 @@ struct SimParams {
   double* scen_beta;               // [P][scen_stride] per-study effects (heterogeneity > 0) or null
   uint32_t scen_stride;
   uint32_t _pad_scen;
+  // divergence-aware replicate order of the lane-per-replicate general-path kernel (scenario_kernels.hip): replicates
+  // counted per transform class, then scattered so that the lanes of a wave share the class; null = identity
+  uint32_t* scen_hist;             // [SCEN_CLASSES + 1] class counts -> exclusive offsets, or null
+  uint32_t* scen_perm;             // [scen_stride] lane -> local replicate index, or null
   const double* t3_table;          // 2048-knot standardized t(3) PPF table (marginals/t3.rs) or null
   // uploaded data (data_gen.rs:552-604, :1243-1277): NORTA quantile table and the strict-bootstrap frame
   const double* upload_normal;     // [upload_rows][K] sorted standardised values per non-factor column, or null

@@ -155,7 +155,9 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
     float z0[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) z0[r] = st[(K * 4u + r) * STRIDE];
-    if (prm.resid_extra_cols) {
+    // the extra columns feed the chi-square forms only: a wave none of whose lanes holds one skips their draws (Philox
+    // is counter-based, nothing downstream depends on the skipped words)
+    if (prm.resid_extra_cols && __builtin_amdgcn_ballot_w64(rd >= 1u && rd <= 3u) != 0ull) {
       const uint32_t dfi = prm.resid_extra_cols - 1u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) chi_sk[r] = (double)z0[r] * (double)z0[r];  // skewed forms start at slot 0
