@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void scenario_class_scatter_kernel(const SimPa
   const uint32_t lsim = blockIdx.x * blockDim.x + threadIdx.x;
   if (lsim >= prm.n_sims) return;
   const uint32_t pos = atomicAdd(&prm.scen_hist[scen_class(prm.scen_meta[lsim], prm.K)], 1u);
-  prm.scen_perm[pos] = lsim;
+  // descending class value: the costly classes (residual columns, then the log, then Phi -- the high bits) are dispatched
+  // first and the cheap ones fill the tail of the launch
+  prm.scen_perm[prm.n_sims - 1u - pos] = lsim;
 }
 
 __global__ __launch_bounds__(256) void scenario_design_kernel(const SimParams* __restrict__ pp) {

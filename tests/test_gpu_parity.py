@@ -650,3 +650,23 @@ def test_full_size_c4_lmm_properties(engine, oracle):
     assert np.array_equal(a.uncorrected[:1000], head.uncorrected) and np.array_equal(a.boundary_hit[:1000], head.boundary_hit)
     # Wald power of x1 = 0.15 with se = 1 / sqrt(n) on standardised within-cluster variation: ~0.95
     assert 0.93 < a.uncorrected[:, 0, 0].mean() < 0.97
+
+
+def test_transform_class_lane_order_changes_no_result(engine):
+    """The general-path OLS kernel runs the replicates of a launch grouped by transform class (scenario_kernels.hip);
+    the identity order (MCP_DEBUG_NO_CLASS_ORDER=1, read once per process) must give the same counters and flags."""
+    import json
+    import subprocess
+    import sys
+    code = ("import json, sys; sys.path.insert(0, 'tests');"
+            "from helpers import spec_c2b, preset, BASE_SEED, C5_GRID; from mcpower_amd import engine;"
+            "s = spec_c2b(); s.scenario = preset('realistic');"
+            "r = engine.run_batch(s, C5_GRID, 20000, BASE_SEED, chunk_sims=7000);"
+            "print(json.dumps([r.counters.tolist(), int(r.uncorrected.astype('u8').sum()), r.uncorrected[:64].tolist()]))")
+    outs = []
+    for env_extra in ({}, {"MCP_DEBUG_NO_CLASS_ORDER": "1"}):
+        env = dict(os.environ, **env_extra)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(__file__)))
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
