@@ -7,6 +7,7 @@ Bars: f32 data plane bit-exact; squared statistics within 1e-10 r
 < 1e-9 (a knife-edge decision: expected count 0); counters identical whenever flags are.
 """
 import math
+import os
 
 import numpy as np
 import pytest
