@@ -527,7 +527,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     // the lane-per-replicate fused kernel runs the replicates of a launch grouped by transform class
     // (MCP_DEBUG_NO_CLASS_ORDER=1 keeps the identity order: tests compare the two)
     static const bool no_class_order = std::getenv("MCP_DEBUG_NO_CLASS_ORDER") != nullptr;
-    if (!glm && !reduced && !staged && spec->n_non_factor <= 6u && !no_class_order) {
+    if (!glm && !staged && spec->n_non_factor <= 6u && !no_class_order) {
       DEV_TRY(ar.get(S_SCEN_HIST, (mcp::SCEN_CLASSES + 1u) * sizeof(uint32_t), (void**)&d_scen_hist));
       DEV_TRY(ar.get(S_SCEN_PERM, (size_t)chunk * sizeof(uint32_t), (void**)&d_scen_perm));
     }

@@ -226,7 +226,8 @@ __global__ __launch_bounds__(BLOCK) void ols_reduced_kernel(const SimParams* __r
   const SimParams& prm = *pp;
   const uint32_t local = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = local < prm.n_sims;
-  const uint32_t lsim = active ? local : (prm.n_sims - 1u);
+  // general path: lanes take the replicates of the launch in transform-class order (scenario_kernels.hip)
+  const uint32_t lsim = active ? ((SCEN && prm.scen_perm) ? prm.scen_perm[local] : local) : (prm.n_sims - 1u);
   const uint64_t sim_id = prm.sim_begin + lsim;
   const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
   const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
