@@ -45,6 +45,22 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// NT threads (NT / 64 waves) share one replicate when its design is too large for many single-wave blocks per CU: each
+// wave reduces as above, the wave totals cross through LDS and every lane adds them in wave order.  NT = 64 is the plain
+// wave reduction (same instructions as before the parameter existed).
+template <int NT>
+__device__ __forceinline__ double block_allreduce_sum(double v, double* red, uint32_t lane) {
+  v = wave_allreduce_sum(v);
+  if (NT == WAVE) return v;
+  if ((lane & 63u) == 0u) red[lane >> 6] = v;
+  __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int w = 1; w < NT / WAVE; ++w) s += red[w];
+  __syncthreads();
+  return s;
+}
+
 // IRLS on the first n rows of the LDS-resident design, all lanes returning identical values.
 // MASKED: `keep` selects the fitted columns; dropped columns become identity rows/columns of X'WX and zeros of
 // X'Wz, so their coefficients stay exactly 0 and the kept block is solved by the same operations as the gathered
@@ -55,10 +71,10 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
 // the factor dies with the pass: nothing of size P^2 is live across passes or after the fit, and the Cholesky runs in
 // place on the packed lower triangle of X'WX -- the live set of a pass is one triangle (P(P+1)/2 doubles: 136 at
 // P = 16) plus O(P), which is what lets the wide instantiations (P = 13..16) stay in the 512-entry register file.
-template <int P, bool MASKED, bool LOGIT, int MT>
+template <int P, bool MASKED, bool LOGIT, int MT, int NT = WAVE>
 __device__ __forceinline__ void irls_fit(const SimParams& prm, const float* design, uint32_t n_pad, uint32_t n, uint32_t lane,
                                          uint32_t keep, uint32_t fam_rt, uint32_t nt, double (&beta)[P], double (&tsq)[MT],
-                                         double& dev, bool& conv) {
+                                         double& dev, bool& conv, double* red = nullptr) {
   const uint32_t fam = LOGIT ? 0u : fam_rt;
   dev = __builtin_nan("");
   double dev_prev = __builtin_inf();
@@ -69,7 +85,7 @@ __device__ __forceinline__ void irls_fit(const SimParams& prm, const float* desi
     for (int i = 0; i < P * (P + 1) / 2; ++i) xtwx[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < P; ++i) xtwz[i] = 0.0;
-    for (uint32_t i = lane; i < n; i += WAVE) {
+    for (uint32_t i = lane; i < n; i += NT) {
       double xd[P];
       xd[0] = 1.0;
 #pragma unroll
@@ -98,6 +114,32 @@ __device__ __forceinline__ void irls_fit(const SimParams& prm, const float* desi
 #pragma unroll
     for (int i = 0; i < P; ++i) xtwz[i] = wave_allreduce_sum(xtwz[i]);
     dev = wave_allreduce_sum(d);
+    if (NT > WAVE) {  // the wave totals of all P(P+1)/2 + P + 1 sums cross through LDS in one exchange
+      constexpr int TRI = P * (P + 1) / 2, NV = TRI + P + 1, NW = NT / WAVE;
+      double* tot = red + (size_t)NW * NV;
+      if ((lane & 63u) == 0u) {
+        double* mine = red + (size_t)(lane >> 6) * NV;
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) mine[i] = xtwx[i];
+#pragma unroll
+        for (int i = 0; i < P; ++i) mine[TRI + i] = xtwz[i];
+        mine[TRI + P] = dev;
+      }
+      __syncthreads();
+      if (lane < (uint32_t)NV) {  // lane i adds sum i over the waves, in wave order
+        double a = red[lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) a += red[(size_t)w * NV + lane];
+        tot[lane] = a;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TRI; ++i) xtwx[i] = tot[i];
+#pragma unroll
+      for (int i = 0; i < P; ++i) xtwz[i] = tot[TRI + i];
+      dev = tot[TRI + P];
+      __syncthreads();
+    }
     if (!(dev < __builtin_inf())) break;  // NaN / inf deviance
     const bool done = it > 0 && __builtin_fabs(dev - dev_prev) / (__builtin_fabs(dev) + 0.1) < IRLS_EPS;
     // Cholesky of X'WX in place on its packed lower triangle, and the weighted least-squares update (all lanes, identical
@@ -380,8 +422,12 @@ __device__ __forceinline__ void irls_fit_wide(const SimParams& prm, const float*
 // smallest minimum level count (code 2) and refit once from a cold start (:1976-2030).
 // SCEN: general data path -- per-replicate correlation factor / marginals from the scenario design records and
 // per-study effects (data_gen.rs:709-751, 990-1093); the fit still starts from the spec's effects.
-template <int P, bool FACTORS, bool RED, bool SCEN, bool LOGIT>
-__global__ __launch_bounds__(WAVE, MCP_GLM_WAVES) void glm_sim_kernel(const SimParams* __restrict__ pp) {
+// NT: threads sharing one replicate (64, or 256 / 512 for designs whose LDS footprint leaves a CU with fewer than two
+// single-wave blocks per SIMD: the reference bench's glm_large_n, n = 5 000, is 80 KB -- ONE wave per CU at NT = 64);
+// rows spread over all NT lanes, sums cross the waves through LDS.  The reduced-fit and wide variants stay at 64.
+template <int P, bool FACTORS, bool RED, bool SCEN, bool LOGIT, int NT = WAVE>
+__global__ __launch_bounds__(NT, MCP_GLM_WAVES) void glm_sim_kernel(const SimParams* __restrict__ pp) {
+  static_assert(NT == WAVE || (!RED && !SCEN && P <= MAX_P_WAVE), "several waves per replicate: plain narrow fits only");
   extern __shared__ float lds[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
@@ -397,13 +443,14 @@ __global__ __launch_bounds__(WAVE, MCP_GLM_WAVES) void glm_sim_kernel(const SimP
   // right-hand side | z^2 | beta | test solves) over the staging area, which is dead once the rows exist
   constexpr bool WIDE = P > MAX_P_WAVE;
   float* design = lds + (WIDE ? n_pad : 0u);  // P columns x n_pad: x1..x_{P-1}, y
-  float* st = design + (size_t)P * n_pad + lane;  // staging, stride WAVE
+  float* st = design + (size_t)P * n_pad + lane;  // staging, stride NT
   double* fit_am = (double*)(design + (size_t)P * n_pad);
-  double* fit_wk = (double*)(design + (size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE);
+  double* fit_wk = (double*)(design + (size_t)P * n_pad + (size_t)4 * (P + 1) * NT);  // NT > 64: the cross-wave exchange area
+  double* red = fit_wk;
   if (WIDE) {
-    for (uint32_t i = lane; i < n_pad; i += WAVE) lds[i] = 1.0f;
+    for (uint32_t i = lane; i < n_pad; i += NT) lds[i] = 1.0f;
     // rows max_n .. n_pad - 1 are never generated; the 4-row steps of the fit read them (with weight 0): keep them finite
-    for (uint32_t i = lane; i < (n_pad - max_n) * (uint32_t)P; i += WAVE) design[(size_t)(i / (n_pad - max_n)) * n_pad + max_n + i % (n_pad - max_n)] = 0.0f;
+    for (uint32_t i = lane; i < (n_pad - max_n) * (uint32_t)P; i += NT) design[(size_t)(i / (n_pad - max_n)) * n_pad + max_n + i % (n_pad - max_n)] = 0.0f;
   }
 
   // ---- generate the replicate into LDS: lane takes Philox blocks lane, lane + 64, ... ----
@@ -411,14 +458,14 @@ __global__ __launch_bounds__(WAVE, MCP_GLM_WAVES) void glm_sim_kernel(const SimP
   row_ctx_init<P, FACTORS>(prm, cx);
   ScenLane<P> sl;
   if (SCEN) scen_lane_load<P>(prm, lsim, sl);
-  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += WAVE) {
-    stage_group<P, WAVE, 1, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
+  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += NT) {
+    stage_group<P, NT, 1, SCEN>(prm, k0, k1, ctr, st, SCEN ? sl.meta : 0u);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const uint32_t rr = 4u * ctr + r;
       if (rr < max_n) {
         float x[P], y;
-        build_row<P, FACTORS, WAVE, 1, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, 0.0, &sl);
+        build_row<P, FACTORS, NT, 1, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, 0.0, &sl);
 #pragma unroll
         for (int c = 1; c < P; ++c) design[(size_t)(c - 1) * n_pad + rr] = x[c];
         design[(size_t)(P - 1) * n_pad + rr] = y;
@@ -431,18 +478,18 @@ __global__ __launch_bounds__(WAVE, MCP_GLM_WAVES) void glm_sim_kernel(const SimP
   for (uint32_t g = 0; g < prm.n_grid; ++g) {
     const uint32_t n = prm.ns[g];
     double sum_y = 0.0;
-    for (uint32_t i = lane; i < n; i += WAVE) sum_y += (double)design[(size_t)(P - 1) * n_pad + i];
-    sum_y = wave_allreduce_sum(sum_y);
+    for (uint32_t i = lane; i < n; i += NT) sum_y += (double)design[(size_t)(P - 1) * n_pad + i];
+    sum_y = block_allreduce_sum<NT>(sum_y, red, lane);
     const double nd = (double)n;
     const double pbar = sum_y / nd;
     double dev_null = (pbar > 0.0 && pbar < 1.0) ? -2.0 * (sum_y * log(pbar) + (nd - sum_y) * log(1.0 - pbar)) : 0.0;
     if (!LOGIT && prm.glm_family == 2u) {  // Poisson: the intercept-only fit has mu = mean(y)
       double dn = 0.0;
-      for (uint32_t i = lane; i < n; i += WAVE) {
+      for (uint32_t i = lane; i < n; i += NT) {
         const double yi = (double)design[(size_t)(P - 1) * n_pad + i];
         dn += 2.0 * (((yi > 0.0 && pbar > 0.0) ? yi * log(yi / pbar) : 0.0) - (yi - pbar));
       }
-      dev_null = wave_allreduce_sum(dn);
+      dev_null = block_allreduce_sum<NT>(dn, red, lane);
     }
 
     constexpr int MT = P > MAX_P_WAVE ? MAX_T : MAX_T_WAVE;  // tests per fit: <= P - 1 marginal targets
@@ -508,7 +555,7 @@ __global__ __launch_bounds__(WAVE, MCP_GLM_WAVES) void glm_sim_kernel(const SimP
       if (P > MAX_P_WAVE)
         irls_fit_wide<P, false, LOGIT, MT>(prm, design, fit_wk, fit_am, n_pad, n, lane, keep, prm.glm_family, nt, beta, tsq, dev, conv);
       else
-        irls_fit<P, false, LOGIT, MT>(prm, design, n_pad, n, lane, keep, prm.glm_family, nt, beta, tsq, dev, conv);
+        irls_fit<P, false, LOGIT, MT, NT>(prm, design, n_pad, n, lane, keep, prm.glm_family, nt, beta, tsq, dev, conv, red);
     }
 
     // ---- decisions on the Wald z^2 the converged pass left in tsq (NaN otherwise), LRT overall ----

@@ -109,25 +109,50 @@ hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t cop
   return hipGetLastError();
 }
 
-size_t glm_lds_bytes(int P, uint32_t max_n) {  // staging sized for the general path's scratch column too
+// nt: threads sharing one replicate (64; 256 / 512 on the several-waves-per-replicate variants)
+size_t glm_lds_bytes_nt(int P, uint32_t max_n, int nt) {  // staging sized for the general path's scratch column too
   const size_t n_pad = (max_n + 3u) & ~3u;
-  // P > 8 (glm_wide_kernels.hip): + the column of ones and the row weights w | w z of irls_fit_wide (2 n_pad doubles)
-  return ((size_t)P * n_pad + (size_t)4 * (P + 1) * WAVE) * sizeof(float) +
-         (P > MAX_P_WAVE ? n_pad * sizeof(float) + (size_t)2 * n_pad * sizeof(double) : 0);
+  // P > 8 (glm_wide_kernels.hip): + the column of ones and the row weights w | w z of irls_fit_wide (2 n_pad doubles);
+  // nt > 64: + the cross-wave exchange of the P(P+1)/2 + P + 1 sums of a pass
+  return ((size_t)P * n_pad + (size_t)4 * (P + 1) * nt) * sizeof(float) +
+         (P > MAX_P_WAVE ? n_pad * sizeof(float) + (size_t)2 * n_pad * sizeof(double) : 0) +
+         (nt > WAVE ? (size_t)(nt / WAVE + 1) * (P * (P + 1) / 2 + P + 1) * sizeof(double) : 0);
+}
+size_t glm_lds_bytes(int P, uint32_t max_n) { return glm_lds_bytes_nt(P, max_n, WAVE); }
+
+// threads per replicate of a plain logit fit: 64 while a CU still holds two single-wave blocks per SIMD (8 blocks,
+// 20 KB each); beyond that the widest block that still fits, so that the CU is not left with one or two waves
+int glm_threads_per_replicate(int P, uint32_t max_n) {
+  if (const char* f = std::getenv("MCP_DEBUG_GLM_THREADS")) {  // tests: force a block width on a small design
+    const int nt = std::atoi(f);
+    if ((nt == 256 || nt == 512) && glm_lds_bytes_nt(P, max_n, nt) <= 150u * 1024u) return nt;
+    if (nt == WAVE) return WAVE;
+  }
+  const size_t cu = 160u * 1024u;
+  if (cu / glm_lds_bytes_nt(P, max_n, WAVE) >= 8u) return WAVE;
+  int best = WAVE;
+  size_t best_waves = cu / glm_lds_bytes_nt(P, max_n, WAVE);
+  for (int nt : {256, 512}) {
+    const size_t b = glm_lds_bytes_nt(P, max_n, nt);
+    if (b > 150u * 1024u) continue;
+    const size_t waves = (cu / b) * (size_t)(nt / WAVE);
+    if (waves > best_waves) { best = nt; best_waves = waves; }
+  }
+  return best;
 }
 
-template <bool FACTORS, bool RED, bool SCEN, bool LOGIT>
+template <bool FACTORS, bool RED, bool SCEN, bool LOGIT, int NT = WAVE>
 static hipError_t launch_glm_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, hipStream_t st) {
-  const size_t lds = glm_lds_bytes(P, max_n);
-  const dim3 block(WAVE), grid(n_sims);
+  const size_t lds = glm_lds_bytes_nt(P, max_n, NT);
+  const dim3 block(NT), grid(n_sims);
 #define LG(PP)                                                                                                        \
   case PP: {                                                                                                          \
     if (lds > 48 * 1024) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS, RED, SCEN, LOGIT>,                               \
+      hipError_t e = hipFuncSetAttribute((const void*)glm_sim_kernel<PP, FACTORS, RED, SCEN, LOGIT, NT>,              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
       if (e != hipSuccess) return e;                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS, RED, SCEN, LOGIT>), grid, block, lds, st, d_prm);                 \
+    hipLaunchKernelGGL((glm_sim_kernel<PP, FACTORS, RED, SCEN, LOGIT, NT>), grid, block, lds, st, d_prm);             \
   } break;
   switch (P) {
     LG(2) LG(3) LG(4) LG(5) LG(6) LG(7) LG(8)
@@ -149,8 +174,12 @@ hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32
   }
   if (scen) return launch_glm_f<true, true, true, true>(P, d_prm, n_sims, max_n, st);
   if (reduced) return launch_glm_f<true, true, false, true>(P, d_prm, n_sims, max_n, st);
-  return factors ? launch_glm_f<true, false, false, true>(P, d_prm, n_sims, max_n, st)
-                 : launch_glm_f<false, false, false, true>(P, d_prm, n_sims, max_n, st);
+  const int nt = glm_threads_per_replicate(P, max_n);  // large designs: several waves share one replicate
+  if (factors) return nt > WAVE ? launch_glm_f<true, false, false, true, 256>(P, d_prm, n_sims, max_n, st)
+                                : launch_glm_f<true, false, false, true>(P, d_prm, n_sims, max_n, st);
+  if (nt == 512) return launch_glm_f<false, false, false, true, 512>(P, d_prm, n_sims, max_n, st);
+  if (nt == 256) return launch_glm_f<false, false, false, true, 256>(P, d_prm, n_sims, max_n, st);
+  return launch_glm_f<false, false, false, true>(P, d_prm, n_sims, max_n, st);
 }
 
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {

@@ -119,3 +119,34 @@ def test_wide_designs_with_a_sparse_factor_take_the_reduced_fit(family, k, engin
     for f in ("uncorrected", "corrected", "converged", "overall"):
         assert np.array_equal(getattr(g, f), getattr(o, f)), f
     assert np.array_equal(g.counters, o.counters)
+
+
+# ---------------------------------------------------------------------------------------------
+# large-n logit designs: several waves share one replicate (glm_kernels.hip: glm_threads_per_replicate)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n,factor", [(3, 5000, False), (3, 1800, False), (7, 2600, False), (2, 3000, True), (5, 1200, True)])
+def test_large_n_logit_on_several_waves_per_replicate_matches_oracle(k, n, factor, engine, oracle):
+    """n x p f32 beyond 20 KB of LDS: 256 or 512 threads per replicate, sums crossing the waves through LDS; a grid whose
+    smaller sizes leave most lanes without rows, and the factor walk on the wide block."""
+    from mcpower_amd import spec as S
+    spec = workloads._glm_spec(k, 0.3)
+    spec.effect_sizes[1] = 0.09
+    if k > 1:
+        spec.effect_sizes[2] = -0.07
+    spec.target_indices = list(range(1, k + 1))
+    spec.report_overall = True
+    spec.correction_method = S.CorrectionMethod.BenjaminiHochberg
+    if factor:
+        spec.n_factor_dummies, spec.factor_n_levels, spec.factor_proportions, spec.factor_sampled = 2, [3], [0.5, 0.3, 0.2], [None]
+        spec.effect_sizes = list(spec.effect_sizes) + [0.2, -0.1]
+        spec.target_indices = list(range(1, k + 3))
+    grid = [90, n // 3, n]
+    g = engine.run_batch(spec, grid, 256, workloads.BASE_SEED, stat_capture=True)
+    o = oracle.run_batch(spec, grid, 256, workloads.BASE_SEED, stat_capture=True, n_threads=16)
+    a, b = g.stat_capture, o.stat_capture
+    m = ~np.isnan(a)
+    assert np.array_equal(m, ~np.isnan(b)) and np.all(np.abs(a[m] - b[m]) <= 1e-8 * np.abs(b[m]) + 1e-10)
+    for f in ("uncorrected", "corrected", "converged", "overall"):
+        assert np.array_equal(getattr(g, f), getattr(o, f)), f
+    assert np.array_equal(g.counters, o.counters) and g.converged[:, 2].all()
