@@ -358,7 +358,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   const bool glm_reduced = (prm.red_active || prm.scen_active || (!mle && prm.glm_family != 0u)) && glm && !prm.glmm_active;
   if (reduced && (flags & MCP_PIPELINE_STAGED))
     return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: the staged pipeline with sparse-factor exclusion / test_formula / post-hoc rounds or more than 8 design columns / tests");
-  const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm;
+  const bool staged = (flags & MCP_PIPELINE_STAGED) && !glm && low.P <= (uint32_t)mcp::MAX_P_WAVE;  // the tile kernels exist for P <= 8
   const uint32_t npc = prm.n_posthoc;
   const uint64_t sim_offset = opts ? opts->sim_offset : 0;
   const uint32_t nt = low.n_tests, P = low.P;

@@ -745,7 +745,11 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   }
   // designs beyond the hot kernels' register budget (more than 8 columns or 8 tests) run on the reduced-design
   // kernel too: its solve and decisions are sized at run time
-  const bool wide = P > (uint32_t)MAX_P_WAVE || nt > (uint32_t)MAX_T_WAVE;
+  // (the fused OLS kernel is instantiated up to MAX_P_FUSED = 12 columns / 12 tests; the wave-per-replicate estimators
+  // keep the 8 / 8 of their own kernels)
+  // (general data path: 9 columns -- the scenario variant of the fused kernel spills from P = 10)
+  const uint32_t hot_limit = spec->estimator == MCP_EST_OLS ? (general ? 9u : (uint32_t)MAX_P_FUSED) : (uint32_t)MAX_P_WAVE;
+  const bool wide = P > hot_limit || nt > (spec->estimator == MCP_EST_OLS ? (uint32_t)MAX_P_FUSED : (uint32_t)MAX_T_WAVE);
   // clustered data fitted by OLS ignoring the clustering (orchestrator tests/clustered_ols_smoke.rs): the random
   // intercept of a row's cluster is re-drawn per row on the reduced-design kernel
   const bool ols_cluster = spec->cluster.present && spec->estimator == MCP_EST_OLS;

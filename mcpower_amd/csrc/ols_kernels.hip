@@ -36,6 +36,11 @@ template <int P>
 __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& s, uint32_t g, uint32_t n,
                                            bool active, uint32_t out_row) {
   // ---- X'X (lower) and X'y ----
+  // P <= 8: the factor gets its own registers; P = 9..12 (MAX_P_FUSED): it overwrites X'X entry by entry -- an entry of
+  // X'X is read for the last time when the factor's entry at the same place is formed -- so the live set stays one
+  // triangle (78 doubles at P = 12) and the kernel keeps two waves per SIMD
+  constexpr bool INPLACE = P > MAX_P_WAVE;
+  constexpr int MT = P > MAX_P_WAVE ? MAX_P_FUSED : MAX_T_WAVE;  // tests per fit
   double A[P][P];
   double rhs[P];
   A[0][0] = (double)n;
@@ -51,7 +56,8 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
     }
   }
   // ---- Cholesky, converged = min|L_ii| / max|L_ii| >= EPS_RANK (batch.rs:40-41) ----
-  double Lm[P][P];
+  double Lsep[INPLACE ? 1 : P][INPLACE ? 1 : P];
+#define Lm(i, j) (*(INPLACE ? &A[i][j] : &Lsep[INPLACE ? 0 : (i)][INPLACE ? 0 : (j)]))
   double invd[P];
   bool ok = true;
   double dmin = __builtin_inf(), dmax = 0.0;
@@ -59,10 +65,10 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   for (int j = 0; j < P; ++j) {
     double d = A[j][j];
 #pragma unroll
-    for (int t = 0; t < j; ++t) d = __builtin_fma(-Lm[j][t], Lm[j][t], d);
+    for (int t = 0; t < j; ++t) d = __builtin_fma(-Lm(j, t), Lm(j, t), d);
     ok = ok && (d > 0.0) && (d < __builtin_inf());
     const double ljj = __builtin_sqrt(d);
-    Lm[j][j] = ljj;
+    Lm(j, j) = ljj;
     invd[j] = 1.0 / ljj;
     dmin = ljj < dmin ? ljj : dmin;
     dmax = ljj > dmax ? ljj : dmax;
@@ -70,8 +76,8 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
     for (int i = j + 1; i < P; ++i) {
       double v = A[i][j];
 #pragma unroll
-      for (int t = 0; t < j; ++t) v = __builtin_fma(-Lm[i][t], Lm[j][t], v);
-      Lm[i][j] = v * invd[j];
+      for (int t = 0; t < j; ++t) v = __builtin_fma(-Lm(i, t), Lm(j, t), v);
+      Lm(i, j) = v * invd[j];
     }
   }
   const bool conv = ok && (dmin / dmax >= EPS_RANK);
@@ -81,14 +87,14 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   for (int i = 0; i < P; ++i) {
     double v = rhs[i];
 #pragma unroll
-    for (int t = 0; t < i; ++t) v = __builtin_fma(-Lm[i][t], zf[t], v);
+    for (int t = 0; t < i; ++t) v = __builtin_fma(-Lm(i, t), zf[t], v);
     zf[i] = v * invd[i];
   }
 #pragma unroll
   for (int i = P - 1; i >= 0; --i) {
     double v = zf[i];
 #pragma unroll
-    for (int t = i + 1; t < P; ++t) v = __builtin_fma(-Lm[t][i], beta[t], v);
+    for (int t = i + 1; t < P; ++t) v = __builtin_fma(-Lm(t, i), beta[t], v);
     beta[i] = v * invd[i];
   }
   double bxty = 0.0;
@@ -103,9 +109,9 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   // ---- squared statistic per test: (c'beta)^2 / (sigma^2 ||L^-1 c||^2)  (posthoc.rs:86-99) ----
   const double* crow = prm.crit + (size_t)g * prm.crit_stride;
   const uint32_t nt = prm.n_tests;
-  double tsq[MAX_T_WAVE];
+  double tsq[MT];
 #pragma unroll
-  for (int t = 0; t < MAX_T_WAVE; ++t) {
+  for (int t = 0; t < MT; ++t) {
     tsq[t] = __builtin_nan("");
     if ((uint32_t)t < nt) {
       const double* c = prm.contrast + t * MAX_P;
@@ -116,7 +122,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
         est = __builtin_fma(c[i], beta[i], est);
         double acc = c[i];
 #pragma unroll
-        for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lm[i][q], u[q], acc);
+        for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lm(i, q), u[q], acc);
         u[i] = acc * invd[i];
         nq = __builtin_fma(u[i], u[i], nq);
       }
@@ -147,7 +153,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
     const size_t cell = (size_t)out_row * prm.n_grid + g;
     if (prm.unc) {
 #pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t)
+      for (int t = 0; t < MT; ++t)
         if ((uint32_t)t < nt) {
           prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
           prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
@@ -157,7 +163,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
     if (prm.overall) prm.overall[cell] = ov ? 1 : 0;
     if (prm.stat && g == 0) {
 #pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t)
+      for (int t = 0; t < MT; ++t)
         if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
     }
   }
@@ -169,7 +175,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   const bool lane0 = (threadIdx.x & 63u) == 0u;
   const uint32_t ub = active ? unc_bits : 0u, cb = active ? cor_bits : 0u;
 #pragma unroll
-  for (int t = 0; t < MAX_T_WAVE; ++t) {
+  for (int t = 0; t < MT; ++t) {
     if ((uint32_t)t < nt) {
       const unsigned long long mu = __ballot((ub >> t) & 1u);
       const unsigned long long mc = __ballot((cb >> t) & 1u);
@@ -181,7 +187,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
   }
   const uint32_t ku = __popc(ub), kc = __popc(cb);
 #pragma unroll
-  for (int k = 0; k <= MAX_T_WAVE; ++k) {
+  for (int k = 0; k <= MT; ++k) {
     if ((uint32_t)k <= nt) {
       const unsigned long long hu = __ballot(active && ku == (uint32_t)k);
       const unsigned long long hc = __ballot(active && kc == (uint32_t)k);
@@ -201,6 +207,7 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
       if (mac) atomicAdd(ctr + prm.ctr_n_sims, (unsigned long long)__popcll(mac));
     }
   }
+#undef Lm
 }
 
 // tile layout of the staged pipeline: [block of 256 replicates][column: x1..x_{P-1}, y][row quad][256 lanes][4 rows]
@@ -430,6 +437,27 @@ __global__ void icdf_probe_kernel(uint32_t first_word, uint32_t stride, uint32_t
 // ---- launchers (C++ linkage, called from host_api.hip) ----
 namespace mcp {
 
+// fused kernel, P = 9..12 (MAX_P_FUSED): the staging area passes 48 KB at P = 12
+template <bool GRID1, int FLAVOR>
+static hipError_t launch_fused_wide(int P, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st) {
+  const dim3 block(BLOCK), grid((n_sims + BLOCK - 1u) / BLOCK);
+#define LFW(PP)                                                                                                         \
+  case PP: {                                                                                                            \
+    if (lds > 48 * 1024) {                                                                                              \
+      hipError_t e = hipFuncSetAttribute((const void*)ols_sim_kernel<PP, MODE_FUSED, GRID1, FLAVOR>,                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      if (e != hipSuccess) return e;                                                                                    \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((ols_sim_kernel<PP, MODE_FUSED, GRID1, FLAVOR>), grid, block, lds, st, d_prm);                   \
+  } break;
+  switch (P) {
+    LFW(9) LFW(10) LFW(11) LFW(12)
+    default: return hipErrorInvalidValue;
+  }
+#undef LFW
+  return hipGetLastError();
+}
+
 template <int MODE, bool GRID1, int FLAVOR>
 static hipError_t launch_sim_pgf(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
   const dim3 block(BLOCK), grid((n_sims + BLOCK - 1u) / BLOCK);
@@ -445,7 +473,9 @@ static hipError_t launch_sim_pgf(int P, const SimParams* d_prm, uint32_t n_sims,
     case 6: hipLaunchKernelGGL((ols_sim_kernel<6, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
     case 7: hipLaunchKernelGGL((ols_sim_kernel<7, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
     case 8: hipLaunchKernelGGL((ols_sim_kernel<8, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
-    default: return hipErrorInvalidValue;
+    default:
+      if (MODE == MODE_FUSED) return launch_fused_wide<GRID1, FLAVOR>(P, d_prm, n_sims, lds, st);
+      return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }

@@ -150,3 +150,34 @@ def test_large_n_logit_on_several_waves_per_replicate_matches_oracle(k, n, facto
     for f in ("uncorrected", "corrected", "converged", "overall"):
         assert np.array_equal(getattr(g, f), getattr(o, f)), f
     assert np.array_equal(g.counters, o.counters) and g.converged[:, 2].all()
+
+
+# ---------------------------------------------------------------------------------------------
+# OLS designs of 9..12 columns run on the fused lane-per-replicate kernel (in-place Cholesky, <= 12 tests)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", [9, 10, 11, 12])
+@pytest.mark.parametrize("factor", [False, True])
+def test_fused_ols_up_to_twelve_columns_matches_oracle(p, factor, engine, oracle):
+    from mcpower_amd import spec as S
+    k = p - 1 - (2 if factor else 0)
+    spec = workloads.base_spec(k)
+    spec.effect_sizes = [0.0] + [0.2, -0.15, 0.1][:k] + [0.0] * max(0, k - 3)
+    if factor:
+        spec.n_factor_dummies, spec.factor_n_levels, spec.factor_proportions, spec.factor_sampled = 2, [3], [0.5, 0.3, 0.2], [None]
+        spec.effect_sizes = list(spec.effect_sizes) + [0.3, -0.2]
+    spec.target_indices = list(range(1, p))
+    spec.contrast_pairs = [(1, 2)]
+    spec.report_overall = True
+    spec.correction_method = S.CorrectionMethod.Holm
+    for grid in ([120], [40, 90, 200]):
+        g = engine.run_batch(spec, grid, 1024, workloads.BASE_SEED, stat_capture=True)
+        o = oracle.run_batch(spec, grid, 1024, workloads.BASE_SEED, stat_capture=True, n_threads=16)
+        a, b = g.stat_capture, o.stat_capture
+        m = ~np.isnan(a)
+        assert np.array_equal(m, ~np.isnan(b)) and np.all(np.abs(a[m] - b[m]) <= 1e-10 * np.abs(b[m]) + 1e-12)
+        for f in ("uncorrected", "corrected", "converged", "overall"):
+            assert np.array_equal(getattr(g, f), getattr(o, f)), (f, grid)
+        assert np.array_equal(g.counters, o.counters)
+        red = engine.run_batch(spec, grid, 1024, workloads.BASE_SEED, per_sim=False)
+        assert np.array_equal(red.counters, g.counters)
