@@ -424,10 +424,10 @@ __device__ __forceinline__ void irls_fit_wide(const SimParams& prm, const float*
 // per-study effects (data_gen.rs:709-751, 990-1093); the fit still starts from the spec's effects.
 // NT: threads sharing one replicate (64, or 256 / 512 for designs whose LDS footprint leaves a CU with fewer than two
 // single-wave blocks per SIMD: the reference bench's glm_large_n, n = 5 000, is 80 KB -- ONE wave per CU at NT = 64);
-// rows spread over all NT lanes, sums cross the waves through LDS.  The reduced-fit and wide variants stay at 64.
+// rows spread over all NT lanes, sums cross the waves through LDS.  The scenario and wide variants stay at 64.
 template <int P, bool FACTORS, bool RED, bool SCEN, bool LOGIT, int NT = WAVE>
 __global__ __launch_bounds__(NT, MCP_GLM_WAVES) void glm_sim_kernel(const SimParams* __restrict__ pp) {
-  static_assert(NT == WAVE || (!RED && !SCEN && P <= MAX_P_WAVE), "several waves per replicate: plain narrow fits only");
+  static_assert(NT == WAVE || (!SCEN && P <= MAX_P_WAVE), "several waves per replicate: narrow fits on the plain data path only");
   extern __shared__ float lds[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
@@ -507,15 +507,19 @@ __global__ __launch_bounds__(NT, MCP_GLM_WAVES) void glm_sim_kernel(const SimPar
             uint32_t mn = 0xffffffffu;
             for (uint32_t l = 0; l < prm.f_levels[f]; ++l) {
               uint32_t cnt = 0;
-              for (uint32_t i = lane; i < n; i += WAVE) {
+              for (uint32_t i = lane; i < n; i += NT) {
                 uint32_t lv = 0;
 #pragma unroll
                 for (int c = 1; c < P; ++c)
                   if (prm.col_factor[c] == (uint32_t)f && design[(size_t)(c - 1) * n_pad + i] == 1.0f) lv = prm.col_level[c];
                 cnt += lv == l ? 1u : 0u;
               }
+              if (NT > WAVE) {
+                cnt = (uint32_t)block_allreduce_sum<NT>((double)cnt, red, lane);  // per-lane counts -> block total (exact in f64)
+              } else {
 #pragma unroll
-              for (int m = 1; m < WAVE; m <<= 1) cnt += __shfl_xor(cnt, m, WAVE);
+                for (int m = 1; m < WAVE; m <<= 1) cnt += __shfl_xor(cnt, m, WAVE);
+              }
               mn = cnt < mn ? cnt : mn;
             }
             fmin[f] = mn;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(NT, MCP_GLM_WAVES) void glm_sim_kernel(const SimPar
         if (P > MAX_P_WAVE)
           irls_fit_wide<P, true, LOGIT, MT>(prm, design, fit_wk, fit_am, n_pad, n, lane, keep, prm.glm_family, nt, beta, tsq, dev, conv);
         else
-          irls_fit<P, true, LOGIT, MT>(prm, design, n_pad, n, lane, keep, prm.glm_family, nt, beta, tsq, dev, conv);
+          irls_fit<P, true, LOGIT, MT, NT>(prm, design, n_pad, n, lane, keep, prm.glm_family, nt, beta, tsq, dev, conv, red);
         if (conv || attempt == 1 || prm.min_level_count == 0u) break;
         int drop = -1;  // included_factor_with_smallest_min_count (batch.rs:2573-2600)
         uint32_t best = 0;

@@ -168,13 +168,15 @@ hipError_t launch_glm_wide(int P, const SimParams* d_prm, uint32_t n_sims, uint3
 hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t max_n, bool factors, bool reduced,
                           bool scen, bool logit, hipStream_t st) {
   if (P > MAX_P_WAVE) return scen ? hipErrorInvalidValue : launch_glm_wide(P, d_prm, n_sims, max_n, factors, reduced, logit, st);
+  const int nt = scen ? WAVE : glm_threads_per_replicate(P, max_n);  // large designs: several waves share one replicate
   if (!logit) {  // probit / Poisson: one run-time-family variant (the superset kernel)
-    return scen ? launch_glm_f<true, true, true, false>(P, d_prm, n_sims, max_n, st)
-                : launch_glm_f<true, true, false, false>(P, d_prm, n_sims, max_n, st);
+    if (scen) return launch_glm_f<true, true, true, false>(P, d_prm, n_sims, max_n, st);
+    return nt > WAVE ? launch_glm_f<true, true, false, false, 256>(P, d_prm, n_sims, max_n, st)
+                     : launch_glm_f<true, true, false, false>(P, d_prm, n_sims, max_n, st);
   }
   if (scen) return launch_glm_f<true, true, true, true>(P, d_prm, n_sims, max_n, st);
-  if (reduced) return launch_glm_f<true, true, false, true>(P, d_prm, n_sims, max_n, st);
-  const int nt = glm_threads_per_replicate(P, max_n);  // large designs: several waves share one replicate
+  if (reduced) return nt > WAVE ? launch_glm_f<true, true, false, true, 256>(P, d_prm, n_sims, max_n, st)
+                                : launch_glm_f<true, true, false, true>(P, d_prm, n_sims, max_n, st);
   if (factors) return nt > WAVE ? launch_glm_f<true, false, false, true, 256>(P, d_prm, n_sims, max_n, st)
                                 : launch_glm_f<true, false, false, true>(P, d_prm, n_sims, max_n, st);
   if (nt == 512) return launch_glm_f<false, false, false, true, 512>(P, d_prm, n_sims, max_n, st);

@@ -181,3 +181,30 @@ def test_fused_ols_up_to_twelve_columns_matches_oracle(p, factor, engine, oracle
         assert np.array_equal(g.counters, o.counters)
         red = engine.run_batch(spec, grid, 1024, workloads.BASE_SEED, per_sim=False)
         assert np.array_equal(red.counters, g.counters)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family", ["probit", "poisson", "logit_exclusion"])
+def test_large_n_reduced_fit_variants_on_several_waves_match_oracle(family, engine, oracle):
+    """The superset kernel (run-time family, sparse-factor exclusion with its level counts, the separation fallback) on
+    256 threads per replicate: counts and sums cross the waves through LDS."""
+    from mcpower_amd import spec as S
+    spec = workloads._glm_spec(3, 0.3)
+    spec.effect_sizes[1], spec.effect_sizes[2] = 0.08, -0.06
+    spec.n_factor_dummies, spec.factor_n_levels, spec.factor_proportions, spec.factor_sampled = 2, [3], [0.55, 0.43, 0.02], [None]
+    spec.effect_sizes = list(spec.effect_sizes) + [0.15, 0.1]
+    spec.target_indices = [1, 2, 3, 4, 5]
+    spec.report_overall = True
+    if family == "probit":
+        spec.link = S.LinkKind.Probit
+    elif family == "poisson":
+        spec.outcome_kind = S.OutcomeKind.Count
+        spec.intercept = spec.effect_sizes[0] = 0.5
+    spec.factor_min_level_count = 12      # the 2 % level: ~6 rows at n = 300 (excluded), ~60 at n = 3000 (kept)
+    grid = [300, 3000]
+    g = engine.run_batch(spec, grid, 192, workloads.BASE_SEED, stat_capture=True)
+    o = oracle.run_batch(spec, grid, 192, workloads.BASE_SEED, stat_capture=True, n_threads=16)
+    assert np.array_equal(g.factor_excluded, o.factor_excluded) and g.factor_excluded[:, 0, 0].mean() > 0.8 and not g.factor_excluded[:, 1, 0].any()
+    for f in ("uncorrected", "corrected", "converged", "overall"):
+        assert np.array_equal(getattr(g, f), getattr(o, f)), f
+    assert np.array_equal(g.counters, o.counters)
