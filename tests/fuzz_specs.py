@@ -79,6 +79,9 @@ def random_spec(seed: int, family: str):
         s.intercept = s.effect_sizes[0] = round(base, 3)
     sizes = sorted({int(v) for v in rng.integers(40, 400, size=int(rng.integers(1, 4)))})
     n_sims = 384
+    if family in ("logit", "probit", "poisson") and rng.integers(0, 5) == 0:
+        sizes = sorted({int(v) for v in rng.integers(900, 4000, size=int(rng.integers(1, 3)))} | {int(rng.integers(40, 200))})
+        n_sims = 96                        # large designs: the several-waves-per-replicate GLM kernels
     if clustered:
         s.estimator = S.EstimatorSpec.Glm if family == "glmm" else S.EstimatorSpec.Mle
         n_cl = int(rng.integers(6, 21))
