@@ -589,24 +589,29 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
   const uint32_t W = prm.lmg_W, R = prm.lmg_R, L0 = prm.lmg_levels[0], d = prm.lmg_n_theta, nterms = prm.lmg_n_terms;
   LmgLds m;
   {
+    // persistent: the sufficient statistics, the sparse-row scratch of their accumulation, the theta carry, the design
     ldd* q = (ldd*)lds_d;
     m.gzz = q; q += (size_t)L0 * Q0 * Q0;
     m.gzw = q; q += (size_t)L0 * Q0 * W;
     m.gww = q; q += lmg_tri(W, 0u);  // lower triangles, packed by rows
-    m.S = q; q += lmg_tri(W, 0u);
-    m.B = q; q += (size_t)L0 * Q0 * W;
-    m.ld = q; q += L0;
-    m.simplex = q; q += (size_t)(d + 4u) * LMG_MAX_THETA;
-    m.fv = q; q += d + 1u;
-    m.tm = q; q += 27;
-    m.misc = q; q += 8;
-    m.tail = q; q += 8 + 64 + 64 + 64 + 8 + 8;  // beta | L | U | Lc | cj | tsq
     m.rval = q; q += LMG_MAX_NZ;
     m.carry = q; q += LMG_MAX_THETA;
     ldu* u = (ldu*)q;
-    m.ridx = u; u += LMG_MAX_NZ;
+    m.ridx = u; u += (LMG_MAX_NZ + 1) & ~1;
     ldf* f = (ldf*)u;
     m.design = f; f += (size_t)P * n_pad;
+    // one region, two lives: the generator's random effects and staging area die when the last row exists; the
+    // evaluation's matrices and simplex are first written by the first evaluation (the LDS footprint bounds the
+    // occupancy of this latency-bound kernel: 24 -> 18 KB on the lmm_slope shape)
+    ldd* e = (ldd*)f;
+    m.S = e; e += lmg_tri(W, 0u);
+    m.B = e; e += (size_t)L0 * Q0 * W;
+    m.ld = e; e += L0;
+    m.simplex = e; e += (size_t)(d + 4u) * LMG_MAX_THETA;
+    m.fv = e; e += d + 1u;
+    m.tm = e; e += 27;
+    m.misc = e; e += 8;
+    m.tail = e; e += 8 + 64 + 64 + 64 + 8 + 8;  // beta | L | U | Lc | cj | tsq
     m.u0 = f; f += L0;
     m.us = f; f += (size_t)L0 * LMG_MAX_SLOPES;
     m.ux = f;

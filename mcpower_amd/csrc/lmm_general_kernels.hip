@@ -9,14 +9,17 @@ namespace mcp {
 // LDS bytes of one replicate
 size_t lmg_lds_bytes(const SimParams& prm) {
   const size_t W = prm.lmg_W, L0 = prm.lmg_levels[0], q0 = prm.lmg_q[0], d = prm.lmg_n_theta;
-  size_t dbl = L0 * q0 * q0 + 2 * L0 * q0 * W + L0 + W * (W + 1) + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8) +
-               LMG_MAX_NZ + LMG_MAX_THETA;
-  size_t u32 = LMG_MAX_NZ;
+  const size_t tri = W * (W + 1) / 2;
+  // persistent: gzz | gzw | gww | rval | carry (doubles), ridx (u32, even count), the design (f32)
   const size_t n_pad = ((size_t)prm.max_n + 3u) & ~(size_t)3u;
+  const size_t persistent = (L0 * q0 * q0 + L0 * q0 * W + tri + LMG_MAX_NZ + LMG_MAX_THETA) * 8 + (((size_t)LMG_MAX_NZ + 1) & ~(size_t)1) * 4 +
+                            (size_t)prm.P * n_pad * 4;
+  // the shared region: the evaluation's S | B | ld | simplex | fv | tm | misc | tail over the generator's u0 | us | ux | staging
+  const size_t eval_bytes = (tri + L0 * q0 * W + L0 + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8)) * 8;
   size_t nlev = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) nlev += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
-  size_t flt = (size_t)prm.P * n_pad + L0 + L0 * LMG_MAX_SLOPES + nlev + 4 * (prm.P + 1) * GW;
-  return dbl * 8 + ((u32 + 1) & ~(size_t)1) * 4 + flt * 4 + 64;
+  const size_t gen_bytes = (L0 + L0 * LMG_MAX_SLOPES + nlev + (size_t)4 * (prm.P + 1) * GW) * 4;
+  return persistent + (eval_bytes > gen_bytes ? eval_bytes : gen_bytes) + 64;
 }
 
 
