@@ -552,7 +552,12 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
         m.ao[t] = na;
         if (t < nterms) na += prm.lmg_q[t];
       }
-      m.av = q; q += (size_t)na * n_pad;
+      // the per-evaluation cache of the transformed random-effect rows shares its LDS with the generator's random
+      // effect draws and staging area, which die when the last row exists (the footprint bounds the occupancy of this
+      // latency-bound kernel: 33 -> 30 KB on the glmm_crossed shape, 4 -> 5 workgroups per CU)
+      m.av = q;
+      const size_t av_d = (size_t)na * n_pad, gen_d = ((size_t)((nd + 1u) & ~1u) + (size_t)4 * (P + 1) * QW + 1u) / 2u;
+      q += av_d > gen_d ? av_d : gen_d;
     }
     m.simplex = q; q += (size_t)(dmax + 4u) * GLMM_ROW;
     m.fv = q; q += (dmax + 2u) & ~1u;
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     m.lx = q; q += 36;  // P x P factor of the Wald precision (P <= 6)
     gdf* f = (gdf*)q;
     m.design = f; f += (size_t)P * n_pad;
-    m.draws = f; f += (nd + 1u) & ~1u;
+    m.draws = (gdf*)m.av;
     m.lvl = (gdu*)f; f += (size_t)(nterms - 1u) * n_pad / 2u + 2u;
     m.rows = (gdu*)f; f += (size_t)(nterms - 1u) * n_pad / 2u + 2u;
     m.lstart = (gdu*)f;
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
       }
       f += (so + 3u) / 2u + 1u;
     }
-    m.st = (float*)f + lane;
+    m.st = (float*)(m.draws + ((nd + 1u) & ~1u)) + lane;
   }
   // ---- 1. random effects on the sequential stream (data_gen.rs:146-284): per grouping its intercepts, then its
   //         correlated slopes through chol(diag(tau) R diag(tau)); draw order: primary intercepts, primary slopes, every
@@ -1434,11 +1439,13 @@ size_t glmm_general_lds_bytes(const SimParams& prm) {
   for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) nd += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
   size_t na = 0;
   for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) na += prm.lmg_q[t];
-  const size_t dbl = (3 + na) * n_pad + R * RS + 4 * R + R * P + 28 + (dmax + 4) * GLMM_ROW + ((dmax + 2) & ~(size_t)1) + 8 + 36;
+  // the av cache (na n_pad doubles) and the generator's draws + staging share one region
+  const size_t av_d = na * n_pad, gen_d = (((nd + 1) & ~(size_t)1) + (size_t)4 * (P + 1) * QW + 1) / 2;
+  const size_t dbl = 3 * n_pad + (av_d > gen_d ? av_d : gen_d) + R * RS + 4 * R + R * P + 28 + (dmax + 4) * GLMM_ROW +
+                     ((dmax + 2) & ~(size_t)1) + 8 + 36;
   size_t so = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) so += (size_t)prm.lmg_levels[t] + 2;
-  const size_t flt = P * n_pad + ((nd + 1) & ~(size_t)1) + 2 * ((prm.lmg_n_terms - 1) * n_pad / 2 + 2) + (so + 3) / 2 + 1 +
-                     (size_t)4 * (P + 1) * QW;
+  const size_t flt = P * n_pad + 2 * ((prm.lmg_n_terms - 1) * n_pad / 2 + 2) + (so + 3) / 2 + 1;
   return dbl * 8 + flt * 4 + 64;
 }
 
