@@ -288,7 +288,8 @@ typedef int (*mcp_progress_fn)(uint64_t current, uint64_t total, void* user);
 /* option bits */
 #define MCP_WANT_PER_SIM      0x1u   /* fill the sim-major u8 tensors (BatchResult parity) */
 #define MCP_WANT_STAT_CAPTURE 0x2u   /* run_batch_st_capture (batch.rs:180) */
-#define MCP_PIPELINE_STAGED   0x4u   /* generator -> HBM design -> fit kernels instead of the fused kernel */
+#define MCP_PIPELINE_STAGED   0x4u   /* generator -> HBM design -> fit kernels instead of the fused kernel (OLS, <= 8
+                                         design columns; wider designs and the other estimators ignore the flag) */
 #define MCP_ALLREDUCE_COUNTERS 0x8u  /* pool `counters` over the ranks of this process's communicator: one
                                         ncclAllReduce(sum, uint64) of the device-resident vector on the launch stream,
                                         before the call's single device-to-host copy (merge.rs:26-70).  Every rank of
