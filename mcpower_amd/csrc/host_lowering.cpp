@@ -436,6 +436,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     if (lmm_general) {
       const mcp_cluster& cl = spec->cluster;
       prm.lmg_active = 1;
+      prm.lmg_stream = (spec->estimator == MCP_EST_MLE && n_ns == 1 && prm.between_mask == 0u && spec->n_factors == 0 && max_n > 256u) ? 1u : 0u;
       prm.lmg_n_terms = 1 + cl.n_extra_groupings;
       uint32_t toff = 0, roff = 0, seq = 0;
       for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) {

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
     ldu* u = (ldu*)q;
     m.ridx = u; u += (LMG_MAX_NZ + 1) & ~1;
     ldf* f = (ldf*)u;
-    m.design = f; f += (size_t)P * n_pad;
+    m.design = f; f += (size_t)P * (prm.lmg_stream ? 256u : n_pad);
     // one region, two lives: the generator's random effects and staging area die when the last row exists; the
     // evaluation's matrices and simplex are first written by the first evaluation (the LDS footprint bounds the
     // occupancy of this latency-bound kernel: 24 -> 18 KB on the lmm_slope shape)
@@ -734,7 +734,12 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
     return u_re;
   };
   const uint32_t bmask = prm.between_mask;
-  for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += GW) {
+  // Streaming (prm.lmg_stream: one sample size, no cluster-level columns, no factors): the rows exist only to be folded
+  // into the sufficient statistics, in row order -- generate 256 of them (one Philox quad per lane), fold, reuse the
+  // window.  dstride / dbase: row stride of a design column in LDS and the first row the window holds.
+  const bool stream = prm.lmg_stream != 0u;
+  const uint32_t dstride = stream ? 256u : n_pad;
+  auto gen_quad = [&](uint32_t ctr, uint32_t dbase) {
     stage_group<P, GW, 0, SCEN>(prm, k0, k1, ctr, m.st, SCEN ? sl.meta : 0u);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -745,11 +750,13 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
         if (bmask == 0u) finish_row<P, 0, SCEN>(prm, cx, x, e, y, row_effect(rr, x), &sl);
         else y = e;  // the residual waits in the outcome slot until the cluster-level columns are broadcast
 #pragma unroll
-        for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * n_pad + rr] = x[c];
-        m.design[(size_t)(P - 1) * n_pad + rr] = y;
+        for (int c = 1; c < P; ++c) m.design[(size_t)(c - 1) * dstride + (rr - dbase)] = x[c];
+        m.design[(size_t)(P - 1) * dstride + (rr - dbase)] = y;
       }
     }
-  }
+  };
+  if (!stream)
+    for (uint32_t ctr = lane; 4u * ctr < max_n; ctr += GW) gen_quad(ctr, 0u);
   if (bmask != 0u) {
     // cluster-level predictors (data_gen.rs:606-636): every row takes the marked columns from its primary cluster's
     // representative row, then interactions, the random-effect contribution and the outcome follow from the
@@ -797,9 +804,10 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
   bool has_prev = false;
   uint32_t prev_n = 0;
   const uint32_t nt = prm.n_tests;
-  for (uint32_t g = 0; g < prm.n_grid; ++g) {
-    const uint32_t n = prm.ns[g];
-    for (uint32_t i = prev_n; i < n; ++i) {
+  // fold rows [lo, hi) into the statistics, in row order; the window holds them from row dbase on
+  auto fold_rows = [&](uint32_t lo, uint32_t hi, uint32_t dbase) {
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t di = i - dbase;
       if (lane < nz) {
         uint32_t idx;
         double val;
@@ -807,11 +815,11 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
           uint32_t t = 1, e = lane;
           while (e >= prm.lmg_q[t]) { e -= prm.lmg_q[t]; ++t; }
           idx = prm.lmg_roff[t] + lmg_level_of_row(prm, t, i) * prm.lmg_q[t] + e;
-          val = e == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[t][e - 1u] - 1u) * n_pad + i];
+          val = e == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[t][e - 1u] - 1u) * dstride + di];
         } else {
           const uint32_t a = lane - nzr;  // 0..P-1 design column, P = outcome
           idx = R + a;
-          val = a == 0u ? 1.0 : (double)m.design[(size_t)(a - 1u) * n_pad + i];
+          val = a == 0u ? 1.0 : (double)m.design[(size_t)(a - 1u) * dstride + di];
         }
         m.ridx[lane] = idx;
         m.rval[lane] = val;
@@ -825,19 +833,34 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
       }
       for (uint32_t pr = lane; pr < (uint32_t)Q0 * nz; pr += GW) {
         const uint32_t a = pr / nz, b = pr % nz;
-        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * n_pad + i];
+        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * dstride + di];
         ldd* cell = m.gzw + ((size_t)c * Q0 + a) * W + m.ridx[b];
         *cell = __builtin_fma(za, m.rval[b], *cell);
       }
       if (lane < (uint32_t)(Q0 * Q0)) {
         const uint32_t a = lane / Q0, b = lane % Q0;
-        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * n_pad + i];
-        const double zb = b == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][b - 1u] - 1u) * n_pad + i];
+        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * dstride + di];
+        const double zb = b == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][b - 1u] - 1u) * dstride + di];
         ldd* cell = m.gzz + (size_t)c * Q0 * Q0 + lane;
         *cell = __builtin_fma(za, zb, *cell);
       }
       lmg_sync();
     }
+  };
+  if (stream) {  // generate and fold window by window (n_grid = 1: every row belongs to the one fit)
+    const uint32_t n_only = prm.ns[0];
+    for (uint32_t base = 0; base < max_n; base += 256u) {
+      if (4u * (base / 4u + lane) < max_n) gen_quad(base / 4u + lane, base);
+      lmg_sync();
+      const uint32_t hi = base + 256u < n_only ? base + 256u : n_only;
+      if (base < hi) fold_rows(base, hi, base);
+      lmg_sync();
+    }
+    prev_n = n_only;
+  }
+  for (uint32_t g = 0; g < prm.n_grid; ++g) {
+    const uint32_t n = prm.ns[g];
+    if (prev_n < n) fold_rows(prev_n, n, 0u);
     prev_n = n;
     // ---- which model this round fits: sparse-factor flags recounted from rows [0, n) (batch.rs:1236-1250), then the
     //      kept columns of that flag combination (test_formula subsets included) ----

@@ -169,7 +169,8 @@ struct SimParams {
   double* lmm_rec;                 // [field][n_grid][lmm_rec_stride]
   uint32_t* lmm_rec_flags;         // [n_grid][lmm_rec_stride]: exclusion flag bits | LMM_FLAG_BALANCED
   uint32_t lmm_rec_stride;         // replicates per chunk, padded to 64
-  uint32_t _pad_lmm;
+  uint32_t lmg_stream;             // general LMM, single-size call without cluster-level columns or factors: the design
+                                   // streams through a 256-row LDS window instead of staying resident (lmm_general_impl.hpp)
 
   // ---- general mixed model: random slopes, crossed / nested extra groupings (generation.rs:196-427,
   //      data_gen.rs:163-284, 812-842; mixed_workspace.rs:57-198).  Term 0 = primary grouping ----
