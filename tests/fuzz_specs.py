@@ -87,11 +87,14 @@ def random_spec(seed: int, family: str):
         n_cl = int(rng.integers(6, 21))
         if rng.integers(0, 2):
             s.cluster = S.ClusterSpec(sizing=("FixedClusters", n_cl), tau_squared=round(float(rng.uniform(0.05, 0.6)), 3))
-            sizes = sorted({n_cl * int(v) for v in rng.integers(5, 16, size=int(rng.integers(1, 3)))})
+            sizes = sorted({n_cl * int(v) for v in rng.integers(10, 21, size=int(rng.integers(1, 3)))})
         else:
-            per = int(rng.integers(5, 16))
+            per = int(rng.integers(8, 16))
             s.cluster = S.ClusterSpec(sizing=("FixedSize", per), tau_squared=round(float(rng.uniform(0.05, 0.6)), 3))
-            sizes = sorted({per * int(v) for v in rng.integers(6, 21, size=int(rng.integers(1, 3)))})
+            sizes = sorted({per * int(v) for v in rng.integers(8, 21, size=int(rng.integers(1, 3)))})
+        # (at n = 35 with a sampled 4-level factor the design goes numerically singular in some replicates: both sides
+        # pass the rank test by a hair and return unrelated numbers -- seed 1098 of the first deep sweep; the sizes
+        # above keep >= 10 rows per cluster / >= 64 rows)
         s.scenario = S.ScenarioPerturbations(name="optimistic", truth_start=bool(rng.integers(0, 2)))
         n_sims = 48 if family == "glmm" else 192
     if scen:
