@@ -294,7 +294,13 @@ typedef int (*mcp_progress_fn)(uint64_t current, uint64_t total, void* user);
                                         ncclAllReduce(sum, uint64) of the device-resident vector on the launch stream,
                                         before the call's single device-to-host copy (merge.rs:26-70).  Every rank of
                                         the communicator must make the same call (same spec, sample sizes and flags;
-                                        its own sim_offset / n_sims shard).  Per-sim tensors stay local.  A progress
+                                        its own sim_offset / n_sims shard; a shard may be EMPTY, n_sims = 0, when
+                                        there are fewer replicates than ranks: that rank launches nothing, joins the
+                                        collective with zeros and returns the pooled counters).  Per-sim tensors stay
+                                        local.  A rank that fails BEFORE its collective (device error, invalid spec)
+                                        strands its peers, as in any collective program: validate with
+                                        mcp_build_crit_table on every rank first, and treat such a failure as fatal
+                                        for the job.  A progress
                                         callback that cancels on ANY rank cancels the call on EVERY rank: the verdict
                                         rides in the reduced payload, so all ranks leave the collective together */
 
@@ -363,6 +369,9 @@ int mcp_comm_unique_id(mcp_comm_id* id_out);
 int mcp_comm_init(int rank, int world, const mcp_comm_id* id);
 /* Leave and free the communicator (waits for the device first).  No-op without one. */
 int mcp_comm_destroy(void);
+/* Host-only: bind RCCL now (librccl.so.1 beside the HIP runtime this library uses, or the file MCP_RCCL_PATH names).
+ * MCP_OK, or MCP_ERR_DEVICE with the loader's message in mcp_last_error() -- what mcp_comm_init would fail with. */
+int mcp_comm_probe(void);
 int mcp_comm_rank(void);    /* -1 without a communicator */
 int mcp_comm_world(void);   /*  0 without a communicator */
 /* The sharding rule: rank r of W owns sim_ids [r*S/W, (r+1)*S/W) of a run of S replicates (host-only arithmetic). */

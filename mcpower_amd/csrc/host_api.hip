@@ -176,6 +176,11 @@ int ensure_device(hipStream_t* st, const mcp_run_options* opts, Arena* extra = n
   if (g_arena.device != dev) {
     g_arena.release();
     g_arena.device = dev;
+    // the timing origin and the side stream belong to the device they were created on
+    if (g_epoch) (void)hipEventDestroy(g_epoch);
+    g_epoch = nullptr;
+    if (g_upload_stream) (void)hipStreamDestroy(g_upload_stream);
+    g_upload_stream = nullptr;
   }
   if (extra && extra->device != dev) {
     extra->release();
@@ -241,6 +246,12 @@ int mcp_comm_init(int rank, int world, const mcp_comm_id* id) {
 int mcp_comm_destroy(void) {
   std::string err;
   const int rc = mcp::comm_destroy(err);
+  return rc ? fail(rc, err) : MCP_OK;
+}
+
+int mcp_comm_probe(void) {
+  std::string err;
+  const int rc = mcp::comm_probe(err);
   return rc ? fail(rc, err) : MCP_OK;
 }
 
@@ -318,10 +329,13 @@ int finish_timing(Arena& ar, hipEvent_t ev_begin, hipEvent_t ev_end, uint32_t la
     const size_t last = (size_t)(launched - 1) * ev_per_chunk;
     hipEvent_t kb = staged ? ar.events[3] : ar.events[2];
     hipEvent_t ke = staged ? ar.events[4 + last] : ar.events[3 + last];
-    HIP_TRY(hipEventElapsedTime(&ms, g_epoch, kb));
-    out->kernel_begin_ms = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, g_epoch, ke));
-    out->kernel_end_ms = ms;
+    float b_ms = 0.f, e_ms = 0.f;  // an origin from another device or stream state: no span rather than a failed batch
+    if (hipEventElapsedTime(&b_ms, g_epoch, kb) == hipSuccess && hipEventElapsedTime(&e_ms, g_epoch, ke) == hipSuccess) {
+      out->kernel_begin_ms = b_ms;
+      out->kernel_end_ms = e_ms;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   return MCP_OK;
 }
@@ -373,9 +387,43 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   out->counters = host_alloc<uint64_t>((size_t)n_ns * layout.stride);
   std::memset(out->counters, 0, (size_t)n_ns * layout.stride * sizeof(uint64_t));
   if (n_sims == 0 && !pool) return MCP_OK;  // batch.rs:390-421: empty tensors, shape carried
-  if (n_sims == 0) {  // an empty shard still owes the other ranks its (zero) contribution
-    mcp_free_result(out);
-    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: MCP_ALLREDUCE_COUNTERS needs n_sims > 0 on every rank (fewer replicates than ranks?)");
+  if (n_sims == 0) {
+    // an empty shard (fewer replicates than ranks) still owes the other ranks its zero contribution: no kernel, a
+    // zeroed vector joins the collective and the pooled counters come back like on every other rank
+    hipStream_t st0 = nullptr;
+    rc = ensure_device(&st0, opts, defer ? &defer->arena : nullptr);
+    if (rc) { mcp_free_result(out); return rc; }
+    Arena& ar0 = defer ? defer->arena : g_arena;
+    const uint32_t n_ctr0 = n_ns * layout.stride;
+    unsigned long long* d_vec = nullptr;
+    uint64_t* h_vec = nullptr;
+    hipEvent_t eb = nullptr, ee = nullptr;
+    std::string cerr;
+    int crc = MCP_OK;
+    hipError_t he = ar0.get(S_COUNTERS, ((size_t)n_ctr0 + 1u) * sizeof(uint64_t), (void**)&d_vec);
+    if (he == hipSuccess) he = ar0.get_pinned(1, ((size_t)n_ctr0 + 1u) * sizeof(uint64_t), (void**)&h_vec);
+    if (he == hipSuccess) he = ar0.event(0, &eb);
+    if (he == hipSuccess) he = ar0.event(1, &ee);
+    if (he == hipSuccess) he = hipEventRecord(eb, st0);
+    if (he == hipSuccess) he = hipMemsetAsync(d_vec, 0, ((size_t)n_ctr0 + 1u) * sizeof(uint64_t), st0);
+    // from here on the peers are waiting: whatever fails locally, the collective is still joined
+    if (d_vec) crc = mcp::comm_allreduce_u64(d_vec, (size_t)n_ctr0 + 1u, st0, cerr);
+    if (he == hipSuccess && !crc) he = hipMemcpyAsync(h_vec, d_vec, ((size_t)n_ctr0 + 1u) * sizeof(uint64_t), hipMemcpyDeviceToHost, st0);
+    if (he == hipSuccess && !crc) he = hipEventRecord(ee, st0);
+    if (he != hipSuccess || crc) {
+      (void)hipStreamSynchronize(st0);
+      mcp_free_result(out);
+      return crc ? fail(crc, cerr) : fail(MCP_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(he) + " on an empty shard");
+    }
+    if (defer) {
+      defer->ev_begin = eb; defer->ev_end = ee; defer->h_ctr = h_vec; defer->n_ctr = n_ctr0;
+      defer->launched = 0; defer->ev_per_chunk = 2; defer->glm = defer->reduced = defer->staged = false;
+      return MCP_OK;
+    }
+    if (hipStreamSynchronize(st0) != hipSuccess) { mcp_free_result(out); return fail(MCP_ERR_DEVICE, "HIP error: stream synchronize on an empty shard"); }
+    if (h_vec[n_ctr0] != 0) { mcp_free_result(out); return fail(MCP_ERR_CANCELLED, "cancelled by host (on another rank of the communicator)"); }
+    std::memcpy(out->counters, h_vec, (size_t)n_ctr0 * sizeof(uint64_t));
+    return MCP_OK;
   }
   const bool lmg = mle && prm.lmg_active;  // random slopes / extra groupings: the general mixed-model kernel
   const bool glmm = prm.glmm_active != 0u;  // clustered GLM: random-intercept GLMM kernel (writes flags like the Mle arm)
@@ -550,9 +598,12 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   hipEvent_t ev_begin, ev_end;
   DEV_TRY(ar.event(0, &ev_begin));
   DEV_TRY(ar.event(1, &ev_end));
-  if (!g_epoch) {
-    DEV_TRY(hipEventCreate(&g_epoch));
-    DEV_TRY(hipEventRecord(g_epoch, st));
+  if (!g_epoch) {  // a failed origin only costs the kernel_begin_ms / kernel_end_ms span (zeros), never the batch
+    hipEvent_t ep = nullptr;
+    if (hipEventCreate(&ep) == hipSuccess) {
+      if (hipEventRecord(ep, st) == hipSuccess) g_epoch = ep;
+      else (void)hipEventDestroy(ep);
+    }
   }
   DEV_TRY(hipEventRecord(ev_begin, st));
   hipStream_t up = st;  // where the counter reset and the table upload go
@@ -773,7 +824,8 @@ int mcp_run_batch_submit(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns
   if (!ticket_out) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: null ticket pointer");
   if (opts && (opts->flags & (MCP_WANT_PER_SIM | MCP_WANT_STAT_CAPTURE)))
     return fail(MCP_ERR_INVALID_SPEC, "invalid spec: mcp_run_batch_submit returns counters only (no per-sim tensors, no statistic capture)");
-  if (n_sims == 0) return fail(MCP_ERR_INVALID_SPEC, "invalid spec: mcp_run_batch_submit needs n_sims > 0");
+  if (n_sims == 0 && !(opts && (opts->flags & MCP_ALLREDUCE_COUNTERS)))  // an empty shard of a pooled call is allowed: it joins the collective
+    return fail(MCP_ERR_INVALID_SPEC, "invalid spec: mcp_run_batch_submit needs n_sims > 0");
   int slot = -1;
   for (int i = 0; i < MAX_IN_FLIGHT; ++i)
     if (!g_tickets[i].busy) { slot = i; break; }

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <mutex>
@@ -57,7 +58,16 @@ bool load_rccl(std::string& err) {
   std::string tried;
   void* h = nullptr;
   Dl_info info;
-  if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+  // MCP_RCCL_PATH names the library outright (a deployment with RCCL outside the runtime's directory); nothing else is tried
+  if (const char* forced = std::getenv("MCP_RCCL_PATH")) {
+    tried = std::string(forced) + " ";
+    h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      const char* why = dlerror();
+      err = std::string("RCCL is not loadable (tried ") + tried + "from MCP_RCCL_PATH): " + (why ? why : "not found");
+      return false;
+    }
+  } else if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
     std::string dir(info.dli_fname);
     const size_t slash = dir.rfind('/');
     if (slash != std::string::npos) {
@@ -78,7 +88,8 @@ bool load_rccl(std::string& err) {
     }
   }
   if (!h) {
-    err = std::string("RCCL is not loadable (tried ") + tried + "): " + (dlerror() ? dlerror() : "not found");
+    const char* why = dlerror();  // the call clears the state: read it once
+    err = std::string("RCCL is not loadable (tried ") + tried + "): " + (why ? why : "not found");
     return false;
   }
   Rccl r;
@@ -157,6 +168,12 @@ int comm_allreduce_u64(unsigned long long* d_words, size_t n, hipStream_t st, st
     return MCP_ERR_DEVICE;
   }
   return MCP_OK;
+}
+
+// host-only: can this process bind RCCL at all?  (no device needed; what mcp_comm_init would fail with otherwise)
+int comm_probe(std::string& err) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return load_rccl(err) ? MCP_OK : MCP_ERR_DEVICE;
 }
 
 int comm_unique_id(mcp_comm_id* out, int device, std::string& err) {

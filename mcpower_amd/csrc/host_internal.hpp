@@ -51,6 +51,7 @@ bool comm_active();
 int comm_device();
 int comm_rank();
 int comm_world();
+int comm_probe(std::string& err);
 int comm_unique_id(mcp_comm_id* out, int device, std::string& err);
 int comm_init(int rank, int world, const mcp_comm_id* id, int device, std::string& err);
 int comm_destroy(std::string& err);

@@ -23,6 +23,7 @@ EXPORTS = (
     "mcp_build_crit_table", "mcp_t_ppf", "mcp_norm_ppf", "mcp_chi2_ppf", "mcp_f_ppf", "mcp_generate_design",
     "mcp_fit_design", "mcp_icdf_probe", "mcp_run_batch_submit", "mcp_run_batch_collect",
     "mcp_comm_unique_id", "mcp_comm_init", "mcp_comm_destroy", "mcp_comm_rank", "mcp_comm_world", "mcp_shard_range",
+    "mcp_comm_probe",
 )
 COMM_ID_BYTES = 128
 _lib = None
@@ -101,6 +102,12 @@ def comm_init(rank: int, world: int, comm_id: bytes) -> None:
 
 def comm_destroy() -> None:
     _check(lib().mcp_comm_destroy())
+
+
+def comm_probe() -> None:
+    """`mcp_comm_probe` (host-only): bind RCCL now; raises `EngineError(Device)` with the loader's message when it is not
+    loadable (what `comm_init` would fail with on a box with a GPU)."""
+    _check(lib().mcp_comm_probe())
 
 
 def comm_rank() -> int:

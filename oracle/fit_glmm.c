@@ -94,6 +94,8 @@ typedef struct glmm_model {
   double* eta0;     /* n */
   double* u;        /* ncl: modes of the last evaluation */
   double* sw;       /* ncl: sum of IRLS weights at the mode */
+  double pirls_tol;  /* 1e-13; experiment knob PIRLS_TOL */
+  int pirls_warm;    /* 0; experiment knob PIRLS_WARM: start the mode loop from the previous evaluation's modes (lme4) */
 } glmm_model;
 
 static void glmm_free(glmm_model* m) {
@@ -105,6 +107,7 @@ static int glmm_build(glmm_model* m, int fam, const float* x, const float* y, co
                       uint32_t p, uint32_t ncl) {
   memset(m, 0, sizeof *m);
   m->fam = fam; m->n = n; m->ld = ld; m->p = p; m->ncl = ncl; m->x = x; m->y = y;
+  m->pirls_tol = mcpo_knob("PIRLS_TOL", 1e-13); m->pirls_warm = (int)mcpo_knob("PIRLS_WARM", 0.0);
   m->start = (uint32_t*)calloc(ncl + 2, sizeof(uint32_t));
   m->rows = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
   m->eta0 = (double*)malloc(sizeof(double) * (n ? n : 1));
@@ -133,6 +136,68 @@ static double glmm_deviance(glmm_model* m, const double* par) {
     m->eta0[i] = e;
   }
   double total = 0.0;
+  if (mcpo_knob("PIRLS_LME4", 0.0) != 0.0) {
+    /* EXPERIMENT (never the default): lme4's pwrssUpdate restated -- all clusters step together from u = 0, weights
+     * from the previous iterate, stop when the relative change of the TOTAL penalised deviance is below tol
+     * (tolPwrss = 1e-7), step halving (<= 10) when it rises; the log-determinant uses the weights of the iterate
+     * BEFORE the last step, as merPredD::ldL2 does after glmerWrkIter's final updateMu. */
+    const double tol = mcpo_knob("PIRLS_TOL", 1e-7);
+    const int lag = mcpo_knob("PIRLS_LAG", 1.0) != 0.0;
+    double oldpd = INFINITY, pdv = INFINITY;
+    double* un = (double*)malloc(sizeof(double) * m->ncl * 3);
+    double *swl = un + m->ncl, *uo = un + 2 * m->ncl;
+    for (uint32_t c = 0; c < m->ncl; ++c) { m->u[c] = 0.0; uo[c] = 0.0; }
+    int cvgd = 0;
+    for (int it = 0; it < 100 && !cvgd; ++it) {
+      /* weights / working residuals at the current u -> full step */
+      for (uint32_t c = 0; c < m->ncl; ++c) {
+        double swt = 0.0, swz = 0.0;
+        for (uint32_t k = m->start[c]; k < m->start[c + 1]; ++k) {
+          uint32_t i = m->rows[k];
+          double w, z, d;
+          mcpo_fam_eval(m->fam, m->eta0[i] + theta * m->u[c], (double)m->y[i], &w, &z, &d);
+          swt += w; swz += w * (z - m->eta0[i]);
+        }
+        swl[c] = swt;
+        un[c] = theta * swz / (theta * theta * swt + 1.0);
+      }
+      double f = 1.0;
+      for (int hv = 0; hv <= 10; ++hv) {
+        pdv = 0.0;
+        for (uint32_t c = 0; c < m->ncl; ++c) {
+          const double ut = m->u[c] + f * (un[c] - m->u[c]);
+          for (uint32_t k = m->start[c]; k < m->start[c + 1]; ++k) {
+            uint32_t i = m->rows[k];
+            double w, z, d;
+            mcpo_fam_eval(m->fam, m->eta0[i] + theta * ut, (double)m->y[i], &w, &z, &d);
+            pdv += d;
+          }
+          pdv += ut * ut;
+        }
+        if (pdv <= oldpd || !isfinite(oldpd)) break;
+        f *= 0.5;
+      }
+      for (uint32_t c = 0; c < m->ncl; ++c) { uo[c] = m->u[c]; m->u[c] += f * (un[c] - m->u[c]); }
+      if (fabs((oldpd - pdv) / pdv) < tol) cvgd = 1;
+      oldpd = pdv;
+    }
+    total = pdv;
+    for (uint32_t c = 0; c < m->ncl; ++c) {
+      double swt = 0.0;
+      if (!lag) {
+        for (uint32_t k = m->start[c]; k < m->start[c + 1]; ++k) {
+          uint32_t i = m->rows[k];
+          double w, z, d;
+          mcpo_fam_eval(m->fam, m->eta0[i] + theta * m->u[c], (double)m->y[i], &w, &z, &d);
+          swt += w;
+        }
+      } else swt = swl[c];
+      m->sw[c] = swt;
+      total += log(theta * theta * swt + 1.0);
+    }
+    free(un);
+    return isfinite(total) ? total : INFINITY;
+  }
   for (uint32_t c = 0; c < m->ncl; ++c) {
     const uint32_t lo = m->start[c], hi = m->start[c + 1];
     if (lo == hi) { m->u[c] = 0.0; m->sw[c] = 0.0; continue; }
@@ -140,7 +205,7 @@ static double glmm_deviance(glmm_model* m, const double* par) {
      * not below the accepted point's is pulled half-way back to it, so the accepted sequence descends monotonically.
      * (An undamped Fisher step 2-cycles on clusters far from their prior, e.g. 15 events of 20 at a 10 % baseline.) */
     double u = 0.0, sw = 0.0, dev = 0.0;            /* accepted point and its sums */
-    double ut = 0.0, pd_acc = INFINITY;              /* trial point */
+    double ut = m->pirls_warm ? m->u[c] : 0.0, pd_acc = INFINITY;  /* trial point */
     for (int it = 0; it < GLMM_PIRLS_ITERS; ++it) {
       double swz = 0.0, swt = 0.0, devt = 0.0;
       for (uint32_t k = lo; k < hi; ++k) {
@@ -149,7 +214,7 @@ static double glmm_deviance(glmm_model* m, const double* par) {
         mcpo_fam_eval(m->fam, m->eta0[i] + theta * ut, (double)m->y[i], &w, &z, &d);
         swt += w; swz += w * (z - m->eta0[i]); devt += d;
       }
-      const double pd = devt + ut * ut, tol = 1e-13 * (fabs(pd) + 1.0);
+      const double pd = devt + ut * ut, tol = m->pirls_tol * (fabs(pd) + 1.0);
       if (!(pd <= pd_acc + tol)) {                   /* worse than the accepted point (or not finite): halve the step */
         const double half = 0.5 * (ut + u);
         if (half == ut || half == u) break;
@@ -265,7 +330,41 @@ int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_
   mt = m;
   for (uint32_t k = nth; k < d; ++k) idx[m++] = k;
   double H[MAXD][MAXD], pt[MAXD];
-  const double dl = HESS_DELTA;
+  const double dl = mcpo_knob("HESS_DELTA", HESS_DELTA);
+  const int kind = (int)mcpo_knob("HESS_KIND", 0.0), rel = (int)mcpo_knob("HESS_REL", 0.0);
+  if (kind || rel) { /* experiment stencils: 1 = forward differences, 2 = Richardson (central at dl and 2 dl), rel: step dl * max(|x|, rel-floor) */
+    double hs[MAXD];
+    for (uint32_t a = 0; a < m; ++a) hs[a] = rel ? dl * fmax(fabs(par[idx[a]]), mcpo_knob("HESS_REL_FLOOR", 1.0)) : dl;
+    for (int pass = 0; pass < (kind == 2 ? 2 : 1); ++pass) {
+      const double sc = pass ? 2.0 : 1.0;
+      for (uint32_t a = 0; a < m; ++a)
+        for (uint32_t b = 0; b <= a; ++b) {
+          double v;
+          const double ha = sc * hs[a], hb = sc * hs[b];
+          if (kind == 1) {
+            memcpy(pt, par, sizeof(double) * d); pt[idx[a]] += ha; pt[idx[b]] += hb; const double fab = fn(ctx, pt);
+            memcpy(pt, par, sizeof(double) * d); pt[idx[a]] += ha; const double fa = fn(ctx, pt);
+            memcpy(pt, par, sizeof(double) * d); pt[idx[b]] += hb; const double fb = fn(ctx, pt);
+            v = (fab - fa - fb + fx) / (ha * hb);
+          } else if (a == b) {
+            memcpy(pt, par, sizeof(double) * d); pt[idx[a]] += ha; const double fp = fn(ctx, pt);
+            memcpy(pt, par, sizeof(double) * d); pt[idx[a]] -= ha; const double fm = fn(ctx, pt);
+            v = (fp - 2.0 * fx + fm) / (ha * ha);
+          } else {
+            double fq[4];
+            for (int q = 0; q < 4; ++q) {
+              memcpy(pt, par, sizeof(double) * d);
+              pt[idx[b]] += (q & 2) ? -hb : hb;
+              pt[idx[a]] += (q & 1) ? -ha : ha;
+              fq[q] = fn(ctx, pt);
+            }
+            v = (fq[0] - fq[1] - fq[2] + fq[3]) / (4.0 * ha * hb);
+          }
+          if (pass == 0) H[a][b] = H[b][a] = v;
+          else H[a][b] = H[b][a] = (4.0 * H[a][b] - v) / 3.0;
+        }
+    }
+  } else
   for (uint32_t a = 0; a < m; ++a) {
     memcpy(pt, par, sizeof(double) * d); pt[idx[a]] = par[idx[a]] + dl;
     const double fadd = fn(ctx, pt);
@@ -346,15 +445,17 @@ static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, uin
   for (uint32_t c = 0; c < p; ++c) par[1 + c] = beta0 ? beta0[c] : 0.0;
   memset(f, 0, sizeof *f);
   uint32_t n_eval = 0;
-  double best = glmm_nelder_mead(m, par, 0.25, 1e-10, 1e-7, &n_eval);
+  const double nmt = mcpo_knob("NM_TOL", 1.0);  /* experiment knob: scales both simplex tolerances */
+  double best = glmm_nelder_mead(m, par, 0.25, 1e-10 * nmt, 1e-7 * nmt, &n_eval);
   /* restarts (they guard against a collapsed simplex) only for a point the stationarity check rejects (oracle_internal.h) */
   uint8_t lower0[GLMM_MAX_DIM] = {1};
   glmm_count_cb probe = {m, &n_eval};
-  const int stationary = mcpo_stationary(glmm_probe_cb, &probe, par, d, lower0, best);
-  for (int restart = 0; !stationary && restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
+  const int polish = (int)mcpo_knob("POLISH", 0.0);  /* experiment knob: that many unconditional restarts */
+  const int stationary = polish ? 0 : mcpo_stationary(glmm_probe_cb, &probe, par, d, lower0, best);
+  for (int restart = 0; !stationary && restart < (polish ? polish : 4) && n_eval < GLMM_MAX_EVAL; ++restart) {
     double prev = best;
-    best = glmm_nelder_mead(m, par, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, &n_eval);
-    if (!(prev - best > 1e-8)) break;
+    best = glmm_nelder_mead(m, par, restart == 0 ? 0.05 : 0.01, 1e-10 * nmt, 1e-7 * nmt, &n_eval);
+    if (!polish && !(prev - best > 1e-8)) break;
   }
   double cur = glmm_f(m, par, &n_eval);
   if (par[0] != 0.0 && par[0] <= 1e-4) { /* snap onto the boundary when that costs no deviance */
@@ -403,7 +504,9 @@ static int glmm_fit_model(glmm_model* m, double theta0, const double* beta0, uin
   if (ok && (mode & MCPO_MODE_HESSIAN) && par[0] >= GLMM_THETA_ZERO) { /* a singular fit, or a block that does not factor, keeps "rx" */
     const uint8_t th_free = 1;
     double lh[MCPO_MAX_P * MCPO_MAX_P];
-    if (mcpo_fd_hessian_factor(glmm_dev_cb, m, par, 1, p, &th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
+    const uint32_t hq = (uint32_t)mcpo_knob("HESS_NAGQ", 0.0);  /* experiment knob: difference the hq-point AGQ deviance at the Laplace optimum */
+    if (hq > 1) { m->nagq = hq; mcpo_gh_rule(hq, m->gz, m->gw); cur = glmm_f(m, par, &n_eval); }
+    if (mcpo_fd_hessian_factor(glmm_dev_cb, m, par, 1, p, &th_free, mcpo_knob("HESS_FX", 0.0) != 0.0 ? best : cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
   }
   f->converged = ok;
   f->pinned = (ok && par[0] < GLMM_THETA_ZERO) ? 1u : 0u;

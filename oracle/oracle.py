@@ -31,7 +31,7 @@ def build(force: bool = False) -> str:
     if force:
         subprocess.run(["make", "-C", _HERE, "clean"], capture_output=True)
     r = subprocess.run(["make", "-C", _HERE], capture_output=True, text=True)
-    if r.returncode != 0 and not os.path.exists(_LIB_PATH):
+    if r.returncode != 0:   # a failed rebuild must never leave a stale library in use
         raise RuntimeError("oracle build failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
     return _LIB_PATH
 
@@ -56,8 +56,12 @@ def cflags() -> str:
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        snap = os.environ.get("MCPO_LIB_PATH")   # worker processes of tools/oracle2_perdraw.py: a snapshot the parent built
+        if snap:
+            L = C.CDLL(snap)
+        else:
+            build()
+            L = C.CDLL(_LIB_PATH)
         L.mcpo_splitmix64.restype = C.c_uint64
         L.mcpo_splitmix64.argtypes = [C.c_uint64]
         L.mcpo_pcg_mix64.restype = C.c_uint64

@@ -71,6 +71,16 @@ void mcpo_gh_rule(uint32_t k, double* z, double* w);
 int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                 const mcpo_re_term* terms, uint32_t n_terms, const double* theta0, const double* beta0,
                                 uint32_t mode, mcpo_gen_fit* f);
+/* EXPERIMENT KNOBS (tools/oracle2_perdraw.py; DESIGN.md section 5, "oracle2 experiments"): environment variable
+ * MCPO_KNOB_<NAME>, read at every call (the harness sets them per worker process); unset = the shipped constant, so the
+ * checker's results are unchanged unless a knob is exported.  Never read by the product. */
+#include <stdlib.h>
+static inline double mcpo_knob(const char* name, double dflt) {
+  char key[64] = "MCPO_KNOB_";
+  strncat(key, name, sizeof key - 11);
+  const char* v = getenv(key);
+  return v && *v ? strtod(v, NULL) : dflt;
+}
 typedef double (*mcpo_dev_fn)(void* ctx, double* par);
 int mcpo_fd_hessian_factor(mcpo_dev_fn fn, void* ctx, const double* par, uint32_t nth, uint32_t p, const uint8_t* theta_free,
                            double fx, double* l_out);

@@ -3,6 +3,8 @@ include/mcpower_hip.h declares, and its host-only entry points (validation, crit
 agree with the oracle.  No device compute here."""
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -87,6 +89,19 @@ def test_comm_entry_points_fail_loudly_without_a_device(engine):
     assert engine.shard_range(10, 0, 3) == (0, 3) and engine.shard_range(10, 2, 3) == (6, 4)
     with pytest.raises(S.EngineError):
         engine.shard_range(10, 3, 3)
+
+
+def test_unloadable_rccl_is_a_clean_device_error():
+    """A host where librccl cannot be loaded must get MCP_ERR_DEVICE and the loader's message from the communicator
+    entry points, not a crash (the error string used to be built from a second, NULL-returning dlerror() call).
+    Fresh process: the binding is cached per process."""
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['MCP_RCCL_PATH'] = '/nonexistent/librccl.so.1'\n"
+            "from mcpower_amd import engine, spec as S\n"
+            "try:\n    engine.comm_probe()\nexcept S.EngineError as e:\n"
+            "    assert e.status == S.Status.Device, e.status\n    print('MSG', e)\nelse:\n    raise SystemExit('no error')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RCCL is not loadable" in r.stdout and "/nonexistent/librccl.so.1" in r.stdout and "MCP_RCCL_PATH" in r.stdout
 
 
 def test_crit_table_matches_oracle(engine, oracle):

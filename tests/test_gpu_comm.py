@@ -71,3 +71,19 @@ def test_cancel_travels_through_the_collective(comm):
     assert int(again.counter("n_sims", 1)[0, 0]) == 10_000
 
 
+
+
+def test_an_empty_shard_joins_the_collective_with_zeros(comm):
+    """Fewer replicates than ranks: the rank whose slice is empty launches nothing but still takes part in the
+    all-reduce (a refusal there would leave its peers waiting in the collective for ever).  World of one: the pooled
+    vector of an empty shard is all zeros, on the blocking and on the submit / collect entry point."""
+    spec = spec_c2a()
+    r = comm.run_batch(spec, [100, 200], 0, BASE_SEED, per_sim=False, allreduce=True)
+    assert r.counters.shape[0] == 2 and int(r.counters.sum()) == 0
+    t = comm.submit_batch(spec.to_c(), [200], 0, BASE_SEED, allreduce=True)
+    assert int(t.collect().counters.sum()) == 0
+    off, cnt = mdist.shard_range(3, 7, 8)
+    assert cnt in (0, 1)
+    # the communicator is still usable afterwards
+    again = comm.run_batch(spec, [200], 10_000, BASE_SEED, per_sim=False, allreduce=True)
+    assert int(again.counter("n_sims", 1)[0, 0]) == 10_000
