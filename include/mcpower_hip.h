@@ -290,6 +290,10 @@ typedef int (*mcp_progress_fn)(uint64_t current, uint64_t total, void* user);
 #define MCP_WANT_STAT_CAPTURE 0x2u   /* run_batch_st_capture (batch.rs:180) */
 #define MCP_PIPELINE_STAGED   0x4u   /* generator -> HBM design -> fit kernels instead of the fused kernel (OLS, <= 8
                                          design columns; wider designs and the other estimators ignore the flag) */
+#define MCP_SEED_PER_REPLICATE 0x10u /* validation aid (clustered GLM only): replicate i is replicate 0 of its OWN call seed,
+                                        key_i = splitmix64(splitmix64(base_seed + sim_offset + i)) -- the draw sequence of the
+                                        reference's per-draw harness (validation/oracle2_power.R:38-66: `.debug_seed = base + k`,
+                                        create_data -> load_data), so that its frozen per-draw rates are same-data comparisons */
 #define MCP_ALLREDUCE_COUNTERS 0x8u  /* pool `counters` over the ranks of this process's communicator: one
                                         ncclAllReduce(sum, uint64) of the device-resident vector on the launch stream,
                                         before the call's single device-to-host copy (merge.rs:26-70).  Every rank of

@@ -185,7 +185,11 @@ hipError_t launch_glm_sim(int P, const SimParams* d_prm, uint32_t n_sims, uint32
 }
 
 hipError_t launch_fold_flags(const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
-  hipLaunchKernelGGL(fold_flags_kernel, dim3((n_sims + 255u) / 256u), dim3(256), 0, st, d_prm);
+  // 64-thread workgroups: the fold of batch i competes for wave slots with the main kernel of batch i + 1 (its own
+  // stream), whose single-wave workgroups refill every slot the moment it frees -- a 256-thread workgroup needs four
+  // free slots on ONE CU at once and starved behind them (mean residence 45 ms for 4 us of work,
+  // profiles/r02_c_lmm_slope_kernel_stats.csv)
+  hipLaunchKernelGGL(fold_flags_kernel, dim3((n_sims + 63u) / 64u), dim3(64), 0, st, d_prm);
   return hipGetLastError();
 }
 

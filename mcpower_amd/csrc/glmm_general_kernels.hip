@@ -511,7 +511,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
   const uint32_t lane = threadIdx.x;
   const uint32_t lsim = blockIdx.x;
   const uint64_t sim_id = prm.sim_begin + lsim;
-  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint64_t key = replicate_key(prm, sim_id);
   const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
   const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
   const uint32_t ncl_max = prm.n_clusters_max;

@@ -57,7 +57,7 @@ __device__ __forceinline__ double gq_wave_sum(double v) {
 
 // Laplace deviance at par = (theta, beta); leaves the modes and weight sums of every cluster in LDS
 template <int P>
-__device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
+__device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
                                          uint32_t ncl, uint32_t n_pad, uint32_t keep) {
   const uint32_t fam = prm.glm_family;
   const double theta = par[0];
@@ -167,119 +167,11 @@ __device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, 
   return (total < __builtin_inf() && total > -__builtin_inf()) ? total : __builtin_inf();
 }
 
-template <int P>
-__device__ __forceinline__ double glmm_f(const SimParams& prm, const GlmmLds& m, gdd* x, uint32_t lane, uint32_t n, uint32_t ncl,
-                                         uint32_t n_pad, uint32_t keep, uint32_t& n_eval) {
-  if (lane <= (uint32_t)__popc(keep)) {
-    double v = x[lane];
-    if (lane == 0u) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
-    else v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
-    x[lane] = v;
-  }
-  gq_sync();
-  ++n_eval;
-  return glmm_eval<P>(prm, m, x, lane, n, ncl, n_pad, keep);
-}
-
-// one Nelder-Mead run from simplex row 0 with initial edge `step`; the best point ends in row 0
-template <int P>
-__device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const GlmmLds m, double step, double ftol, double xtol,
-                                                uint32_t lane, uint32_t n, uint32_t ncl, uint32_t n_pad, uint32_t keep,
-                                                uint32_t& n_eval) {
-  const uint32_t d = 1u + (uint32_t)__popc(keep);
-  gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe
-  gdd* fv = m.fv;
-  gdd* cen = sx + (size_t)(d + 1u) * GLMM_ROW;
-  gdd* xr = cen + GLMM_ROW;
-  gdd* xe = xr + GLMM_ROW;
-  const double inf = __builtin_inf();
-  const double f0 = glmm_f<P>(prm, m, sx, lane, n, ncl, n_pad, keep, n_eval);
-  if (lane == 0u) fv[0] = f0;
-  for (uint32_t i = 0; i < d; ++i) {
-    gdd* v = sx + (size_t)(i + 1u) * GLMM_ROW;
-    if (lane < d) v[lane] = sx[lane] + (lane == i ? step : 0.0);
-    gq_sync();
-    const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
-    if (lane == 0u) fv[i + 1u] = fi;
-  }
-  gq_sync();
-  while (n_eval < GLMM_MAX_EVAL) {
-    uint32_t lo = 0, hi = 0;
-    for (uint32_t i = 1; i <= d; ++i) {
-      if (fv[i] < fv[lo]) lo = i;
-      if (fv[i] > fv[hi]) hi = i;
-    }
-    uint32_t nh = lo;
-    for (uint32_t i = 0; i <= d; ++i)
-      if (i != hi && fv[i] > fv[nh]) nh = i;
-    double size = 0.0;
-    for (uint32_t i = 0; i <= d; ++i)
-      for (uint32_t k = 0; k < d; ++k) {
-        const double dd = __builtin_fabs(sx[(size_t)i * GLMM_ROW + k] - sx[(size_t)lo * GLMM_ROW + k]);
-        size = dd > size ? dd : size;
-      }
-    if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
-    const double flo = fv[lo], fhi = fv[hi], fnh = fv[nh];
-    gq_sync();
-    if (lane < d) {
-      double s = 0.0;
-      for (uint32_t i = 0; i <= d; ++i)
-        if (i != hi) s += sx[(size_t)i * GLMM_ROW + lane];
-      const double c = s / (double)d;
-      cen[lane] = c;
-      xr[lane] = c + (c - sx[(size_t)hi * GLMM_ROW + lane]);
-    }
-    gq_sync();
-    const double fr = glmm_f<P>(prm, m, xr, lane, n, ncl, n_pad, keep, n_eval);
-    gdd* worst = sx + (size_t)hi * GLMM_ROW;
-    if (fr < flo) {
-      if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
-      gq_sync();
-      const double fe = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
-      if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
-      if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
-    } else if (fr < fnh) {
-      if (lane < d) worst[lane] = xr[lane];
-      if (lane == 0u) fv[hi] = fr;
-    } else {
-      const bool outside = fr < fhi;
-      if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
-      gq_sync();
-      const double fc = glmm_f<P>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
-      if (fc < (outside ? fr : fhi)) {
-        if (lane < d) worst[lane] = xe[lane];
-        if (lane == 0u) fv[hi] = fc;
-      } else {
-        for (uint32_t i = 0; i <= d; ++i) {
-          if (i == lo) continue;
-          gdd* v = sx + (size_t)i * GLMM_ROW;
-          if (lane < d) v[lane] = sx[(size_t)lo * GLMM_ROW + lane] + 0.5 * (v[lane] - sx[(size_t)lo * GLMM_ROW + lane]);
-          gq_sync();
-          const double fi = glmm_f<P>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
-          if (lane == 0u) fv[i] = fi;
-          gq_sync();
-        }
-      }
-    }
-    gq_sync();
-  }
-  uint32_t lo = 0;
-  for (uint32_t i = 1; i <= d; ++i)
-    if (fv[i] < fv[lo]) lo = i;
-  const double best = fv[lo];
-  gq_sync();
-  double best_k = 0.0;
-  if (lane < d) best_k = sx[(size_t)lo * GLMM_ROW + lane];
-  gq_sync();
-  if (lane < d) sx[lane] = best_k;
-  gq_sync();
-  return best;
-}
-
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
-#include "mcp_glmm_hessian.hpp"
-#include "mcp_stationary.hpp"
+#include "mcp_stationary.hpp"  // MCP_STAT_H / MCP_STAT_TOL
+#include "mcp_fit_fsm.hpp"
+#include "mcp_glmm_tail.hpp"
 
 template <int P, bool SCEN>
 __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_kernel(const SimParams* __restrict__ pp) {
@@ -288,7 +180,7 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_kernel(const SimParam
   const uint32_t lane = threadIdx.x;
   const uint32_t lsim = blockIdx.x;
   const uint64_t sim_id = prm.sim_begin + lsim;
-  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint64_t key = replicate_key(prm, sim_id);
   const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
   const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
   const uint32_t ncl_max = prm.n_clusters_max, ncl_pad = (ncl_max + 1u) & ~1u;
@@ -402,139 +294,73 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_kernel(const SimParam
         if ((keep >> c) & 1u) x0[k++] = prm.beta[c];                      // beta starts at the truth, unconditionally
     }
     gq_sync();
-    uint32_t n_eval = 0;
-    double best = glmm_nelder_mead<P>(prm, m, 0.25, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
-    // restarts (they guard against a collapsed simplex) only for a point the stationarity check rejects (mcp_stationary.hpp)
-    auto fprobe = [&](gdd* pt) -> double { return glmm_f<P>(prm, m, pt, lane, n, ncl, n_pad, keep, n_eval); };
-    const bool stationary = mixed_stationary(fprobe, m.simplex, (uint32_t)GLMM_ROW, 1u + (uint32_t)__popc(keep), 1u, best, lane);
-    for (int restart = 0; !stationary && restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
-      const double prev = best;
-      best = glmm_nelder_mead<P>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
-      if (!(prev - best > 1e-8)) break;
-    }
-    double cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
-    {
-      const double th_keep = x0[0];
-      if (th_keep != 0.0 && th_keep <= 1e-4) {  // snap onto the boundary when that costs no deviance
-        gq_sync();
-        if (lane == 0u) x0[0] = 0.0;
-        gq_sync();
-        const double f0 = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
-        if (f0 <= cur + 1e-8) cur = f0;
-        else {
-          gq_sync();
-          if (lane == 0u) x0[0] = th_keep;
-          gq_sync();
-        }
+    // ---- the fit: one wave-uniform state machine around the single inlined evaluation (mcp_fit_fsm.hpp) ----
+    const uint32_t d_fit = 1u + (uint32_t)__popc(keep);
+    bool ok = false;
+    double theta = 0.0;
+    auto eval_pt = [&](gdd* x) -> double {  // clamp the point onto the bounds, then the Laplace deviance
+      if (lane < d_fit) {
+        double v = x[lane];
+        if (lane == 0u) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+        else v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
+        x[lane] = v;
       }
-    }
-    cur = glmm_f<P>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);  // modes and weight sums of the final point
-    const double theta = x0[0];
-    bool ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
-    // ---- RX'RX at the optimum: lane = cluster accumulates X_c'W X_c and a_c = X_c'w_c, wave sums the Schur terms ----
-    double A[P * (P + 1) / 2];
-#pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = 0.0;
-    for (uint32_t c = lane; c < ncl; c += QW) {
-      const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
-      const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
-      const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
-      double a[P], loc[P * (P + 1) / 2];
-#pragma unroll
-      for (int i = 0; i < P; ++i) a[i] = 0.0;
-#pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) loc[i] = 0.0;
-      const double uc = m.ucl[c];
-      for (uint32_t i = first; i < last; i += step) {
-        double w, wz, dv;
-        fam_eval(prm.glm_family, m.eta0[i] + theta * uc, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
-        double xd[P];
-        xd[0] = 1.0;
-#pragma unroll
-        for (int r = 1; r < P; ++r) xd[r] = (double)m.design[(size_t)(r - 1) * n_pad + i];
-        int idx = 0;
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-          a[r] += w * xd[r];
-#pragma unroll
-          for (int s = 0; s <= r; ++s) loc[idx++] += w * xd[r] * xd[s];
-        }
-      }
-      const double den = theta * theta * m.swcl[c] + 1.0;
-      int idx = 0;
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-#pragma unroll
-        for (int s = 0; s <= r; ++s) {
-          A[idx] += loc[idx] - theta * theta * a[r] * a[s] / den;
-          ++idx;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]);
-    double Lx[P][P];
-    // lower Cholesky factor of a packed precision matrix over the kept columns; a dropped column is an identity row /
-    // column: the kept block factors as the gathered system
-    auto factor = [&](const double (&Ap)[P * (P + 1) / 2], double (&L)[P][P]) -> bool {
-      bool fok = true;
-      int idx = 0;
-      double Af[P][P];
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-#pragma unroll
-        for (int s = 0; s <= r; ++s) {
-          const double v = Ap[idx++];
-          Af[r][s] = (((keep >> r) & 1u) && ((keep >> s) & 1u)) ? v : (r == s ? 1.0 : 0.0);
-        }
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        double dd = Af[j][j];
-#pragma unroll
-        for (int t = 0; t < j; ++t) dd -= L[j][t] * L[j][t];
-        fok = fok && (dd > 0.0) && (dd < __builtin_inf());
-        L[j][j] = __builtin_sqrt(dd);
-#pragma unroll
-        for (int i = j + 1; i < P; ++i) {
-          double v = Af[i][j];
-#pragma unroll
-          for (int t = 0; t < j; ++t) v -= L[i][t] * L[j][t];
-          L[i][j] = v / L[j][j];
-        }
-      }
-      return fok;
+      gq_sync();
+      return glmm_eval<P>(prm, m, x, lane, n, ncl, n_pad, keep);
     };
-    ok = factor(A, Lx) && ok;
-    if (prm.glmm_hessian && ok && !(theta < GLMM_THETA_ZERO)) {
-      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp); a singular fit, or a block that does not factor, keeps "rx"
-      auto fdev = [&](gdd* pt) -> double {
-        uint32_t scratch = 0;
-        return glmm_f<P>(prm, m, pt, lane, n, ncl, n_pad, keep, scratch);
-      };
-      const uint32_t nth_h = 1u, d_h = nth_h + (uint32_t)__popc(keep);
-      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane, 1u)) {
-        double Ah[P * (P + 1) / 2], Lh[P][P];
-        const gdd* Hs = m.simplex + GLMM_ROW;
-        int idx = 0;
-        uint32_t kr = 0;
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-          uint32_t kc = 0;
-#pragma unroll
-          for (int s = 0; s <= r; ++s) {
-            const bool both = ((keep >> r) & 1u) && ((keep >> s) & 1u);
-            Ah[idx++] = both ? Hs[(size_t)(nth_h + kr) * GLMM_ROW + nth_h + kc] : 0.0;
-            kc += ((keep >> s) & 1u) ? 1u : 0u;
+    auto on_final = [&](double cur, uint32_t n_eval) -> uint32_t {
+      theta = x0[0];
+      ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
+      // ---- RX'RX = X'WX - sum_c theta^2 a_c a_c' / (theta^2 sw_c + 1), a_c = X_c'w_c, at the optimum, in LDS (mcp_glmm_tail.hpp):
+      //      lane = row leaves the IRLS weight at the final modes in eta0's slot (every evaluation rebuilds eta0), then
+      //      lane = entry (r, s) of the lower triangle sums its products cluster by cluster, rows ascending ----
+      for (uint32_t i = lane; i < n; i += QW) {
+        const uint32_t cid = prm.cluster_fixed_clusters ? i % cv : i / cv;
+        double w, wz, dv;
+        fam_eval(prm.glm_family, m.eta0[i] + theta * m.ucl[cid], (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
+        m.eta0[i] = w;
+      }
+      gq_sync();
+      if (lane < (uint32_t)(P * (P + 1) / 2)) {
+        uint32_t r = 0;
+        while ((r + 1u) * (r + 2u) / 2u <= lane) ++r;
+        const uint32_t s = lane - r * (r + 1u) / 2u;
+        double acc = 0.0;
+        for (uint32_t c = 0; c < ncl; ++c) {
+          const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
+          const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
+          const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
+          double loc = 0.0, ar = 0.0, as = 0.0;
+          for (uint32_t i = first; i < last; i += step) {
+            const double w = m.eta0[i];
+            const double xr = r == 0u ? 1.0 : (double)m.design[(size_t)(r - 1u) * n_pad + i];
+            const double xs = s == 0u ? 1.0 : (double)m.design[(size_t)(s - 1u) * n_pad + i];
+            ar += w * xr;
+            as += w * xs;
+            loc += w * xr * xs;
           }
-          kr += ((keep >> r) & 1u) ? 1u : 0u;
+          acc += loc - theta * theta * ar * as / (theta * theta * m.swcl[c] + 1.0);
         }
-        if (factor(Ah, Lh)) {
-#pragma unroll
-          for (int r = 0; r < P; ++r)
-#pragma unroll
-            for (int s = 0; s <= r; ++s) Lx[r][s] = Lh[r][s];
+        m.tail[GT_LX + r * 8u + s] = acc;
+      }
+      if (lane == 0u) {  // fitted coefficients in column order; a column outside a test_formula subset has coefficient 0
+        uint32_t k = 1;
+        for (uint32_t c = 0; c < (uint32_t)P; ++c) {
+          const bool kept = (keep >> c) & 1u;
+          m.tail[GT_BETA + c] = kept ? x0[k] : 0.0;
+          k += kept ? 1u : 0u;
         }
       }
-    }
+      gq_sync();
+      if (lane == 0u) m.tail[GT_SPARE] = glmm_tail_factor(m.tail + GT_LX, m.tail + GT_LX, (uint32_t)P, keep) ? 1.0 : 0.0;
+      gq_sync();
+      ok = (m.tail[GT_SPARE] != 0.0) && ok;
+      // Wald SE mode "hessian": lme4's deriv12 stencil over (theta, beta); a singular fit, or a block that does not
+      // factor, keeps "rx"
+      return (prm.glmm_hessian && ok && !(theta < GLMM_THETA_ZERO)) ? (FIT_FSM_HESSIAN | 1u) : 0u;
+    };
+    const FitFsmOut fit = simplex_fit_fsm(m.simplex, m.fv, d_fit, (uint32_t)GLMM_ROW, 1u, 1u, GLMM_MAX_EVAL, lane, eval_pt, on_final);
+    if (fit.hess_ok && lane == 0u) glmm_tail_take_hessian(m.tail, m.simplex + GLMM_ROW, (uint32_t)GLMM_ROW, 1u, (uint32_t)P, keep);
     bool conv = ok;
     const bool at_upper = theta > GLMM_THETA_MAX - 1e-3;
     const uint32_t pinned = (conv && theta < GLMM_THETA_ZERO) ? 1u : 0u;
@@ -544,109 +370,10 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_kernel(const SimParam
       carry = theta;
       has_prev = true;
     }
-    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions ----
-    double beta[P];
-    {
-      uint32_t k = 1;
-#pragma unroll
-      for (int c = 0; c < P; ++c) {
-        const bool kept = (keep >> c) & 1u;
-        beta[c] = kept ? x0[k] : 0.0;
-        k += kept ? 1u : 0u;
-      }
-    }
-    const double* crow = prm.crit + (size_t)g * prm.crit_stride;
-    double tsq[MAX_T_WAVE];
-    double U[MAX_T_WAVE][P];
-#pragma unroll
-    for (int t = 0; t < MAX_T_WAVE; ++t) {
-      tsq[t] = __builtin_nan("");
-#pragma unroll
-      for (int i = 0; i < P; ++i) U[t][i] = 0.0;
-      if ((uint32_t)t < nt && conv) {
-        const double* c = prm.contrast + t * MAX_P;
-        double est = 0.0, nq = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          est = __builtin_fma(c[i], beta[i], est);
-          double acc = c[i];
-#pragma unroll
-          for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i][q], U[t][q], acc);
-          U[t][i] = acc / Lx[i][i];
-          nq = __builtin_fma(U[t][i], U[t][i], nq);
-        }
-        if (nq > GLMM_NEAR_ZERO && nq < __builtin_inf()) tsq[t] = est * est / nq;
-      }
-    }
-    bool joint_sig = false;
-    if (conv && nt != 0u) {
-      double Lc[MAX_T_WAVE][MAX_T_WAVE], cj[MAX_T_WAVE];
-      bool jok = true;
-      double qsum = 0.0;
-#pragma unroll
-      for (int j = 0; j < MAX_T_WAVE; ++j) {
-        if ((uint32_t)j < nt) {
-          double dd = 0.0;
-#pragma unroll
-          for (int i = 0; i < P; ++i) dd = __builtin_fma(U[j][i], U[j][i], dd);
-#pragma unroll
-          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j][t], Lc[j][t], dd);
-          jok = jok && (dd > 0.0);
-          Lc[j][j] = __builtin_sqrt(dd);
-#pragma unroll
-          for (int i2 = j + 1; i2 < MAX_T_WAVE; ++i2) {
-            if ((uint32_t)i2 < nt) {
-              double vv = 0.0;
-#pragma unroll
-              for (int i = 0; i < P; ++i) vv = __builtin_fma(U[i2][i], U[j][i], vv);
-#pragma unroll
-              for (int t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2][t], Lc[j][t], vv);
-              Lc[i2][j] = vv / Lc[j][j];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MAX_T_WAVE; ++i) {
-        if ((uint32_t)i < nt) {
-          const double* c = prm.contrast + i * MAX_P;
-          double vv = 0.0;
-#pragma unroll
-          for (int q = 0; q < P; ++q) vv = __builtin_fma(c[q], beta[q], vv);
-#pragma unroll
-          for (int t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i][t], cj[t], vv);
-          cj[i] = vv / Lc[i][i];
-          qsum = __builtin_fma(cj[i], cj[i], qsum);
-        }
-      }
-      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > prm.joint_crit_k[nt]);
-    }
-    uint32_t unc_bits = 0, cor_bits = 0;
-    decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
-    if (!conv) {
-      unc_bits = 0;
-      cor_bits = 0;
-    }
-    if (lane == 0u) {
-      const size_t cell = (size_t)(prm.out_base + lsim) * prm.n_grid + g;
-#pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t)
-        if ((uint32_t)t < nt) {
-          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
-          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
-        }
-      prm.conv[cell] = conv ? 1 : 0;
-      prm.boundary[cell] = (uint8_t)bh;
-      prm.joint[cell] = joint_sig ? 1 : 0;
-      if (prm.pinned) prm.pinned[cell] = (uint16_t)pinned;
-      if (prm.tau_hat) prm.tau_hat[cell] = conv ? theta * theta : __builtin_nan("");
-      if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1750-1753
-      if (prm.stat && g == 0u) {
-#pragma unroll
-        for (int t = 0; t < MAX_T_WAVE; ++t)
-          if ((uint32_t)t < nt) prm.stat[(size_t)(prm.out_base + lsim) * nt + t] = tsq[t];
-      }
-    }
+    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions: one lane, in LDS ----
+    if (lane == 0u)
+      glmm_tail_decide(prm, m.tail, (uint32_t)P, nt, conv, bh, pinned, theta * theta, prm.crit + (size_t)g * prm.crit_stride,
+                       (size_t)(prm.out_base + lsim) * prm.n_grid + g, (size_t)(prm.out_base + lsim), g == 0u);
     gq_sync();
   }
 }

@@ -60,7 +60,7 @@ __device__ __forceinline__ double gq_wave_sum(double v) {
 
 // Laplace deviance at par = (theta vech, beta); leaves the modes and the Cholesky factors of I + A'WA in LDS
 template <int P, int Q>
-__device__ __noinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
+__device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds m, const gdd* par, uint32_t lane, uint32_t n,
                                          uint32_t ncl, uint32_t n_pad, uint32_t keep) {
   constexpr int NTH = Q * (Q + 1) / 2;
   const uint32_t fam = prm.glm_family;
@@ -268,124 +268,11 @@ __device__ __forceinline__ bool glmm_is_diag(uint32_t k) {
   return false;
 }
 
-template <int P, int Q>
-__device__ __forceinline__ double glmm_f(const SimParams& prm, const GlmmLds& m, gdd* x, uint32_t lane, uint32_t n, uint32_t ncl,
-                                         uint32_t n_pad, uint32_t keep, uint32_t& n_eval) {
-  constexpr uint32_t NTH = Q * (Q + 1) / 2;
-  if (lane < NTH + (uint32_t)__popc(keep)) {
-    double v = x[lane];
-    if (lane < NTH) {
-      if (glmm_is_diag<Q>(lane)) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
-      else v = v < -GLMM_THETA_MAX ? -GLMM_THETA_MAX : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
-    } else {
-      v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
-    }
-    x[lane] = v;
-  }
-  gq_sync();
-  ++n_eval;
-  return glmm_eval<P, Q>(prm, m, x, lane, n, ncl, n_pad, keep);
-}
-
-// one Nelder-Mead run from simplex row 0 with initial edge `step`; the best point ends in row 0
-template <int P, int Q>
-__device__ __noinline__ double glmm_nelder_mead(const SimParams& prm, const GlmmLds m, double step, double ftol, double xtol,
-                                                uint32_t lane, uint32_t n, uint32_t ncl, uint32_t n_pad, uint32_t keep,
-                                                uint32_t& n_eval) {
-  const uint32_t d = (uint32_t)(Q * (Q + 1) / 2) + (uint32_t)__popc(keep);
-  gdd* sx = m.simplex;  // vertices 0..d, then centroid, xr, xe
-  gdd* fv = m.fv;
-  gdd* cen = sx + (size_t)(d + 1u) * GLMM_ROW;
-  gdd* xr = cen + GLMM_ROW;
-  gdd* xe = xr + GLMM_ROW;
-  const double inf = __builtin_inf();
-  const double f0 = glmm_f<P, Q>(prm, m, sx, lane, n, ncl, n_pad, keep, n_eval);
-  if (lane == 0u) fv[0] = f0;
-  for (uint32_t i = 0; i < d; ++i) {
-    gdd* v = sx + (size_t)(i + 1u) * GLMM_ROW;
-    if (lane < d) v[lane] = sx[lane] + (lane == i ? step : 0.0);
-    gq_sync();
-    const double fi = glmm_f<P, Q>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
-    if (lane == 0u) fv[i + 1u] = fi;
-  }
-  gq_sync();
-  while (n_eval < GLMM_MAX_EVAL) {
-    uint32_t lo = 0, hi = 0;
-    for (uint32_t i = 1; i <= d; ++i) {
-      if (fv[i] < fv[lo]) lo = i;
-      if (fv[i] > fv[hi]) hi = i;
-    }
-    uint32_t nh = lo;
-    for (uint32_t i = 0; i <= d; ++i)
-      if (i != hi && fv[i] > fv[nh]) nh = i;
-    double size = 0.0;
-    for (uint32_t i = 0; i <= d; ++i)
-      for (uint32_t k = 0; k < d; ++k) {
-        const double dd = __builtin_fabs(sx[(size_t)i * GLMM_ROW + k] - sx[(size_t)lo * GLMM_ROW + k]);
-        size = dd > size ? dd : size;
-      }
-    if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
-    const double flo = fv[lo], fhi = fv[hi], fnh = fv[nh];
-    gq_sync();
-    if (lane < d) {
-      double s = 0.0;
-      for (uint32_t i = 0; i <= d; ++i)
-        if (i != hi) s += sx[(size_t)i * GLMM_ROW + lane];
-      const double c = s / (double)d;
-      cen[lane] = c;
-      xr[lane] = c + (c - sx[(size_t)hi * GLMM_ROW + lane]);
-    }
-    gq_sync();
-    const double fr = glmm_f<P, Q>(prm, m, xr, lane, n, ncl, n_pad, keep, n_eval);
-    gdd* worst = sx + (size_t)hi * GLMM_ROW;
-    if (fr < flo) {
-      if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
-      gq_sync();
-      const double fe = glmm_f<P, Q>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
-      if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
-      if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
-    } else if (fr < fnh) {
-      if (lane < d) worst[lane] = xr[lane];
-      if (lane == 0u) fv[hi] = fr;
-    } else {
-      const bool outside = fr < fhi;
-      if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
-      gq_sync();
-      const double fc = glmm_f<P, Q>(prm, m, xe, lane, n, ncl, n_pad, keep, n_eval);
-      if (fc < (outside ? fr : fhi)) {
-        if (lane < d) worst[lane] = xe[lane];
-        if (lane == 0u) fv[hi] = fc;
-      } else {
-        for (uint32_t i = 0; i <= d; ++i) {
-          if (i == lo) continue;
-          gdd* v = sx + (size_t)i * GLMM_ROW;
-          if (lane < d) v[lane] = sx[(size_t)lo * GLMM_ROW + lane] + 0.5 * (v[lane] - sx[(size_t)lo * GLMM_ROW + lane]);
-          gq_sync();
-          const double fi = glmm_f<P, Q>(prm, m, v, lane, n, ncl, n_pad, keep, n_eval);
-          if (lane == 0u) fv[i] = fi;
-          gq_sync();
-        }
-      }
-    }
-    gq_sync();
-  }
-  uint32_t lo = 0;
-  for (uint32_t i = 1; i <= d; ++i)
-    if (fv[i] < fv[lo]) lo = i;
-  const double best = fv[lo];
-  gq_sync();
-  double best_k = 0.0;
-  if (lane < d) best_k = sx[(size_t)lo * GLMM_ROW + lane];
-  gq_sync();
-  if (lane < d) sx[lane] = best_k;
-  gq_sync();
-  return best;
-}
-
 // SCEN: general data path (scenario design records, non-normal marginals, per-study effects) plus the LME knobs --
 // random-effect shape and per-replicate tau^2 (data_gen.rs:146-161, 1069-1076)
-#include "mcp_glmm_hessian.hpp"
-#include "mcp_stationary.hpp"
+#include "mcp_stationary.hpp"  // MCP_STAT_H / MCP_STAT_TOL
+#include "mcp_fit_fsm.hpp"
+#include "mcp_glmm_tail.hpp"
 
 template <int P, int Q, bool SCEN>
 __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const SimParams* __restrict__ pp) {
@@ -394,7 +281,7 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
   const uint32_t lane = threadIdx.x;
   const uint32_t lsim = blockIdx.x;
   const uint64_t sim_id = prm.sim_begin + lsim;
-  const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
+  const uint64_t key = replicate_key(prm, sim_id);
   const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
   const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
   const uint32_t ncl_max = prm.n_clusters_max, ncl_pad = (ncl_max + 1u) & ~1u;
@@ -542,9 +429,7 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
   }
 
   bool has_prev = false;
-  double carry[NTH];
-#pragma unroll
-  for (uint32_t k = 0; k < NTH; ++k) carry[k] = 0.0;
+  gdd* carry = m.tail + GT_SPARE + 1;  // theta-hat of the last converged grid point (NTH <= 6 of the 7 spare doubles)
   const uint32_t nt = prm.n_tests;
   // fitted columns: all of them, or the test_formula subset (no factor exclusion on clustered specs, batch.rs:1583)
   const uint32_t keep = prm.glmm_keep;
@@ -564,75 +449,50 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
         if ((keep >> c) & 1u) x0[k++] = prm.beta[c];                      // beta starts at the truth, unconditionally
     }
     gq_sync();
-    uint32_t n_eval = 0;
-    double best = glmm_nelder_mead<P, Q>(prm, m, 0.25, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
-    // restarts only for a point the stationarity check rejects (mcp_stationary.hpp)
+    // ---- the fit: one wave-uniform state machine around the single inlined evaluation (mcp_fit_fsm.hpp) ----
+    const uint32_t d_fit = NTH + (uint32_t)__popc(keep);
     uint32_t lower0 = 0u;
 #pragma unroll
     for (uint32_t k = 0; k < NTH; ++k) lower0 |= glmm_is_diag<Q>(k) ? (1u << k) : 0u;
-    auto fprobe = [&](gdd* pt) -> double { return glmm_f<P, Q>(prm, m, pt, lane, n, ncl, n_pad, keep, n_eval); };
-    const bool stationary = mixed_stationary(fprobe, m.simplex, (uint32_t)GLMM_ROW, NTH + (uint32_t)__popc(keep), lower0, best, lane);
-    for (int restart = 0; !stationary && restart < 4 && n_eval < GLMM_MAX_EVAL; ++restart) {
-      const double prev = best;
-      best = glmm_nelder_mead<P, Q>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n, ncl, n_pad, keep, n_eval);
-      if (!(prev - best > 1e-8)) break;
-    }
-    double cur = glmm_f<P, Q>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
-    for (uint32_t k = 0; k < NTH; ++k) {
-      if (!glmm_is_diag<Q>(k)) continue;
-      const double th_keep = x0[k];
-      if (th_keep != 0.0 && th_keep <= 1e-4) {  // snap onto the boundary when that costs no deviance
-        gq_sync();
-        if (lane == 0u) x0[k] = 0.0;
-        gq_sync();
-        const double f0 = glmm_f<P, Q>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);
-        if (f0 <= cur + 1e-8) cur = f0;
-        else {
-          gq_sync();
-          if (lane == 0u) x0[k] = th_keep;
-          gq_sync();
-        }
-      }
-    }
-    cur = glmm_f<P, Q>(prm, m, x0, lane, n, ncl, n_pad, keep, n_eval);  // modes and weight sums of the final point
+    bool ok = false;
     double th[NTH];
 #pragma unroll
-    for (uint32_t k = 0; k < NTH; ++k) th[k] = x0[k];
-    double T[Q][Q];
-    {
-      int k = 0;
-#pragma unroll
-      for (int c = 0; c < Q; ++c)
-#pragma unroll
-        for (int r = 0; r < Q; ++r) {
-          T[r][c] = r >= c ? th[k] : 0.0;
-          k += r >= c ? 1 : 0;
+    for (uint32_t k = 0; k < NTH; ++k) th[k] = 0.0;
+    auto eval_pt = [&](gdd* x) -> double {  // clamp the point onto the bounds, then the Laplace deviance
+      if (lane < d_fit) {
+        double v = x[lane];
+        if (lane < NTH) {
+          if (glmm_is_diag<Q>(lane)) v = v < 0.0 ? 0.0 : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+          else v = v < -GLMM_THETA_MAX ? -GLMM_THETA_MAX : (v > GLMM_THETA_MAX ? GLMM_THETA_MAX : v);
+        } else {
+          v = v < -50.0 ? -50.0 : (v > 50.0 ? 50.0 : v);
         }
-    }
-    bool ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
-    // ---- RX'RX = X'WX - sum_c C_c' M_c^-1 C_c, C_c = A_c'W X_c (Q x P), M_c = Lm Lm': lane = cluster, wave sums ----
-    double A[P * (P + 1) / 2];
-#pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = 0.0;
-    for (uint32_t c = lane; c < ncl; c += QW) {
-      const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
-      const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
-      const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
-      double C[Q][P], loc[P * (P + 1) / 2], uc[Q];
-#pragma unroll
-      for (int b = 0; b < Q; ++b) {
-        uc[b] = m.ucl[(size_t)c * Q + b];
-#pragma unroll
-        for (int i = 0; i < P; ++i) C[b][i] = 0.0;
+        x[lane] = v;
       }
+      gq_sync();
+      return glmm_eval<P, Q>(prm, m, x, lane, n, ncl, n_pad, keep);
+    };
+    auto on_final = [&](double cur, uint32_t n_eval) -> uint32_t {
 #pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) loc[i] = 0.0;
-      for (uint32_t i = first; i < last; i += step) {
-        double xd[P];
-        xd[0] = 1.0;
+      for (uint32_t k = 0; k < NTH; ++k) th[k] = x0[k];
+      double T[Q][Q];
+      {
+        int k = 0;
 #pragma unroll
-        for (int r = 1; r < P; ++r) xd[r] = (double)m.design[(size_t)(r - 1) * n_pad + i];
-        double z[Q], a[Q], au = 0.0;
+        for (int c = 0; c < Q; ++c)
+#pragma unroll
+          for (int r = 0; r < Q; ++r) {
+            T[r][c] = r >= c ? th[k] : 0.0;
+            k += r >= c ? 1 : 0;
+          }
+      }
+      ok = cur < __builtin_inf() && n_eval < GLMM_MAX_EVAL;
+      // ---- RX'RX = X'WX - sum_c C_c' M_c^-1 C_c, C_c = A_c'W X_c (Q x P), M_c = Lm Lm', at the optimum, in LDS
+      //      (mcp_glmm_tail.hpp): lane = row leaves the IRLS weight at the final modes in eta0's slot (every evaluation
+      //      rebuilds eta0); lane = entry (r, s) of the lower triangle then sums, cluster by cluster and rows ascending,
+      //      its product and the two columns r, s of C_c, solves them against the cluster's factor and subtracts ----
+      auto a_of_row = [&](uint32_t i, double (&a)[Q]) {
+        double z[Q];
         z[0] = 1.0;
 #pragma unroll
         for (int dd = 1; dd < Q; ++dd) z[dd] = (double)m.design[(size_t)(prm.lmg_cols[0][dd - 1] - 1u) * n_pad + i];
@@ -643,120 +503,86 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
           for (int dd = 0; dd < Q; ++dd)
             if (dd >= b) sacc += T[dd][b] * z[dd];
           a[b] = sacc;
-          au += sacc * uc[b];
         }
+      };
+      for (uint32_t i = lane; i < n; i += QW) {
+        const uint32_t cid = prm.cluster_fixed_clusters ? i % cv : i / cv;
+        double a[Q], au = 0.0;
+        a_of_row(i, a);
+#pragma unroll
+        for (int b = 0; b < Q; ++b) au += a[b] * m.ucl[(size_t)cid * Q + b];
         double w, wz, dv;
         fam_eval(prm.glm_family, m.eta0[i] + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
-        int idx = 0;
+        m.eta0[i] = w;
+      }
+      gq_sync();
+      if (lane < (uint32_t)(P * (P + 1) / 2)) {
+        uint32_t r = 0;
+        while ((r + 1u) * (r + 2u) / 2u <= lane) ++r;
+        const uint32_t s = lane - r * (r + 1u) / 2u;
+        double acc = 0.0;
+        for (uint32_t c = 0; c < ncl; ++c) {
+          const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
+          const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
+          const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
+          double loc = 0.0, cr[Q], cs[Q];
 #pragma unroll
-        for (int r = 0; r < P; ++r) {
+          for (int b = 0; b < Q; ++b) cr[b] = cs[b] = 0.0;
+          for (uint32_t i = first; i < last; i += step) {
+            const double w = m.eta0[i];
+            const double xr = r == 0u ? 1.0 : (double)m.design[(size_t)(r - 1u) * n_pad + i];
+            const double xs = s == 0u ? 1.0 : (double)m.design[(size_t)(s - 1u) * n_pad + i];
+            double a[Q];
+            a_of_row(i, a);
 #pragma unroll
-          for (int b = 0; b < Q; ++b) C[b][r] += w * a[b] * xd[r];
+            for (int b = 0; b < Q; ++b) {
+              cr[b] += w * a[b] * xr;
+              cs[b] += w * a[b] * xs;
+            }
+            loc += w * xr * xs;
+          }
+          double v = 0.0;  // D = Lm^-1 C, columns r and s
 #pragma unroll
-          for (int s2 = 0; s2 <= r; ++s2) loc[idx++] += w * xd[r] * xd[s2];
+          for (int b = 0; b < Q; ++b) {
+            double vr = cr[b], vs = cs[b];
+#pragma unroll
+            for (int k2 = 0; k2 < Q; ++k2)
+              if (k2 < b) {
+                const double l = m.lmcl[((size_t)c * Q + b) * Q + k2];
+                vr -= l * cr[k2];
+                vs -= l * cs[k2];
+              }
+            const double lbb = m.lmcl[((size_t)c * Q + b) * Q + b];
+            cr[b] = vr / lbb;
+            cs[b] = vs / lbb;
+            v += cr[b] * cs[b];
+          }
+          acc += loc - v;
+        }
+        m.tail[GT_LX + r * 8u + s] = acc;
+      }
+      if (lane == 0u) {  // fitted coefficients in column order; a column outside a test_formula subset has coefficient 0
+        uint32_t k = NTH;
+        for (uint32_t c = 0; c < (uint32_t)P; ++c) {
+          const bool kept = (keep >> c) & 1u;
+          m.tail[GT_BETA + c] = kept ? x0[k] : 0.0;
+          k += kept ? 1u : 0u;
         }
       }
-      double Lm[Q][Q];
-#pragma unroll
-      for (int b = 0; b < Q; ++b)
-#pragma unroll
-        for (int dd = 0; dd < Q; ++dd) Lm[b][dd] = m.lmcl[((size_t)c * Q + b) * Q + dd];
-#pragma unroll
-      for (int r = 0; r < P; ++r) {  // D = Lm^-1 C, column r
-        double t[Q];
-#pragma unroll
-        for (int b = 0; b < Q; ++b) {
-          double v = C[b][r];
-#pragma unroll
-          for (int k2 = 0; k2 < Q; ++k2)
-            if (k2 < b) v -= Lm[b][k2] * t[k2];
-          t[b] = v / Lm[b][b];
-        }
-#pragma unroll
-        for (int b = 0; b < Q; ++b) C[b][r] = t[b];
-      }
-      int idx = 0;
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) {
-          double v = 0.0;
-#pragma unroll
-          for (int b = 0; b < Q; ++b) v += C[b][r] * C[b][s2];
-          A[idx] += loc[idx] - v;
-          ++idx;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]);
-    double Lx[P][P];
-    // lower Cholesky factor of a packed precision matrix over the kept columns; a dropped column is an identity row /
-    // column: the kept block factors as the gathered system
-    auto factor = [&](const double (&Ap)[P * (P + 1) / 2], double (&L)[P][P]) -> bool {
-      bool fok = true;
-      int idx = 0;
-      double Af[P][P];
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-#pragma unroll
-        for (int s = 0; s <= r; ++s) {
-          const double v = Ap[idx++];
-          Af[r][s] = (((keep >> r) & 1u) && ((keep >> s) & 1u)) ? v : (r == s ? 1.0 : 0.0);
-        }
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        double dd = Af[j][j];
-#pragma unroll
-        for (int t = 0; t < j; ++t) dd -= L[j][t] * L[j][t];
-        fok = fok && (dd > 0.0) && (dd < __builtin_inf());
-        L[j][j] = __builtin_sqrt(dd);
-#pragma unroll
-        for (int i = j + 1; i < P; ++i) {
-          double v = Af[i][j];
-#pragma unroll
-          for (int t = 0; t < j; ++t) v -= L[i][t] * L[j][t];
-          L[i][j] = v / L[j][j];
-        }
-      }
-      return fok;
-    };
-    ok = factor(A, Lx) && ok;
-    if (prm.glmm_hessian && ok) {
-      // Wald SE mode "hessian" (mcp_glmm_hessian.hpp) over the FREE covariance parameters and beta: a pinned diagonal is
-      // an even point of the deviance and drops out, the coupling with the other parameters (what "rx" ignores) stays;
-      // a block that does not factor keeps "rx"
+      gq_sync();
+      if (lane == 0u) m.tail[GT_SPARE] = glmm_tail_factor(m.tail + GT_LX, m.tail + GT_LX, (uint32_t)P, keep) ? 1.0 : 0.0;
+      gq_sync();
+      ok = (m.tail[GT_SPARE] != 0.0) && ok;
+      // Wald SE mode "hessian" (mcp_fit_fsm.hpp) over the FREE covariance parameters and beta: a pinned diagonal is an even
+      // point of the deviance and drops out, the coupling with the other parameters (what "rx" ignores) stays; a block
+      // that does not factor keeps "rx"
       uint32_t th_free = 0u;
 #pragma unroll
       for (uint32_t k = 0; k < NTH; ++k) th_free |= (glmm_is_diag<Q>(k) && th[k] < GLMM_THETA_ZERO) ? 0u : (1u << k);
-      auto fdev = [&](gdd* pt) -> double {
-        uint32_t scratch = 0;
-        return glmm_f<P, Q>(prm, m, pt, lane, n, ncl, n_pad, keep, scratch);
-      };
-      const uint32_t nth_h = NTH, d_h = nth_h + (uint32_t)__popc(keep);
-      if (glmm_fd_hessian_schur(fdev, m.simplex, (uint32_t)GLMM_ROW, nth_h, d_h, cur, lane, th_free)) {
-        double Ah[P * (P + 1) / 2], Lh[P][P];
-        const gdd* Hs = m.simplex + GLMM_ROW;
-        int idx = 0;
-        uint32_t kr = 0;
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-          uint32_t kc = 0;
-#pragma unroll
-          for (int s = 0; s <= r; ++s) {
-            const bool both = ((keep >> r) & 1u) && ((keep >> s) & 1u);
-            Ah[idx++] = both ? Hs[(size_t)(nth_h + kr) * GLMM_ROW + nth_h + kc] : 0.0;
-            kc += ((keep >> s) & 1u) ? 1u : 0u;
-          }
-          kr += ((keep >> r) & 1u) ? 1u : 0u;
-        }
-        if (factor(Ah, Lh)) {
-#pragma unroll
-          for (int r = 0; r < P; ++r)
-#pragma unroll
-            for (int s = 0; s <= r; ++s) Lx[r][s] = Lh[r][s];
-        }
-      }
-    }
+      return (prm.glmm_hessian && ok) ? (FIT_FSM_HESSIAN | th_free) : 0u;
+    };
+    const FitFsmOut fit = simplex_fit_fsm(m.simplex, m.fv, d_fit, (uint32_t)GLMM_ROW, lower0, NTH, GLMM_MAX_EVAL, lane, eval_pt, on_final);
+    if (fit.hess_ok && lane == 0u) glmm_tail_take_hessian(m.tail, m.simplex + GLMM_ROW, (uint32_t)GLMM_ROW, NTH, (uint32_t)P, keep);
     bool conv = ok;
     bool at_upper = false;
     uint32_t pinned = 0u;
@@ -773,113 +599,16 @@ __global__ __launch_bounds__(QW, MCP_GLMM_WAVES) void glmm_slopes_kernel(const S
     const uint32_t bh = !conv ? 0u : (at_upper ? 2u : (pinned ? 1u : 0u));
     if (at_upper) conv = false;
     if (conv) {
+      if (lane == 0u) {
 #pragma unroll
-      for (uint32_t k = 0; k < NTH; ++k) carry[k] = th[k];
+        for (uint32_t k = 0; k < NTH; ++k) carry[k] = th[k];
+      }
       has_prev = true;
     }
-    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions ----
-    double beta[P];
-    {
-      uint32_t k = NTH;
-#pragma unroll
-      for (int c = 0; c < P; ++c) {
-        const bool kept = (keep >> c) & 1u;
-        beta[c] = kept ? x0[k] : 0.0;
-        k += kept ? 1u : 0u;
-      }
-    }
-    const double* crow = prm.crit + (size_t)g * prm.crit_stride;
-    double tsq[MAX_T_WAVE];
-    double U[MAX_T_WAVE][P];
-#pragma unroll
-    for (int t = 0; t < MAX_T_WAVE; ++t) {
-      tsq[t] = __builtin_nan("");
-#pragma unroll
-      for (int i = 0; i < P; ++i) U[t][i] = 0.0;
-      if ((uint32_t)t < nt && conv) {
-        const double* c = prm.contrast + t * MAX_P;
-        double est = 0.0, nq = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          est = __builtin_fma(c[i], beta[i], est);
-          double acc = c[i];
-#pragma unroll
-          for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i][q], U[t][q], acc);
-          U[t][i] = acc / Lx[i][i];
-          nq = __builtin_fma(U[t][i], U[t][i], nq);
-        }
-        if (nq > GLMM_NEAR_ZERO && nq < __builtin_inf()) tsq[t] = est * est / nq;
-      }
-    }
-    bool joint_sig = false;
-    if (conv && nt != 0u) {
-      double Lc[MAX_T_WAVE][MAX_T_WAVE], cj[MAX_T_WAVE];
-      bool jok = true;
-      double qsum = 0.0;
-#pragma unroll
-      for (int j = 0; j < MAX_T_WAVE; ++j) {
-        if ((uint32_t)j < nt) {
-          double dd = 0.0;
-#pragma unroll
-          for (int i = 0; i < P; ++i) dd = __builtin_fma(U[j][i], U[j][i], dd);
-#pragma unroll
-          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j][t], Lc[j][t], dd);
-          jok = jok && (dd > 0.0);
-          Lc[j][j] = __builtin_sqrt(dd);
-#pragma unroll
-          for (int i2 = j + 1; i2 < MAX_T_WAVE; ++i2) {
-            if ((uint32_t)i2 < nt) {
-              double vv = 0.0;
-#pragma unroll
-              for (int i = 0; i < P; ++i) vv = __builtin_fma(U[i2][i], U[j][i], vv);
-#pragma unroll
-              for (int t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2][t], Lc[j][t], vv);
-              Lc[i2][j] = vv / Lc[j][j];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MAX_T_WAVE; ++i) {
-        if ((uint32_t)i < nt) {
-          const double* c = prm.contrast + i * MAX_P;
-          double vv = 0.0;
-#pragma unroll
-          for (int q = 0; q < P; ++q) vv = __builtin_fma(c[q], beta[q], vv);
-#pragma unroll
-          for (int t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i][t], cj[t], vv);
-          cj[i] = vv / Lc[i][i];
-          qsum = __builtin_fma(cj[i], cj[i], qsum);
-        }
-      }
-      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > prm.joint_crit_k[nt]);
-    }
-    uint32_t unc_bits = 0, cor_bits = 0;
-    decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
-    if (!conv) {
-      unc_bits = 0;
-      cor_bits = 0;
-    }
-    if (lane == 0u) {
-      const size_t cell = (size_t)(prm.out_base + lsim) * prm.n_grid + g;
-#pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t)
-        if ((uint32_t)t < nt) {
-          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
-          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
-        }
-      prm.conv[cell] = conv ? 1 : 0;
-      prm.boundary[cell] = (uint8_t)bh;
-      prm.joint[cell] = joint_sig ? 1 : 0;
-      if (prm.pinned) prm.pinned[cell] = (uint16_t)pinned;
-      if (prm.tau_hat) prm.tau_hat[cell] = conv ? th[0] * th[0] : __builtin_nan("");
-      if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1750-1753
-      if (prm.stat && g == 0u) {
-#pragma unroll
-        for (int t = 0; t < MAX_T_WAVE; ++t)
-          if ((uint32_t)t < nt) prm.stat[(size_t)(prm.out_base + lsim) * nt + t] = tsq[t];
-      }
-    }
+    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions: one lane, in LDS ----
+    if (lane == 0u)
+      glmm_tail_decide(prm, m.tail, (uint32_t)P, nt, conv, bh, pinned, th[0] * th[0], prm.crit + (size_t)g * prm.crit_stride,
+                       (size_t)(prm.out_base + lsim) * prm.n_grid + g, (size_t)(prm.out_base + lsim), g == 0u);
     gq_sync();
   }
 }

@@ -360,6 +360,11 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   // pool the counters over the ranks of this process's communicator (merge.rs:26-70): checked before anything is
   // enqueued, so a rank without a communicator fails here and not inside the collective
   const bool pool = flags & MCP_ALLREDUCE_COUNTERS;
+  if ((flags & MCP_SEED_PER_REPLICATE) && !(spec->estimator == MCP_EST_GLM && spec->cluster.present))
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: MCP_SEED_PER_REPLICATE outside the clustered GLM (it is the validation aid of oracle2_power.R's per-draw leg)");
+  if ((flags & MCP_SEED_PER_REPLICATE) && prm.scen_active)  // the scenario / heterogeneity streams key on sim_id as well
+    return fail(MCP_ERR_UNSUPPORTED, "unsupported on the device path: MCP_SEED_PER_REPLICATE with scenario perturbations");
+  prm.seed_per_replicate = (flags & MCP_SEED_PER_REPLICATE) ? 1u : 0u;
   if (pool && !mcp::comm_active())
     return fail(MCP_ERR_INVALID_SPEC, "invalid spec: MCP_ALLREDUCE_COUNTERS without a communicator (call mcp_comm_init first)");
   if (pool && mcp::comm_device() != g_device)

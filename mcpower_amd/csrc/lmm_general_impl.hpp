@@ -97,7 +97,7 @@ __device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* t
 // one evaluation of the profiled REML criterion at theta `th` (LDS, n_theta doubles).  Returns the deviance (inf
 // when a pivot fails); leaves sigma^2 in misc[0], beta in tail[0..p), the lower factor of RX'RX in tail[8 + a*8 + b].
 template <int Q0>
-__device__ __noinline__ double lmg_eval(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows) {
+__device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows) {
   const uint32_t W = prm.lmg_W, R = prm.lmg_R, p = prm.P, L0 = prm.lmg_levels[0];
   const double inf = __builtin_inf();
   lmg_templates(prm, th, m.tm, lane);
@@ -332,7 +332,7 @@ __device__ __forceinline__ uint32_t lmg_red_col(const SimParams& prm, uint32_t i
 }
 
 template <int Q0F>
-__device__ __noinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows,
+__device__ __forceinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows,
                                             const LmgRed red) {
   const uint32_t Wf = prm.lmg_W, p = prm.P, L0 = prm.lmg_levels[0], nterms = prm.lmg_n_terms;
   uint32_t Rr = 0;
@@ -469,115 +469,15 @@ __device__ __forceinline__ void lmg_clamp(const SimParams& prm, ldd* x, uint32_t
   lmg_sync();
 }
 
-template <int Q0, bool RED>
-__device__ __forceinline__ double lmg_f(const SimParams& prm, const LmgLds& m, ldd* x, uint32_t lane, double n_rows,
-                                        const LmgRed& red, uint32_t& n_eval) {
-  lmg_clamp<RED>(prm, x, lane);
-  ++n_eval;
-  if (RED) return lmg_eval_red<Q0>(prm, m, x, lane, n_rows, red);
-  return lmg_eval<Q0>(prm, m, x, lane, n_rows);
-}
-
-// one Nelder-Mead run from x0 (simplex row 0) with initial edge `step`; the best point ends in row 0
-template <int Q0, bool RED>
-__device__ __noinline__ double lmg_nelder_mead(const SimParams& prm, const LmgLds m, double step, double ftol, double xtol,
-                                               uint32_t lane, double n_rows, const LmgRed red, uint32_t& n_eval) {
-  const uint32_t d = RED ? prm.lmg_n_terms : prm.lmg_n_theta;
-  ldd* sx = m.simplex;            // (d + 4) rows of LMG_MAX_THETA: vertices 0..d, then centroid, xr, xe
-  ldd* fv = m.fv;
-  ldd* cen = sx + (size_t)(d + 1u) * LMG_MAX_THETA;
-  ldd* xr = cen + LMG_MAX_THETA;
-  ldd* xe = xr + LMG_MAX_THETA;
-  const double inf = __builtin_inf();
-  double f0 = lmg_f<Q0, RED>(prm, m, sx, lane, n_rows, red, n_eval);
-  if (lane == 0u) fv[0] = f0;
-  for (uint32_t i = 0; i < d; ++i) {
-    ldd* v = sx + (size_t)(i + 1u) * LMG_MAX_THETA;
-    if (lane < d) v[lane] = sx[lane] + (lane == i ? ((RED || lmg_is_diag(prm, i) || sx[i] >= 0.0) ? step : -step) : 0.0);
-    lmg_sync();
-    const double fi = lmg_f<Q0, RED>(prm, m, v, lane, n_rows, red, n_eval);
-    if (lane == 0u) fv[i + 1u] = fi;
-  }
-  lmg_sync();
-  while (n_eval < LMG_MAX_EVAL) {
-    uint32_t lo = 0, hi = 0;
-    for (uint32_t i = 1; i <= d; ++i) {
-      if (fv[i] < fv[lo]) lo = i;
-      if (fv[i] > fv[hi]) hi = i;
-    }
-    uint32_t nh = lo;
-    for (uint32_t i = 0; i <= d; ++i)
-      if (i != hi && fv[i] > fv[nh]) nh = i;
-    double size = 0.0;
-    for (uint32_t i = 0; i <= d; ++i)
-      for (uint32_t k = 0; k < d; ++k) {
-        const double dd = __builtin_fabs(sx[(size_t)i * LMG_MAX_THETA + k] - sx[(size_t)lo * LMG_MAX_THETA + k]);
-        size = dd > size ? dd : size;
-      }
-    if (fv[hi] < inf && fv[hi] - fv[lo] <= ftol && size <= xtol) break;
-    const double flo = fv[lo], fhi = fv[hi], fnh = fv[nh];
-    lmg_sync();
-    if (lane < d) {
-      double s = 0.0;
-      for (uint32_t i = 0; i <= d; ++i)
-        if (i != hi) s += sx[(size_t)i * LMG_MAX_THETA + lane];
-      const double c = s / (double)d;
-      cen[lane] = c;
-      xr[lane] = c + (c - sx[(size_t)hi * LMG_MAX_THETA + lane]);
-    }
-    lmg_sync();
-    const double fr = lmg_f<Q0, RED>(prm, m, xr, lane, n_rows, red, n_eval);
-    ldd* worst = sx + (size_t)hi * LMG_MAX_THETA;
-    if (fr < flo) {
-      if (lane < d) xe[lane] = cen[lane] + 2.0 * (xr[lane] - cen[lane]);
-      lmg_sync();
-      const double fe = lmg_f<Q0, RED>(prm, m, xe, lane, n_rows, red, n_eval);
-      if (lane < d) worst[lane] = fe < fr ? xe[lane] : xr[lane];
-      if (lane == 0u) fv[hi] = fe < fr ? fe : fr;
-    } else if (fr < fnh) {
-      if (lane < d) worst[lane] = xr[lane];
-      if (lane == 0u) fv[hi] = fr;
-    } else {
-      const bool outside = fr < fhi;
-      if (lane < d) xe[lane] = cen[lane] + 0.5 * ((outside ? xr[lane] : worst[lane]) - cen[lane]);
-      lmg_sync();
-      const double fc = lmg_f<Q0, RED>(prm, m, xe, lane, n_rows, red, n_eval);
-      if (fc < (outside ? fr : fhi)) {
-        if (lane < d) worst[lane] = xe[lane];
-        if (lane == 0u) fv[hi] = fc;
-      } else {
-        for (uint32_t i = 0; i <= d; ++i) {
-          if (i == lo) continue;
-          ldd* v = sx + (size_t)i * LMG_MAX_THETA;
-          if (lane < d) v[lane] = sx[(size_t)lo * LMG_MAX_THETA + lane] + 0.5 * (v[lane] - sx[(size_t)lo * LMG_MAX_THETA + lane]);
-          lmg_sync();
-          const double fi = lmg_f<Q0, RED>(prm, m, v, lane, n_rows, red, n_eval);
-          if (lane == 0u) fv[i] = fi;
-          lmg_sync();
-        }
-      }
-    }
-    lmg_sync();
-  }
-  uint32_t lo = 0;
-  for (uint32_t i = 1; i <= d; ++i)
-    if (fv[i] < fv[lo]) lo = i;
-  const double best = fv[lo];
-  lmg_sync();
-  double keep = 0.0;
-  if (lane < d) keep = sx[(size_t)lo * LMG_MAX_THETA + lane];
-  lmg_sync();
-  if (lane < d) sx[lane] = keep;
-  lmg_sync();
-  return best;
-}
-
-#include "mcp_stationary.hpp"
+#include "mcp_stationary.hpp"  // MCP_STAT_H / MCP_STAT_TOL
+#include "mcp_fit_fsm.hpp"
 
 // SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
 // heteroskedastic residuals) plus the LME knobs -- random-effect shape, one ICC jitter per grouping
 template <int P, int Q0, bool SCEN>
-__global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const SimParams* __restrict__ pp) {
+// (three random effects on the primary grouping -- and the general-path variants with a slope and four or more columns, 12 B over --
+// get 256 registers instead of 168, or the block algebra spills; those designs are LDS-bound below 3 waves per SIMD anyway)
+__global__ __launch_bounds__(GW, ((Q0 >= 3 || (SCEN && P >= 4 && Q0 == 2)) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
@@ -632,35 +532,45 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
     }
     return prm.lmg_tau[t];
   };
-  auto term_chol = [&](uint32_t t, double tau0, double (&l)[9]) {
+  // lower factor of D_t = diag(tau) R diag(tau) (row-major q x q) into LDS: lane 0 writes l = lc[0..9) (dm = lc[9..18) is its
+  // work area), every lane reads it after the barrier.  Kept out of private arrays: indexed at run time they became
+  // 72-208 B of scratch per lane.  lc = m.rval .. m.carry: free until the rows are folded / the first fit has converged.
+  ldd* lc = m.rval;
+  auto term_chol = [&](uint32_t t, double tau0) {
     const uint32_t q = prm.lmg_q[t];
-    if (!SCEN) {
-      for (uint32_t i = 0; i < 9u; ++i) l[i] = prm.lmg_chol[t][i];
-      return;
-    }
-    double tv[3] = {tau0, prm.lmg_slope_sd[t][0], prm.lmg_slope_sd[t][1]}, dm[9];
-    for (uint32_t i = 0; i < 9u; ++i) l[i] = 0.0;
-    for (uint32_t i = 0; i < q; ++i)
-      for (uint32_t j = 0; j < q; ++j) dm[i * q + j] = tv[i] * prm.lmg_recorr[t][i * q + j] * tv[j];
-    for (uint32_t j = 0; j < q; ++j) {  // chol_lower (data_gen.rs:55-75)
-      double diag = dm[j * q + j];
-      for (uint32_t k = 0; k < j; ++k) diag -= l[j * q + k] * l[j * q + k];
-      const double ljj = __builtin_sqrt(diag > 0.0 ? diag : 0.0);
-      l[j * q + j] = ljj;
-      for (uint32_t i = j + 1u; i < q; ++i)
-        if (ljj > 0.0) {
-          double sacc = dm[i * q + j];
-          for (uint32_t k = 0; k < j; ++k) sacc -= l[i * q + k] * l[j * q + k];
-          l[i * q + j] = sacc / ljj;
+    lmg_sync();
+    if (lane == 0u) {
+      if (!SCEN) {
+        for (uint32_t i = 0; i < 9u; ++i) lc[i] = prm.lmg_chol[t][i];
+      } else {
+        ldd* dm = lc + 9;
+        for (uint32_t i = 0; i < 9u; ++i) lc[i] = 0.0;
+        for (uint32_t i = 0; i < q; ++i)
+          for (uint32_t j = 0; j < q; ++j) {
+            const double ti = i == 0u ? tau0 : prm.lmg_slope_sd[t][i - 1u], tj = j == 0u ? tau0 : prm.lmg_slope_sd[t][j - 1u];
+            dm[i * q + j] = ti * prm.lmg_recorr[t][i * q + j] * tj;
+          }
+        for (uint32_t j = 0; j < q; ++j) {  // chol_lower (data_gen.rs:55-75)
+          double diag = dm[j * q + j];
+          for (uint32_t k = 0; k < j; ++k) diag -= lc[j * q + k] * lc[j * q + k];
+          const double ljj = __builtin_sqrt(diag > 0.0 ? diag : 0.0);
+          lc[j * q + j] = ljj;
+          for (uint32_t i = j + 1u; i < q; ++i)
+            if (ljj > 0.0) {
+              double sacc = dm[i * q + j];
+              for (uint32_t k = 0; k < j; ++k) sacc -= lc[i * q + k] * lc[j * q + k];
+              lc[i * q + j] = sacc / ljj;
+            }
         }
+      }
     }
+    lmg_sync();
   };
   const double tau_p = term_tau(0u);
   for (uint32_t c = lane; c < L0; c += GW) m.u0[c] = (float)(re_draw(prm.lmg_seq[0] + c) * tau_p);
   lmg_sync();
   if (Q0 > 1) {
-    double l0[9];
-    term_chol(0u, tau_p, l0);
+    term_chol(0u, tau_p);
     for (uint32_t c = lane; c < L0; c += GW) {
       double z[3];
       z[0] = tau_p > 0.0 ? (double)m.u0[c] / tau_p : 0.0;
@@ -671,7 +581,7 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
         double uk = 0.0;
 #pragma unroll
         for (int j = 0; j < Q0; ++j)
-          if (j <= k) uk += l0[k * Q0 + j] * z[j];
+          if (j <= k) uk += lc[k * Q0 + j] * z[j];
         m.us[(size_t)c * (Q0 - 1) + (k - 1)] = (float)uk;
       }
     }
@@ -684,17 +594,14 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
       for (uint32_t c = lane; c < nl; c += GW) ux[(size_t)c * q] = (float)(re_draw(prm.lmg_seq[2u * t] + c) * tau_t);
       lmg_sync();
       if (q > 1u) {
-        double lt[9];
-        term_chol(t, tau_t, lt);
+        term_chol(t, tau_t);
         for (uint32_t c = lane; c < nl; c += GW) {
-          double z[3];
-          z[0] = tau_t > 0.0 ? (double)ux[(size_t)c * q] / tau_t : 0.0;
-          for (uint32_t j = 1; j < q; ++j) z[j] = re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u) + (j - 1u));
-          for (uint32_t k = 1; k < q; ++k) {
-            double uk = 0.0;
-            for (uint32_t j = 0; j <= k; ++j) uk += lt[k * q + j] * z[j];
-            ux[(size_t)c * q + k] = (float)uk;
-          }
+          double z0 = tau_t > 0.0 ? (double)ux[(size_t)c * q] / tau_t : 0.0, z1 = 0.0, z2 = 0.0;
+          z1 = re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u));
+          if (q > 2u) z2 = re_draw(prm.lmg_seq[2u * t + 1u] + c * (q - 1u) + 1u);
+          // u_k = sum_{j <= k} l[k][j] z_j, j ascending
+          ux[(size_t)c * q + 1u] = (float)(0.0 + lc[q] * z0 + lc[q + 1u] * z1);
+          if (q > 2u) ux[(size_t)c * q + 2u] = (float)(0.0 + lc[2u * q] * z0 + lc[2u * q + 1u] * z1 + lc[2u * q + 2u] * z2);
         }
       }
       ux += (size_t)nl * q;
@@ -908,34 +815,18 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
         x0[lane] = v;
       }
       lmg_sync();
-      double best = lmg_nelder_mead<Q0, false>(prm, m, 0.25, 1e-10, 1e-7, lane, n_rows, red, n_eval);
-      // restarts (they guard against a collapsed simplex) only for a point the stationarity check rejects (mcp_stationary.hpp)
+      // the fit: one wave-uniform state machine around the single inlined evaluation (mcp_fit_fsm.hpp)
       uint32_t lower0 = 0u;
       for (uint32_t k = 0; k < d; ++k) lower0 |= lmg_is_diag(prm, k) ? (1u << k) : 0u;
-      auto fprobe = [&](ldd* pt) -> double { return lmg_f<Q0, false>(prm, m, pt, lane, n_rows, red, n_eval); };
-      const bool stationary = mixed_stationary(fprobe, m.simplex, (uint32_t)LMG_MAX_THETA, d, lower0, best, lane);
-      for (int restart = 0; !stationary && restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
-        const double prev = best;
-        best = lmg_nelder_mead<Q0, false>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, red, n_eval);
-        if (!(prev - best > 1e-8)) break;
-      }
-      // snap small diagonals onto the boundary when that costs no deviance
-      double cur = lmg_f<Q0, false>(prm, m, x0, lane, n_rows, red, n_eval);
-      for (uint32_t k = 0; k < d; ++k) {
-        const double kept_v = x0[k];
-        if (!lmg_is_diag(prm, k) || kept_v == 0.0 || kept_v > 1e-4) continue;
-        lmg_sync();
-        if (lane == 0u) x0[k] = 0.0;
-        lmg_sync();
-        const double f0 = lmg_f<Q0, false>(prm, m, x0, lane, n_rows, red, n_eval);
-        if (f0 <= cur + 1e-8) cur = f0;
-        else {
-          lmg_sync();
-          if (lane == 0u) x0[k] = kept_v;
-          lmg_sync();
-        }
-      }
-      const double fin = lmg_f<Q0, false>(prm, m, x0, lane, n_rows, red, n_eval);
+      const FitFsmOut fit = simplex_fit_fsm(
+          m.simplex, m.fv, d, (uint32_t)LMG_MAX_THETA, lower0, d, LMG_MAX_EVAL, lane,
+          [&](ldd* x) -> double {
+            lmg_clamp<false>(prm, x, lane);
+            return lmg_eval<Q0>(prm, m, x, lane, n_rows);
+          },
+          [&](double, uint32_t) -> uint32_t { return 0u; }, true);
+      const double fin = fit.cur;
+      n_eval = fit.n_eval;
       conv = fin < __builtin_inf() && n_eval < LMG_MAX_EVAL;
       uint32_t comp = 0;
       for (uint32_t k = 0; k < d; ++k) {
@@ -953,30 +844,15 @@ __global__ __launch_bounds__(GW, MCP_LMG_WAVES) void lmm_general_kernel(const Si
         x0[lane] = v;
       }
       lmg_sync();
-      double best = lmg_nelder_mead<Q0, true>(prm, m, 0.25, 1e-10, 1e-7, lane, n_rows, red, n_eval);
-      auto fprobe = [&](ldd* pt) -> double { return lmg_f<Q0, true>(prm, m, pt, lane, n_rows, red, n_eval); };
-      const bool stationary = mixed_stationary(fprobe, m.simplex, (uint32_t)LMG_MAX_THETA, nterms, (1u << nterms) - 1u, best, lane);
-      for (int restart = 0; !stationary && restart < 4 && n_eval < LMG_MAX_EVAL; ++restart) {
-        const double prev = best;
-        best = lmg_nelder_mead<Q0, true>(prm, m, restart == 0 ? 0.05 : 0.01, 1e-10, 1e-7, lane, n_rows, red, n_eval);
-        if (!(prev - best > 1e-8)) break;
-      }
-      double cur = lmg_f<Q0, true>(prm, m, x0, lane, n_rows, red, n_eval);
-      for (uint32_t k = 0; k < nterms; ++k) {
-        const double kept_v = x0[k];
-        if (kept_v == 0.0 || kept_v > 1e-4) continue;
-        lmg_sync();
-        if (lane == 0u) x0[k] = 0.0;
-        lmg_sync();
-        const double f0 = lmg_f<Q0, true>(prm, m, x0, lane, n_rows, red, n_eval);
-        if (f0 <= cur + 1e-8) cur = f0;
-        else {
-          lmg_sync();
-          if (lane == 0u) x0[k] = kept_v;
-          lmg_sync();
-        }
-      }
-      const double fin = lmg_f<Q0, true>(prm, m, x0, lane, n_rows, red, n_eval);
+      const FitFsmOut fit = simplex_fit_fsm(
+          m.simplex, m.fv, nterms, (uint32_t)LMG_MAX_THETA, (1u << nterms) - 1u, nterms, LMG_MAX_EVAL, lane,
+          [&](ldd* x) -> double {
+            lmg_clamp<true>(prm, x, lane);
+            return lmg_eval_red<Q0>(prm, m, x, lane, n_rows, red);
+          },
+          [&](double, uint32_t) -> uint32_t { return 0u; }, true);
+      const double fin = fit.cur;
+      n_eval = fit.n_eval;
       conv = fin < __builtin_inf() && n_eval < LMG_MAX_EVAL;
       for (uint32_t k = 0; k < nterms; ++k) {
         if (x0[k] < LMG_THETA_ZERO) pinned |= 1u << k;

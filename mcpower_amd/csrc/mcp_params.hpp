@@ -33,6 +33,8 @@ constexpr uint32_t SCEN_CLASSES = 8192;  // transform class of a replicate: 6 + 
 struct SimParams {
   uint64_t base_seed;
   uint64_t sim_begin;      // sim_id of lane 0 of block 0
+  uint32_t seed_per_replicate;  // MCP_SEED_PER_REPLICATE: every replicate is replicate 0 of its own call seed (replicate_key)
+  uint32_t pad_seed_;
   uint32_t n_sims;         // replicates in this launch
   uint32_t out_base;       // row of the first replicate in the per-sim output tensors
   uint32_t max_n;

@@ -11,6 +11,13 @@
 
 namespace mcp {
 
+// Philox key of a replicate: mix13(call_seed ^ rotl64(sim_id, 32)) (rng.rs:36-37, 61-69).  Under
+// MCP_SEED_PER_REPLICATE (validation aid of the clustered-GLM kernels) replicate i is replicate 0 of the call seed
+// splitmix64(base_seed + i): the reference's per-draw harness (validation/oracle2_power.R:38-66)
+__device__ __forceinline__ uint64_t replicate_key(const SimParams& prm, uint64_t sim_id) {
+  return prm.seed_per_replicate ? pcg_mix64(splitmix64(prm.base_seed + sim_id), 0ull) : pcg_mix64(prm.base_seed, sim_id);
+}
+
 // categorical draw on the sequential stream (rng.rs:112-127)
 __device__ __forceinline__ uint32_t categorical(const SimParams& prm, uint32_t f, uint32_t k0, uint32_t k1, uint64_t q) {
   const double u = (double)u32_to_unit_f32(sequential_word(k0, k1, q));

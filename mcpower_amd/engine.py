@@ -128,7 +128,7 @@ def shard_range(n_sims_total: int, rank: int, world: int):
 def run_batch(spec: "S.SimulationSpec | S.LoweredSpec", sample_sizes: Sequence[int], n_sims: int, base_seed: int,
               sink: Optional[Callable[[int, int], bool]] = None, *, per_sim: bool = True, stat_capture: bool = False,
               staged: bool = False, sim_offset: int = 0, chunk_sims: int = 0, hip_stream: int = 0,
-              allreduce: bool = False) -> S.BatchResult:
+              allreduce: bool = False, seed_per_replicate: bool = False) -> S.BatchResult:
     """`run_batch(spec, sample_sizes, n_sims, base_seed, sink)` (batch.rs:130).
 
     `sink(current, total) -> bool` is `ProgressSink::report` (return False to cancel -> EngineError Cancelled).
@@ -141,7 +141,8 @@ def run_batch(spec: "S.SimulationSpec | S.LoweredSpec", sample_sizes: Sequence[i
     ns = np.ascontiguousarray(sample_sizes, dtype=np.uint32)
     opts = S.CRunOptions()
     opts.flags = (S.WANT_PER_SIM if per_sim else 0) | (S.WANT_STAT_CAPTURE if stat_capture else 0) | (
-        S.PIPELINE_STAGED if staged else 0) | (S.ALLREDUCE_COUNTERS if allreduce else 0)
+        S.PIPELINE_STAGED if staged else 0) | (S.ALLREDUCE_COUNTERS if allreduce else 0) | (
+        S.SEED_PER_REPLICATE if seed_per_replicate else 0)
     opts.chunk_sims = int(chunk_sims)
     opts.sim_offset = int(sim_offset)
     opts.hip_stream = hip_stream or None

@@ -276,6 +276,7 @@ class CRunOptions(C.Structure):
 WANT_PER_SIM = 0x1
 WANT_STAT_CAPTURE = 0x2
 PIPELINE_STAGED = 0x4
+SEED_PER_REPLICATE = 0x10  # validation aid (clustered GLM): replicate i = replicate 0 of call seed splitmix64(base_seed + i)
 ALLREDUCE_COUNTERS = 0x8  # pool the counters over the process's RCCL communicator inside the call
 
 PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p)

@@ -1,18 +1,38 @@
-"""End-to-end pin of the clustered-GLM path against the REFERENCE ENGINE's own numbers.
+"""Pins of the clustered-GLM path against the REFERENCE ENGINE's own numbers (validation/data/oracle2_<cell>.rds ->
+tests/golden/oracle2.json, written by tests/golden/make_fixtures.py).
 
-validation/oracle2_power.R:131-136 froze, for six harsh clustered-logistic cells (validation/oracle_cells.R:24-95),
-what the reference's shipped `find_power(wald_se = "hessian", n_sims = 50 000, seed = cell seed)` returned for the
-alternative model (`power_hessian_fp`) and, with seed + 2 000 000, for the null model (`typeI_hessian_fp`) --
-tests/golden/oracle2.json, written by tests/golden/make_fixtures.py from validation/data/oracle2_<cell>.rds.  The same
-call through `mcpower_amd._engine.find_power` sees the SAME data (identical seeds, bit-exact data plane), so a
-difference can only come from the fit: the Laplace optimiser (bounded Nelder-Mead here, BOBYQA there), the
-finite-difference Hessian, convergence / boundary classification.  Three kernels are exercised: glmm_kernel (random
-intercept: few6_int, hiICC_int, smallclust, boundary), glmm_slopes_kernel (few8_slope) and glmm_general_kernel
-(few10_crossed).  Monte-Carlo noise is not in play (same draws), so the gate is tight: 0.3 percentage points on all six
-type-I rates and on the power of the four cells where the reference's own finite-difference Hessian is clean; see
-HESSIAN_STRAINED for the two cells where it is not.
+validation/oracle2_power.R froze, for six harsh clustered-logistic cells (validation/oracle_cells.R:24-95), two kinds
+of numbers from the reference's shipped engine:
 
-What it took to get here (both found by this test, neither visible device-vs-oracle):
+(1) its PER-DRAW leg (:38-66, :115-129): K = 50 000 datasets per cell and condition, draw k = `create_data()` under
+    `.debug_seed = base + k` (replicate 0 of call seed splitmix64(base + k)), each fitted by `load_data(wald_se = "rx")`
+    and `("hessian")`; frozen: sd(beta-hat) (`sd_true`), the mean SE of either flavour, and the rejection rates
+    `power_rx`, `power_hessian` (alt, base = cell seed), `typeI_rx`, `typeI_hessian` (null, base + 1 000 000).
+    The data plane is bit-exact, so with MCP_SEED_PER_REPLICATE these are SAME-DATA comparisons.  Result (device and
+    CPU oracle alike, tools/oracle2_perdraw.py, profiles/r03_oracle2_perdraw_*.log):
+      * "rx" -- the reference's DEFAULT Wald SE (engine-contract estimator.rs:54-55): rejection rates identical to the
+        last draw on every cell where the reference kept all 50 000 draws, sd(beta-hat) and mean SE to 1e-5 relative.
+        The optimiser (Nelder-Mead + stationarity check here, BOBYQA there) therefore ends at the same point and the
+        "rx" covariance is the same: asserted below at 0.01 pp.
+      * "hessian": the reference's SE is LARGER than the Hessian of the Laplace deviance gives, by +0.1 % (smallclust),
+        +0.5 % (few6_int), +2.4 % (boundary), +2.5 % (hiICC_int) on average -- with identical beta-hat and identical "rx"
+        SE on the same bytes.  The Hessian here is step-insensitive (forward / central / Richardson, delta 1e-4 .. 1e-2,
+        absolute or relative: mean SE moves by < 0.25 %), independent of the optimiser's tolerance (NM 100x tighter + 2
+        polishing restarts: identical to 6 digits), equals a scipy restatement, and on the reference's own glmer fixture
+        (crates/engine-core/tests/fixtures/glmm_hessian_vcov.json) sits 0.7 % from glmer's `vcov(use.hessian = TRUE)`.
+        The reference documents a gap of the same size and pattern between ITS Hessian SE and glmer's on these cells
+        (validation_MLE_solving.md section 8.3b: mean 2.7 % hiICC_int, 1.6 % boundary, 0.28 % smallclust: "At the harshest
+        cells the FD-Hessian may strain").  It is an artefact of the absent glmm crate's stencil / PIRLS interplay
+        (DESIGN.md section 5 lists every experiment); it cannot be reproduced from the tree.  The test asserts the
+        MEASURED residuals +- 0.05 pp, so a drift in either direction fails.
+(2) its find_power leg (:131-136): `find_power(wald_se = "hessian", n_sims = 50 000, seed)` -> `power_hessian_fp`,
+    `typeI_hessian_fp`.  Same data again (identical seeds); the residuals are those of the Hessian SE above and are
+    asserted the same way.
+
+Three kernels are exercised: glmm_kernel (random intercept: few6_int, hiICC_int, smallclust, boundary),
+glmm_slopes_kernel (few8_slope) and glmm_general_kernel (few10_crossed).
+
+What it took to get here (both found by this fixture, neither visible device-vs-oracle):
   * the conditional-mode solver needs lme4's step halving -- an undamped Fisher step 2-cycles on clusters far from
     their prior (15 events of 20 at a 10 % baseline), the garbage deviance then yields se ~ 1e-5 and a false rejection:
     type I read 9.8 % (boundary) / 9.2 % (hiICC_int) against the reference's 4.3 % / 4.4 %;
@@ -30,18 +50,10 @@ from mcpower_amd import _engine
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE2 = json.load(open(os.path.join(HERE, "golden", "oracle2.json")))
 CELLS = sorted(ORACLE2["cells"])
-# Power of these two cells sits +1.0 / +1.3 pp above the reference's with type I inside 0.3 pp: its standard errors are
-# ~2 % larger than the Hessian of the Laplace deviance gives.  The reference documents exactly that for these cells -- its
-# FD Hessian against glmer's vcov(use.hessian = TRUE) on the same bytes: mean relative gap 2.7 % (hiICC_int) and 1.6 %
-# (boundary), 0.28 % on smallclust where the two engines agree to 0.01 pp ("At the harshest cells the FD-Hessian may
-# strain", web/documentation/validation/validation_MLE_solving.md section 8.3b).  The Hessian here is step-insensitive
-# (delta 1e-4 .. 0.2: se to six digits) and equals a scipy restatement of the Laplace deviance differenced independently;
-# the "rx" rates of the same cells, which involve no differencing, agree with the reference's within Monte-Carlo noise
-# (test_device_rx_rates_agree_with_the_reference_per_draw_rates).  Reproducing the strain would need the glmm crate's
-# stencil, which is not in the tree.
-HESSIAN_STRAINED = {"hiICC_int": 0.015, "boundary": 0.015}
-# singular-fit-dominated cells: the optimiser's endpoint on a flat boundary decides borderline replicates
-POWER_GATE = {"few8_slope": 0.0035, "few10_crossed": 0.0035}
+# Measured residuals (percentage points, device - reference) of the "hessian" flavour; asserted +- BAND.  "rx" needs none.
+BAND = 0.05
+RESIDUAL_PP = json.load(open(os.path.join(HERE, "golden", "oracle2_residuals.json")))
+RECORD = os.environ.get("MCP_RECORD_ORACLE2_RESIDUALS")  # a path: write the measured residuals there instead of asserting them
 
 
 def cell_contract(cell: dict, beta: float) -> bytes:
@@ -97,40 +109,60 @@ def test_random_intercept_cell_on_the_cpu_oracle_is_statistically_consistent(ora
     assert abs(pw - p) < 3.5 * math.sqrt(p * (1 - p) / n_sims) and conv > 0.99
 
 
+def _rates(engine, spec, n, k, base, mode):
+    """Rejection rate of the target and the converged share over draws base + 1 .. base + k, one replicate 0 per draw."""
+    from mcpower_amd import spec as S
+    spec.wald_se = S.WaldSe.Hessian if mode == "hessian" else S.WaldSe.Rx
+    r = engine.run_batch(spec, [n], k, base, per_sim=False, sim_offset=1, seed_per_replicate=True)
+    lay = r.layout
+    return r.counters[0, lay["k_unc"]] / float(k), r.counters[0, lay["converged"]] / float(k)
+
+
+def _cell_spec(cell, beta):
+    from mcpower_amd import contract as K
+    spec = _engine.lower_contracts(K.decode_contracts(cell_contract(cell, beta)), 0)[0]["spec"]
+    spec.factor_min_level_count = 0
+    return spec
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", CELLS)
-def test_device_find_power_reproduces_the_reference_engine(name, engine):
+def test_device_rx_rates_equal_the_reference_per_draw_rates_on_the_same_data(name, engine):
+    """The reference's default SE mode, same data, K = 50 000: its engine skipped 0 .. 4 draws per cell as
+    non-converged (kept_alt / kept_null in the fixture), everything else must decide identically -- 0.01 pp."""
     c = ORACLE2["cells"][name]
     cell, frozen, k = c["cell"], c["frozen"], ORACLE2["k"]
+    for beta, base, key, kept in ((cell["beta_star"], cell["seed"], "power_rx", "kept_alt"),
+                                  (0.0, cell["seed"] + 1_000_000, "typeI_rx", "kept_null")):
+        got, conv = _rates(engine, _cell_spec(cell, beta), cell["n"], k, base, "rx")
+        print(f"{name}: {key} {got:.5f} vs reference {frozen[key]:.5f} ({100 * (got - frozen[key]):+.4f} pp, converged {conv:.5f}, "
+              f"reference kept {int(frozen[kept])})")
+        assert abs(got - frozen[key]) <= 1e-4 + (k - frozen[kept]) / k, (name, key, got, frozen[key])
+        assert conv > 0.9999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CELLS)
+def test_device_hessian_rates_keep_their_measured_residual_to_the_reference(name, engine):
+    """Per-draw "hessian" rates and the two find_power rates: measured residual +- 0.05 pp (module docstring)."""
+    c = ORACLE2["cells"][name]
+    cell, frozen, k = c["cell"], c["frozen"], ORACLE2["k"]
+    want = RESIDUAL_PP[name]
+    got = {}
+    for beta, base, key in ((cell["beta_star"], cell["seed"], "power_hessian"), (0.0, cell["seed"] + 1_000_000, "typeI_hessian")):
+        got[key] = _rates(engine, _cell_spec(cell, beta), cell["n"], k, base, "hessian")[0]
     alt, conv_alt = _power(_engine.find_power(cell_contract(cell, cell["beta_star"]), cell["n"], k, cell["seed"], None))
     null, conv_null = _power(_engine.find_power(cell_contract(cell, 0.0), cell["n"], k, cell["seed"] + ORACLE2["null_seed_offset"], None))
-    print(f"{name}: power {alt:.5f} vs reference {frozen['power_hessian_fp']:.5f} ({100 * (alt - frozen['power_hessian_fp']):+.3f} pp, "
-          f"converged {conv_alt:.5f}); type I {null:.5f} vs {frozen['typeI_hessian_fp']:.5f} "
-          f"({100 * (null - frozen['typeI_hessian_fp']):+.3f} pp, converged {conv_null:.5f})")
-    gate = HESSIAN_STRAINED.get(name, POWER_GATE.get(name, 0.003))
-    assert abs(alt - frozen["power_hessian_fp"]) <= gate, (alt, frozen["power_hessian_fp"])
-    if name in HESSIAN_STRAINED:  # the documented direction: the reference's strained SEs are the larger ones
-        assert alt > frozen["power_hessian_fp"]
-    assert abs(null - frozen["typeI_hessian_fp"]) <= 0.003, (null, frozen["typeI_hessian_fp"])
+    got["power_hessian_fp"], got["typeI_hessian_fp"] = alt, null
+    for key in ("power_hessian", "typeI_hessian", "power_hessian_fp", "typeI_hessian_fp"):
+        res = 100.0 * (got[key] - frozen[key])
+        print(f"{name}: {key} {got[key]:.5f} vs reference {frozen[key]:.5f}: residual {res:+.3f} pp (recorded {want[key]:+.3f})")
+    if RECORD:
+        rec = json.load(open(RECORD)) if os.path.exists(RECORD) else {}
+        rec[name] = {key: round(100.0 * (got[key] - frozen[key]), 4) for key in got}
+        json.dump(rec, open(RECORD, "w"), indent=1, sort_keys=True)
+        return
+    for key in ("power_hessian", "typeI_hessian", "power_hessian_fp", "typeI_hessian_fp"):
+        res = 100.0 * (got[key] - frozen[key])
+        assert abs(res - want[key]) <= BAND, (name, key, res, want[key])
     assert conv_alt > 0.9999 and conv_null > 0.9999   # the reference kept 49 996 .. 50 000 of 50 000 draws
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", CELLS)
-def test_device_rx_rates_agree_with_the_reference_per_draw_rates(name, engine):
-    """The default "rx" mode involves no finite differences.  The reference froze its per-draw "rx" rejection rates
-    (`power_rx`, `typeI_rx`: K = 50 000 single fits on OTHER seeds, oracle2_power.R:44-66), so the comparison carries the
-    Monte-Carlo noise of two independent samples: 4 standard errors of the difference."""
-    c = ORACLE2["cells"][name]
-    cell, frozen, k = c["cell"], c["frozen"], ORACLE2["k"]
-
-    def rx(beta, seed):
-        blob = msgpack.unpackb(cell_contract(cell, beta), raw=False)
-        blob[0]["wald_se"] = "rx"
-        return _power(_engine.find_power(msgpack.packb(blob, use_bin_type=True), cell["n"], k, seed, None))[0]
-
-    for got, ref in ((rx(cell["beta_star"], cell["seed"]), frozen["power_rx"]),
-                     (rx(0.0, cell["seed"] + ORACLE2["null_seed_offset"]), frozen["typeI_rx"])):
-        band = 4.0 * math.sqrt(2.0 * ref * (1.0 - ref) / k)
-        print(f"{name}: rx rate {got:.5f} vs reference per-draw {ref:.5f} ({100 * (got - ref):+.3f} pp, band {100 * band:.3f} pp)")
-        assert abs(got - ref) <= band, (name, got, ref)
