@@ -257,7 +257,7 @@ def _aggregate_counters(batch: S.BatchResult, target_indices, contrast_pairs, es
     return out
 
 
-def sharded_runner(rank: int, world: int, group=None, run_batch=None):
+def sharded_runner(rank: int, world: int, group=None, run_batch=None, allow_host_pool: bool = False):
     """Runner for `find_power` / `find_sample_size` when one process drives one GPU: this rank simulates its
     contiguous slice of the replicates (same base seed, so the union is the single-device run), one all-reduce pools
     the counters, and every rank aggregates the same pooled block -- identical results on all ranks.
@@ -265,9 +265,11 @@ def sharded_runner(rank: int, world: int, group=None, run_batch=None):
 
     With a C-ABI communicator of this world (`mcpower_amd.dist.init_comm`) the collective runs inside `run_batch`
     on the device-resident counters, and a cancelling progress callback on any rank cancels every rank (the verdict
-    rides in the reduced payload).  Without one (gloo rehearsals, `run_batch=` stand-ins) the host blocks are pooled
-    through the torch process group; there only rank 0 drives the progress sink and its verdict is agreed on with a
-    one-word all-reduce ahead of the block's, so no rank is left waiting in a collective."""
+    rides in the reduced payload); an empty shard (fewer replicates than ranks) still joins it.  Without a communicator
+    the device path REFUSES to run sharded: only rehearsals -- a `run_batch=` stand-in (the CPU oracle under gloo in the
+    tests) or `allow_host_pool=True` -- pool the host blocks through the torch process group; there only rank 0 drives
+    the progress sink and its verdict is agreed on with a one-word all-reduce ahead of the block's, so no rank is left
+    waiting in a collective."""
     def run(spec, sample_sizes, n_sims, base_seed, sink):
         from . import dist as mdist
         from . import engine
@@ -275,6 +277,10 @@ def sharded_runner(rank: int, world: int, group=None, run_batch=None):
         if run_batch is None and engine.comm_world() == world and world > 1:
             local = engine.run_batch(spec, sample_sizes, cnt, base_seed, sink, per_sim=False, sim_offset=off, allreduce=True)
         else:
+            if run_batch is None and world > 1 and not allow_host_pool:
+                raise OrchestratorError("InvalidScenarios", f"sharded_runner: no C-ABI communicator of world {world} in this process "
+                                        "(mcpower_amd.dist.init_comm first); allow_host_pool=True pools host counter blocks through "
+                                        "the torch process group instead (rehearsals)")
             my_sink = sink if rank == 0 else None
             cancelled = 0
             try:

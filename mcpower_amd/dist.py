@@ -12,9 +12,13 @@ The product form of that collective lives behind the C ABI (`mcp_comm_init` + `M
 `csrc/host_comm.cpp`): `ncclAllReduce(sum, uint64)` over RCCL / xGMI on the device-resident vector, on the launch
 stream, before the call's single device-to-host copy -- no torch, no host bounce.  This module is the thin caller:
 `init_comm` carries the 128-byte rendezvous id over the host's control plane (a `torch.distributed` process group of
-any backend) and `run_batch_sharded` sets the option.  The `allreduce_counters*` functions below pool HOST counter
-blocks through a torch process group instead; they exist for the gloo rehearsals on GPU-less boxes (tests) and as a
-fallback when a caller already holds host counters.
+any backend) and `run_batch_sharded` sets the option.
+
+REHEARSAL ONLY: the `allreduce_counters*` functions below pool HOST counter blocks through a torch process group.  They
+are not the product's collective: they exist for the world-size-2 gloo tests on GPU-less boxes (tests/test_dist_cpu.py,
+tests/test_sharded_engine.py) and for `bench.py --backend gloo|nccl` / `--allow-host-fallback`.  On a box with a device
+`run_batch_sharded` and `_engine.sharded_runner` REFUSE to pool on the host unless told to (`allow_host_pool=True`):
+a multi-GPU result must never be mistaken for the RCCL path when it is not.
 """
 from __future__ import annotations
 
@@ -111,10 +115,12 @@ def wilson_ci(k: int, n: int):
     return max(center - margin, 0.0), min(center + margin, 1.0)
 
 
-def run_batch_sharded(spec, sample_sizes, n_sims: int, base_seed: int, *, rank: int, world: int, group=None, **kw):
-    """Each rank runs its slice on its own GPU (counters-only); the counts are pooled by the ONE all-reduce.
-    With a C-ABI communicator of this world (`init_comm`) the collective runs inside the call, on the device;
-    otherwise the host counter blocks are pooled through the torch process group.
+def run_batch_sharded(spec, sample_sizes, n_sims: int, base_seed: int, *, rank: int, world: int, group=None,
+                      allow_host_pool: bool = False, **kw):
+    """Each rank runs its slice on its own GPU (counters-only); the counts are pooled by the ONE all-reduce, inside the
+    call, on the device, through the C-ABI communicator of this world (`init_comm`).  A shard may be empty (fewer
+    replicates than ranks): that rank still joins the collective.  Without a communicator of this world the call
+    raises; `allow_host_pool=True` (rehearsals) pools the host counter blocks through the torch process group instead.
     Returns (pooled_counters, local BatchResult)."""
     from . import engine
 
@@ -122,5 +128,8 @@ def run_batch_sharded(spec, sample_sizes, n_sims: int, base_seed: int, *, rank: 
     if engine.comm_world() == world:
         local = engine.run_batch(spec, sample_sizes, cnt, base_seed, per_sim=False, sim_offset=off, allreduce=True, **kw)
         return local.counters, local
+    if world > 1 and not allow_host_pool:
+        raise RuntimeError(f"run_batch_sharded: no C-ABI communicator of world {world} in this process (init_comm first); "
+                           "pass allow_host_pool=True to pool host counter blocks through the torch process group instead")
     local = engine.run_batch(spec, sample_sizes, cnt, base_seed, per_sim=False, sim_offset=off, **kw)
     return allreduce_counters(local.counters, group), local

@@ -358,9 +358,27 @@ int mcpo_glmm_slopes_fit_ids(int fam, const float* x, const float* y, const uint
      * that does not factor keeps "rx". */
     uint8_t th_free[6];
     for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = !(is_diag[k] && par[k] < GS_THETA_ZERO);
+    {  /* EXPERIMENT KNOB HESS_PINNED (oracle_internal.h): 1 = keep pinned diagonals in the stencil (steps past the bound are
+          clamped onto it), 2 = a singular fit keeps "rx" (vcov.merMod), 4 = a singular fit differences over beta alone,
+          5 = a pinned diagonal takes the rest of its template column out as well */
+      const int hp = (int)mcpo_knob("HESS_PINNED", 0.0);
+      int singular = 0;
+      for (uint32_t k = 0; k < m.nth; ++k) singular |= !th_free[k];
+      if (hp == 1) for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = 1;
+      if (hp == 2 && singular) goto hess_done;
+      if (hp == 4 && singular) for (uint32_t k = 0; k < m.nth; ++k) th_free[k] = 0;
+      if (hp == 5 && singular) {
+        uint32_t k = 0;
+        for (uint32_t c = 0; c < q; ++c) {
+          const int pinned = !th_free[k];
+          for (uint32_t r = c; r < q; ++r, ++k) if (pinned) th_free[k] = 0;
+        }
+      }
+    }
     gs_cb cb = {&m, is_diag, NULL};
     double lh[MCPO_MAX_P * MCPO_MAX_P];
     if (mcpo_fd_hessian_factor(gs_dev_cb, &cb, par, m.nth, p, th_free, cur, lh) == 0) memcpy(f->L, lh, sizeof(double) * p * p);
+  hess_done:;
   }
   f->converged = ok;
   uint32_t comp = 0;
