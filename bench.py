@@ -84,7 +84,7 @@ def kernel_name(workload, p):
         return f"lmm_general_kernel<{p}>"
     if workload.startswith("glmm"):
         return {"glmm": f"glmm_kernel<{p}>", "glmm_slope": f"glmm_slopes_kernel<{p},2>"}.get(workload, f"glmm_general_kernel<{p}>")
-    return f"ols_sim_kernel<{p},fused>" if p <= 12 else f"ols_reduced_kernel<{p}>"
+    return f"ols_sim_kernel<{p},fused>" if p <= 12 else f"ols_wide_kernel<{p}>"
 
 
 def pmc_traffic(workload, kernel_tag):

@@ -24,6 +24,7 @@
 #include "mcp_rows.hpp"
 #include "mcp_decide.hpp"
 #include "mcp_suff.hpp"
+#include "mcp_ols_finish.hpp"
 
 #pragma clang fp contract(off)
 
@@ -131,82 +132,8 @@ __device__ __forceinline__ void fit_decide(const SimParams& prm, const Suff<P>& 
     }
   }
 
-  // ---- decisions (batch.rs:1089-1117, correction.rs:16-92) ----
-  uint32_t unc_bits = 0, cor_bits = 0;
-  decide_tests(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
-  if (!conv) {
-    unc_bits = 0;
-    cor_bits = 0;
-  }
-  // overall F (batch.rs:1118-1142)
-  bool ov = false;
-  if (prm.report_overall && conv) {
-    const double dfn = (double)(P - 1);
-    if (sst > 1e-10 && rss > 0.0 && rss < __builtin_inf() && sst < __builtin_inf()) {
-      const double f = ((sst - rss) / dfn) / (rss / df);
-      ov = (f < __builtin_inf()) && (f > crow[3 + nt]);
-    }
-  }
-
-  // ---- per-replicate tensors (BatchResult, spec.rs:553-600) ----
-  if (active) {
-    const size_t cell = (size_t)out_row * prm.n_grid + g;
-    if (prm.unc) {
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        if ((uint32_t)t < nt) {
-          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
-          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
-        }
-    }
-    if (prm.conv) prm.conv[cell] = conv ? 1 : 0;
-    if (prm.overall) prm.overall[cell] = ov ? 1 : 0;
-    if (prm.stat && g == 0) {
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-        if ((uint32_t)t < nt) prm.stat[(size_t)out_row * nt + t] = tsq[t];
-    }
-  }
-
-  // ---- additive counters (aggregation.rs:84-284): one atomic per wave per counter ----
-  unsigned long long* ctr = prm.counters +
-                            (size_t)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % CTR_COPIES) * prm.ctr_copy_stride +
-                            (size_t)g * prm.ctr_stride;
-  const bool lane0 = (threadIdx.x & 63u) == 0u;
-  const uint32_t ub = active ? unc_bits : 0u, cb = active ? cor_bits : 0u;
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    if ((uint32_t)t < nt) {
-      const unsigned long long mu = __ballot((ub >> t) & 1u);
-      const unsigned long long mc = __ballot((cb >> t) & 1u);
-      if (lane0) {
-        if (mu) atomicAdd(ctr + prm.ctr_k_unc + t, (unsigned long long)__popcll(mu));
-        if (mc) atomicAdd(ctr + prm.ctr_k_cor + t, (unsigned long long)__popcll(mc));
-      }
-    }
-  }
-  const uint32_t ku = __popc(ub), kc = __popc(cb);
-#pragma unroll
-  for (int k = 0; k <= MT; ++k) {
-    if ((uint32_t)k <= nt) {
-      const unsigned long long hu = __ballot(active && ku == (uint32_t)k);
-      const unsigned long long hc = __ballot(active && kc == (uint32_t)k);
-      if (lane0) {
-        if (hu) atomicAdd(ctr + prm.ctr_hist_unc + k, (unsigned long long)__popcll(hu));
-        if (hc) atomicAdd(ctr + prm.ctr_hist_cor + k, (unsigned long long)__popcll(hc));
-      }
-    }
-  }
-  {
-    const unsigned long long mcv = __ballot(active && conv);
-    const unsigned long long mov = __ballot(active && ov);
-    const unsigned long long mac = __ballot(active);
-    if (lane0) {
-      if (mcv) atomicAdd(ctr + prm.ctr_conv, (unsigned long long)__popcll(mcv));
-      if (mov) atomicAdd(ctr + prm.ctr_overall, (unsigned long long)__popcll(mov));
-      if (mac) atomicAdd(ctr + prm.ctr_n_sims, (unsigned long long)__popcll(mac));
-    }
-  }
+  // ---- decisions, per-replicate tensors, additive counters (mcp_ols_finish.hpp) ----
+  ols_finish<MT>(prm, tsq, conv, rss, sst, df, (double)(P - 1), g, active, out_row);
 #undef Lm
 }
 
@@ -437,6 +364,8 @@ __global__ void icdf_probe_kernel(uint32_t first_word, uint32_t stride, uint32_t
 // ---- launchers (C++ linkage, called from host_api.hip) ----
 namespace mcp {
 
+hipError_t launch_ols_wide(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);  // ols_wide_kernels.hip
+
 // fused kernel, P = 9..12 (MAX_P_FUSED): the staging area passes 48 KB at P = 12
 template <bool GRID1, int FLAVOR>
 static hipError_t launch_fused_wide(int P, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st) {
@@ -452,7 +381,8 @@ static hipError_t launch_fused_wide(int P, const SimParams* d_prm, uint32_t n_si
   } break;
   switch (P) {
     LFW(9) LFW(10) LFW(11) LFW(12)
-    default: return hipErrorInvalidValue;
+    // P = 13 .. 16, one sample size, plain data path: two waves share 64 replicates (ols_wide_kernels.hip)
+    default: return (GRID1 && FLAVOR != 2 && P >= 13 && P <= MAX_P) ? launch_ols_wide(P, d_prm, n_sims, FLAVOR, st) : hipErrorInvalidValue;
   }
 #undef LFW
   return hipGetLastError();
