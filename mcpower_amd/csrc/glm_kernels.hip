@@ -93,19 +93,26 @@ __global__ __launch_bounds__(256) void fold_flags_kernel(const SimParams* __rest
   }
 }
 
-// final[i] = sum over copies of counters[copy][i]
-__global__ void reduce_counter_copies_kernel(const unsigned long long* __restrict__ copies, uint32_t copy_stride,
-                                             uint32_t n, unsigned long long* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// final[i] = sum over copies of counters[copy][i].  One wave per word: lane l adds the copies l, l + 64, ... (independent
+// loads), a butterfly finishes -- the serial form (one thread walking the 256 copies of its word) was an 11 us latency
+// chain on every batch's critical path (profiles/r03 C4 timeline), this one is ~2 us.
+__global__ __launch_bounds__(256) void reduce_counter_copies_kernel(const unsigned long long* __restrict__ copies, uint32_t copy_stride,
+                                                                    uint32_t n, unsigned long long* __restrict__ out) {
+  const uint32_t i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= n) return;
+  const uint32_t lane = threadIdx.x & 63u;
   unsigned long long s = 0;
-  for (int c = 0; c < CTR_COPIES; ++c) s += copies[(size_t)c * copy_stride + i];
-  out[i] = s;
+#pragma unroll
+  for (int c = 0; c < CTR_COPIES / 64; ++c) s += copies[(size_t)(lane + 64u * (uint32_t)c) * copy_stride + i];
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+  if (lane == 0u) out[i] = s;
 }
 
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_counter_copies_kernel, dim3((n + 127u) / 128u), dim3(128), 0, st, copies, copy_stride, n, out);
+  static_assert(CTR_COPIES % 64 == 0, "one wave sums the copies of a word");
+  hipLaunchKernelGGL(reduce_counter_copies_kernel, dim3((n + 3u) / 4u), dim3(256), 0, st, copies, copy_stride, n, out);
   return hipGetLastError();
 }
 

@@ -67,7 +67,10 @@ __device__ __forceinline__ size_t rec_at(const SimParams& prm, uint32_t field, u
 // SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
 // heteroskedastic residuals) plus the LME knobs: random-effect shape and per-replicate tau^2 (data_gen.rs:146-161).
 template <int P, bool FACTORS, bool RED, bool SCEN>
-__global__ __launch_bounds__(LWAVE) void lmm_prepare_kernel(const SimParams* __restrict__ pp) {
+// P <= 3 on the plain data path (BASELINE configs[3]: 30 clusters x 20, P = 3) is held to 128 registers: a CU then holds the
+// 14 single-wave workgroups its LDS admits (11.4 KB each) instead of 12, and 10^4 replicates take 3 rounds of resident
+// waves instead of 4; the wider / general-path variants keep the default budget (they need 200+)
+__global__ __launch_bounds__(LWAVE, (P <= 3 && !SCEN) ? 4 : 1) void lmm_prepare_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ float lds_f[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
@@ -235,18 +238,33 @@ __global__ __launch_bounds__(LWAVE) void lmm_prepare_kernel(const SimParams* __r
           }
       }
     }
+    // every field is reduced over the wave and stored at once by lane 0 (record order: M0 | M1 | size0 size1 cnt0 cnt1 |
+    // X'X | X'y | y'y): nothing of the record stays live behind its store
+    {
+      uint32_t o = 0;
+      auto put = [&](double v) {
+        const double t = lwave_sum(v);
+        if (lane == 0) rec[rec_at(prm, o, g, lsim)] = t;
+        ++o;
+      };
+      auto put_uniform = [&](double v) {
+        if (lane == 0) rec[rec_at(prm, o, g, lsim)] = v;
+        ++o;
+      };
 #pragma unroll
-    for (int i = 0; i < P * (P + 1) / 2; ++i) xtx[i] = lwave_sum(xtx[i]);
+      for (uint32_t i = 0; i < MF; ++i) put(M0[i]);
 #pragma unroll
-    for (int i = 0; i < P; ++i) xty[i] = lwave_sum(xty[i]);
-    yty = lwave_sum(yty);
+      for (uint32_t i = 0; i < MF; ++i) put(M1[i]);
+      put_uniform((double)size0);
+      put_uniform((double)size1);
+      put(cnt0);
+      put(cnt1);
 #pragma unroll
-    for (uint32_t i = 0; i < MF; ++i) {
-      M0[i] = lwave_sum(M0[i]);
-      M1[i] = lwave_sum(M1[i]);
+      for (int i = 0; i < P * (P + 1) / 2; ++i) put(xtx[i]);
+#pragma unroll
+      for (int i = 0; i < P; ++i) put(xty[i]);
+      put(yty);
     }
-    cnt0 = lwave_sum(cnt0);
-    cnt1 = lwave_sum(cnt1);
     uint32_t flag_bits = 0;
     if (RED && prm.min_level_count) {  // update_factor_exclusions (batch.rs:2451-2500), rows [0, n)
 #pragma unroll
@@ -270,29 +288,7 @@ __global__ __launch_bounds__(LWAVE) void lmm_prepare_kernel(const SimParams* __r
         }
       }
     }
-    // lanes share the stores: lane i writes fields i, i + 64, ... (all lanes hold identical reduced values)
-    {
-      double out[lmm_total_fields<P>()];
-      uint32_t o = 0;
-#pragma unroll
-      for (uint32_t i = 0; i < MF; ++i) out[o++] = M0[i];
-#pragma unroll
-      for (uint32_t i = 0; i < MF; ++i) out[o++] = M1[i];
-      out[o++] = (double)size0;
-      out[o++] = (double)size1;
-      out[o++] = cnt0;
-      out[o++] = cnt1;
-#pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) out[o++] = xtx[i];
-#pragma unroll
-      for (int i = 0; i < P; ++i) out[o++] = xty[i];
-      out[o++] = yty;
-      if (lane == 0) {
-#pragma unroll
-        for (uint32_t f = 0; f < lmm_total_fields<P>(); ++f) rec[rec_at(prm, f, g, lsim)] = out[f];
-        prm.lmm_rec_flags[(size_t)g * prm.lmm_rec_stride + lsim] = flag_bits;
-      }
-    }
+    if (lane == 0) prm.lmm_rec_flags[(size_t)g * prm.lmm_rec_stride + lsim] = flag_bits;
   }
 }
 
