@@ -193,12 +193,17 @@ __global__ __launch_bounds__(LWAVE, (P <= 3 && !SCEN) ? 4 : 1) void lmm_prepare_
       M0[i] = 0.0;
       M1[i] = 0.0;
     }
-    for (uint32_t c = lane; c < ncl; c += LWAVE) {
+    // few clusters leave lanes idle (30 of 64 at BASELINE configs[3]): with <= 32 clusters the lanes l and l + 32 share
+    // cluster l, each takes every other row of it, and one exchange leaves the cluster's sums v_c in both
+    const uint32_t halves = ncl <= 32u ? 2u : 1u;
+    const uint32_t half = halves == 2u ? (lane >> 5) : 0u;
+    for (uint32_t c = halves == 2u ? (lane & 31u) : lane; c < ncl; c += LWAVE) {
       double v[P + 1];  // (n_c, Sx_1..Sx_{P-1}, Sy)
 #pragma unroll
       for (int a = 0; a <= P; ++a) v[a] = 0.0;
-      const uint32_t first = prm.cluster_fixed_clusters ? c : c * cv;
-      const uint32_t step = prm.cluster_fixed_clusters ? cv : 1u;
+      const uint32_t step1 = prm.cluster_fixed_clusters ? cv : 1u;
+      const uint32_t first = (prm.cluster_fixed_clusters ? c : c * cv) + half * step1;
+      const uint32_t step = step1 * halves;
       const uint32_t last = prm.cluster_fixed_clusters ? n : ((c + 1u) * cv < n ? (c + 1u) * cv : n);
       for (uint32_t i = first; i < last; i += step) {
         double xd[P];
@@ -221,8 +226,12 @@ __global__ __launch_bounds__(LWAVE, (P <= 3 && !SCEN) ? 4 : 1) void lmm_prepare_
         }
         yty = __builtin_fma(yi, yi, yty);
       }
+      if (halves == 2u) {
+#pragma unroll
+        for (int a = 0; a <= P; ++a) v[a] += __shfl_xor(v[a], 32, LWAVE);  // a + b == b + a: both halves hold the same sums
+      }
       const uint32_t sz = size_of(c);
-      if (sz != 0u) {
+      if (sz != 0u && half == 0u) {
         const bool k0c = sz == size0;
         cnt0 += k0c ? 1.0 : 0.0;
         cnt1 += k0c ? 0.0 : 1.0;
@@ -238,32 +247,55 @@ __global__ __launch_bounds__(LWAVE, (P <= 3 && !SCEN) ? 4 : 1) void lmm_prepare_
           }
       }
     }
-    // every field is reduced over the wave and stored at once by lane 0 (record order: M0 | M1 | size0 size1 cnt0 cnt1 |
-    // X'X | X'y | y'y): nothing of the record stays live behind its store
+    // The record (order: M0 | M1 | size0 size1 cnt0 cnt1 | X'X | X'y | y'y) is reduced over the wave through the staging
+    // area (dead once the rows exist): CH = 2 (P + 1) fields at a time, lane l parks its partial of field k at [k][l];
+    // lane (k = l mod 8 .., part = l / CH ..) then adds a run of the 64 partials of field k in lane order and a short
+    // butterfly over the parts finishes -- ~35 instructions per chunk where 6-step butterflies of every field took
+    // 18 each (a third of this kernel's non-RNG instructions at P = 3).  Fixed summation order: deterministic.
     {
-      uint32_t o = 0;
-      auto put = [&](double v) {
-        const double t = lwave_sum(v);
-        if (lane == 0) rec[rec_at(prm, o, g, lsim)] = t;
-        ++o;
-      };
-      auto put_uniform = [&](double v) {
-        if (lane == 0) rec[rec_at(prm, o, g, lsim)] = v;
-        ++o;
-      };
+      constexpr int NV = 2 * (int)MF + 2 + P * (P + 1) / 2 + P + 1;  // reduced fields
+      double vals[NV];
+      {
+        int o = 0;
 #pragma unroll
-      for (uint32_t i = 0; i < MF; ++i) put(M0[i]);
+        for (uint32_t i = 0; i < MF; ++i) vals[o++] = M0[i];
 #pragma unroll
-      for (uint32_t i = 0; i < MF; ++i) put(M1[i]);
-      put_uniform((double)size0);
-      put_uniform((double)size1);
-      put(cnt0);
-      put(cnt1);
+        for (uint32_t i = 0; i < MF; ++i) vals[o++] = M1[i];
+        vals[o++] = cnt0;
+        vals[o++] = cnt1;
 #pragma unroll
-      for (int i = 0; i < P * (P + 1) / 2; ++i) put(xtx[i]);
+        for (int i = 0; i < P * (P + 1) / 2; ++i) vals[o++] = xtx[i];
 #pragma unroll
-      for (int i = 0; i < P; ++i) put(xty[i]);
-      put(yty);
+        for (int i = 0; i < P; ++i) vals[o++] = xty[i];
+        vals[o++] = yty;
+      }
+      // record slot of reduced field j: the two uniform size fields sit behind M0 | M1
+      auto slot_of = [&](uint32_t j) -> uint32_t { return j < 2u * MF ? j : j + 2u; };
+      constexpr int CH = 8;                       // fields per chunk: 8 doubles per lane fit the staging area from P = 3 on
+      static_assert(4 * (P + 1) * (int)sizeof(float) >= CH * (int)sizeof(double) || P < 3, "staging area too small for a chunk");
+      constexpr int CHP = P >= 3 ? CH : 4;        // P = 2: 4 (P + 1) floats = 6 doubles per lane
+      constexpr int PARTS = LWAVE / CHP, RUN = LWAVE / PARTS;
+      double* sbuf = reinterpret_cast<double*>(cluster_u + ncl_pad);  // the staging area (8-byte aligned: ncl_pad is even)
+#pragma unroll
+      for (int c0 = 0; c0 < NV; c0 += CHP) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CHP; ++k)
+          if (c0 + k < NV) sbuf[k * LWAVE + lane] = vals[c0 + k];
+        __syncthreads();
+        const uint32_t k = lane % (uint32_t)CHP, part = lane / (uint32_t)CHP;
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < RUN; ++j) t += sbuf[k * LWAVE + part * RUN + j];
+#pragma unroll
+        for (int m = CHP; m < LWAVE; m <<= 1) t += __shfl_xor(t, m, LWAVE);
+        if (lane < (uint32_t)CHP && c0 + (int)lane < NV) rec[rec_at(prm, slot_of((uint32_t)c0 + lane), g, lsim)] = t;
+      }
+      if (lane == 0) {
+        rec[rec_at(prm, 2u * MF, g, lsim)] = (double)size0;
+        rec[rec_at(prm, 2u * MF + 1u, g, lsim)] = (double)size1;
+      }
+      __syncthreads();
     }
     uint32_t flag_bits = 0;
     if (RED && prm.min_level_count) {  // update_factor_exclusions (batch.rs:2451-2500), rows [0, n)
