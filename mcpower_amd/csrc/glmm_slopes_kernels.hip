@@ -235,7 +235,73 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds 
       double uu = 0.0;
 #pragma unroll
       for (int b = 0; b < Q; ++b) uu += u[b] * u[b];
-      if (sub == 0u) m.tcl[c] = dev + uu + logdet;
+      double term = dev + uu + logdet;
+      if (prm.glmm_nagq > 1u) {
+        // adaptive Gauss-Hermite quadrature over the Q random effects of the cluster (validate.rs:918-941 admits it for one
+        // grouping with <= 3 of them): the k^Q tensor rule centred at the mode, scaled by the factor of the curvature
+        // there, u_j = u~ + Lm^-T z_j, as a ratio to the Laplace term -- oracle/fit_glmm_slopes.c, node index 0 fastest.
+        // Every lane of the group sweeps its rows once per off-centre node.
+        const uint32_t kq = prm.glmm_nagq;
+        const double d0 = dev + uu;
+        uint32_t nn = 1u;
+#pragma unroll
+        for (int b = 0; b < Q; ++b) nn *= kq;
+        double mult = 0.0;
+        for (uint32_t node = 0; node < nn; ++node) {
+          double zn[Q], xs[Q], v[Q], wj = 1.0, zz = 0.0;
+          uint32_t rem = node;
+          bool centre = true;
+#pragma unroll
+          for (int b = 0; b < Q; ++b) {
+            const uint32_t ib = rem % kq;
+            rem /= kq;
+            zn[b] = prm.glmm_gz[ib];
+            wj *= prm.glmm_gw[ib];
+            zz += zn[b] * zn[b];
+            centre = centre && (2u * ib + 1u == kq);
+          }
+          if (centre) {
+            mult += wj;
+            continue;
+          }
+#pragma unroll
+          for (int b = Q - 1; b >= 0; --b) {  // Lm' xs = z
+            double t = zn[b];
+#pragma unroll
+            for (int k2 = 0; k2 < Q; ++k2)
+              if (k2 > b) t -= Lm[k2][b] * xs[k2];
+            xs[b] = t / Lm[b][b];
+          }
+          double vv = 0.0;
+#pragma unroll
+          for (int b = 0; b < Q; ++b) {
+            v[b] = u[b] + xs[b];
+            vv += v[b] * v[b];
+          }
+          double ds = 0.0;
+          for (uint32_t i = first + sub * step; i < last; i += step << ls) {
+            double z[Q], au = 0.0;
+            z[0] = 1.0;
+#pragma unroll
+            for (int dd = 1; dd < Q; ++dd) z[dd] = (double)m.design[(size_t)(prm.lmg_cols[0][dd - 1] - 1u) * n_pad + i];
+#pragma unroll
+            for (int b = 0; b < Q; ++b) {
+              double sacc = 0.0;
+#pragma unroll
+              for (int dd = 0; dd < Q; ++dd)
+                if (dd >= b) sacc += T[dd][b] * z[dd];
+              au += sacc * v[b];
+            }
+            double w, wz, dv;
+            fam_eval(fam, m.eta0[i] + au, (double)m.design[(size_t)(P - 1) * n_pad + i], w, wz, dv);
+            ds += dv;
+          }
+          for (uint32_t o = 1u; o < (1u << ls); o <<= 1) ds += __shfl_xor(ds, (int)o);
+          mult += wj * exp(-0.5 * (ds + vv - d0) + 0.5 * zz);
+        }
+        term -= 2.0 * log(mult);
+      }
+      if (sub == 0u) m.tcl[c] = term;
     } else if (sub == 0u) {
       m.tcl[c] = 0.0;
     }

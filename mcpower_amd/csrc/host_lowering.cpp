@@ -763,9 +763,10 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (glmm) {
     prm.glmm_active = 1;
     if (spec->wald_se > MCP_WALD_SE_HESSIAN) { err = "invalid spec: wald_se out of range"; return MCP_ERR_INVALID_SPEC; }
-    // validate.rs:918-945: odd, <= 25; quadrature here integrates a scalar random intercept
+    // validate.rs:918-945: odd, <= 25
     if (spec->nagq > 25 || (spec->nagq > 1 && !(spec->nagq & 1u))) { err = "invalid spec: nagq must be odd and in 1..=25"; return MCP_ERR_INVALID_SPEC; }
-    if (spec->nagq > 1 && lmm_general) return unsupported("adaptive Gauss-Hermite quadrature (nagq > 1) with random slopes (random intercept only)");
+    // validate.rs:918-941: one grouping, <= 3 random effects (the k^q tensor rule of glmm_slopes_kernel); extra groupings never
+    if (spec->nagq > 1 && spec->cluster.n_extra_groupings) return unsupported("adaptive Gauss-Hermite quadrature (nagq > 1) with extra groupings (the reference admits one grouping with <= 3 random effects)");
     prm.glmm_nagq = spec->nagq > 1 ? spec->nagq : 1u;
     if (prm.glmm_nagq > 1) gauss_hermite_normal(prm.glmm_nagq, prm.glmm_gz, prm.glmm_gw);
     prm.glmm_hessian = spec->wald_se == MCP_WALD_SE_HESSIAN ? 1u : 0u;

@@ -634,7 +634,7 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
   if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL) return MCP_ERR_UNSUPPORTED;
   const int fam = spec->outcome_kind == MCP_OUTCOME_COUNT ? 2 : (spec->link == MCP_LINK_PROBIT ? 1 : 0);
   const uint32_t mode = (spec->wald_se == MCP_WALD_SE_HESSIAN ? MCPO_MODE_HESSIAN : 0u) | ((uint32_t)spec->nagq << 8);
-  if (spec->nagq > 1 && cl->slopes.n_slopes) return MCP_ERR_UNSUPPORTED; /* quadrature: random intercept only */
+  /* quadrature with random slopes: the tensor rule of fit_glmm_slopes.c (validate.rs:918-941: <= 3 random effects, one grouping) */
   const uint32_t p = 1 + spec->n_non_factor + spec->n_factor_dummies + spec->n_interactions;
   const uint32_t nt = spec->n_target_indices;
   const uint32_t cv = cl->sizing_value ? cl->sizing_value : 1;

@@ -381,7 +381,7 @@ def gh_rule(k: int):
 
 
 def glmm_slopes_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.ndarray, slope_cols, family: str = "logit",
-                    theta_start=None, beta_start=None, wald_se: str = "rx"):
+                    theta_start=None, beta_start=None, wald_se: str = "rx", nagq: int = 1):
     """GLMM with random slopes on the primary grouping (Laplace; Wald SE mode "rx" or "hessian") on provided bytes."""
     n, p = design.shape
     x = np.ascontiguousarray(design.T, dtype=np.float32)
@@ -402,7 +402,7 @@ def glmm_slopes_fit(design: np.ndarray, outcome: np.ndarray, cluster_ids: np.nda
                                     None if b0 is None else b0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
                                     se.ctypes.data_as(pd), theta.ctypes.data_as(pd), vars_out.ctypes.data_as(pd),
                                     C.byref(conv), C.byref(bh), C.byref(pinned), C.byref(ne),
-                                    C.c_uint32(1 if wald_se == "hessian" else 0))
+                                    C.c_uint32((1 if wald_se == "hessian" else 0) | (int(nagq) << 8)))
     _check(rc)
     return dict(beta=beta, se=se, theta=theta[:q * (q + 1) // 2], cov=vars_out[:q, :q], converged=bool(conv.value),
                 boundary_hit=bh.value, pinned=pinned.value, n_eval=ne.value)

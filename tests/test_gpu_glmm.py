@@ -318,11 +318,31 @@ def test_glmm_agq_matches_oracle(shape, nagq, engine, oracle):
         assert np.mean(dev.tau_squared_hat[both]) > np.mean(lap.tau_squared_hat[both])
 
 
-def test_glmm_agq_with_slopes_is_refused(engine):
-    spec, _, a, low = load_case("glmm_slope")
+@pytest.mark.parametrize("case,nagq", [("glmm_slope", 5), ("glmm_slope", 9), ("glmm_multislope", 3)])
+def test_glmm_agq_with_random_slopes_matches_oracle(case, nagq, engine, oracle):
+    """validate.rs:918-941: nagq > 1 for ONE grouping with <= 3 random effects -- the k^q tensor adaptive rule of
+    glmm_slopes_kernel (25 / 81 nodes per cluster at q = 2, 27 at q = 3) against oracle/fit_glmm_slopes.c, which is pinned
+    to the exact marginal likelihood (tests/test_oracle_glmm.py)."""
+    spec, _, a, low = load_case(case)
+    n = int(low["n"]) if "n" in low else a["design"].shape[0]
+    spec.scenario.truth_start = True
+    lap = engine.run_batch(spec, [n], 24, BASE_SEED)
+    spec.nagq = nagq
+    dev, stat = engine.run_batch_st_capture(spec, [n], 24, BASE_SEED)
+    ora = oracle.run_batch(spec, [n], 24, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.85
+    _compare(dev, ora, 24, stat, ora.stat_capture, slack=1)
+    both = (dev.converged[:, 0] == 1) & (lap.converged[:, 0] == 1)
+    assert not np.allclose(dev.tau_squared_hat[both], lap.tau_squared_hat[both], rtol=1e-5)   # the rule changes the fit
+    red = engine.run_batch(spec, [n], 24, BASE_SEED, per_sim=False)
+    assert np.array_equal(red.counters, dev.counters)
+
+
+def test_glmm_agq_with_extra_groupings_is_refused(engine):
+    spec, _, a, low = load_case("glmm_slope_crossed")
     spec.nagq = 5
     with pytest.raises(S.EngineError) as e:
-        engine.run_batch(spec, [600], 4, BASE_SEED)
+        engine.run_batch(spec, [a["design"].shape[0]], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "nagq" in str(e.value)
     spec, _, a, low = load_case("glmm_intercept")
     spec.nagq = 4

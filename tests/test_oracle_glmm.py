@@ -241,10 +241,64 @@ def test_agq_on_the_laplace_bias_shape_and_through_run_batch(oracle):
     r = oracle.run_batch(spec, [600], 8, 2404, n_threads=8, stat_capture=True)
     assert r.converged[0, 0] == 1 and np.isclose(r.tau_squared_hat[0, 0], agq["theta"] ** 2, rtol=1e-12)
     assert np.isclose(r.stat_capture[0, 0], agq["z_sq"][1], rtol=1e-12)
-    spec.cluster.slopes = [{"column": 0, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": []}]
+
+
+def _marginal_deviance_q2(par, x, y, ids, zcol, nodes=48):
+    """-2 log marginal likelihood of the logistic model with a random intercept and one random slope on column `zcol`
+    (theta = column-major vech of the lower template: t11, t21, t22) by a NON-adaptive nodes x nodes tensor rule."""
+    from scipy.special import expit
+    z, w = np.polynomial.hermite_e.hermegauss(nodes)
+    w = w / np.sqrt(2 * np.pi)
+    t11, t21, t22 = par[:3]
+    beta = par[3:]
+    u1, u2 = np.meshgrid(z, z, indexing="ij")
+    ww = (w[:, None] * w[None, :]).ravel()
+    b0 = (t11 * u1).ravel()                       # b = Lambda u
+    b1 = (t21 * u1 + t22 * u2).ravel()
+    eta0 = x @ beta
+    tot = 0.0
+    for c in range(ids.max() + 1):
+        m = ids == c
+        eta = eta0[m][:, None] + b0[None, :] + x[m, zcol][:, None] * b1[None, :]
+        ll = np.where(y[m][:, None] > 0.5, np.log(expit(eta)), np.log(expit(-eta))).sum(axis=0)
+        tot += -2.0 * np.log(np.sum(ww * np.exp(ll)))
+    return tot
+
+
+def test_agq_with_a_random_slope_lands_on_the_marginal_likelihood_optimum(oracle):
+    """validate.rs:918-941 admits nagq > 1 for ONE grouping with <= 3 random effects; lme4 itself integrates a scalar only,
+    and the reference freezes no estimates for the vector case, so the k^q tensor rule of fit_glmm_slopes.c is pinned by
+    an independent restatement: the exact marginal likelihood (non-adaptive 48 x 48 rule) maximised with scipy.  The 9 x 9
+    adaptive rule sits on that optimum, the Laplace fit does not; q = 1 through the vector code is the scalar AGQ fit."""
+    from scipy.optimize import minimize
+    spec, _, a, low = load_case("glmm_intercept")
+    spec.cluster = S.ClusterSpec(sizing=("FixedClusters", 24), tau_squared=1.5,
+                                 slopes=[{"column": 0, "variance": 0.6, "corr_with_intercept": 0.3, "corr_with": []}])
     spec.cluster_slope_design_cols = [1]
-    with pytest.raises(Exception):
-        oracle.run_batch(spec, [600], 2, 2404, n_threads=2)
+    spec.scenario.truth_start = True
+    x, y, ids, _ = oracle.generate_sim_data_ids(spec, 777, 0, 288)   # 24 clusters of 12
+    th0, b0 = oracle.truth_theta(spec, True), spec.effect_sizes
+    lap = oracle.glmm_slopes_fit(x, y, ids, [1], theta_start=th0, beta_start=b0)
+    agq = oracle.glmm_slopes_fit(x, y, ids, [1], theta_start=th0, beta_start=b0, nagq=9)
+    assert lap["converged"] and agq["converged"] and agq["pinned"] == 0
+    xf, yf = x.astype(float), y.astype(float)
+    p_agq = np.concatenate([agq["theta"], agq["beta"]])
+    p_lap = np.concatenate([lap["theta"], lap["beta"]])
+    ref = minimize(_marginal_deviance_q2, p_agq, args=(xf, yf, ids, 1), method="Nelder-Mead",
+                   options=dict(xatol=1e-8, fatol=1e-11, maxiter=6000))
+    assert np.all(np.abs(ref.x - p_agq) < 2e-4), (ref.x, p_agq)
+    assert _marginal_deviance_q2(p_agq, xf, yf, ids, 1) <= ref.fun + 1e-6
+    assert _marginal_deviance_q2(p_lap, xf, yf, ids, 1) > ref.fun + 1e-3    # the Laplace optimum is measurably elsewhere
+    k5 = oracle.glmm_slopes_fit(x, y, ids, [1], theta_start=th0, beta_start=b0, nagq=5)
+    assert np.all(np.abs(k5["beta"] - agq["beta"]) < 5e-3)   # the 5 x 5 rule is already close (clusters of 12, tau^2 = 1.5)
+    # q = 1 through the vector code == the scalar quadrature of fit_glmm.c
+    s1 = oracle.glmm_slopes_fit(x, y, ids, [], theta_start=[1.0], beta_start=b0, nagq=7)
+    s0 = oracle.glmm_fit(x, y, ids, theta_start=1.0, beta_start=b0, nagq=7)
+    assert np.allclose(s1["beta"], s0["beta"], atol=2e-6) and abs(s1["theta"][0] - s0["theta"]) < 2e-6
+    # and through run_batch (replicate 0 of the same seed is this dataset)
+    spec.nagq = 9
+    r = oracle.run_batch(spec, [288], 4, 777, n_threads=4, stat_capture=True)
+    assert r.converged[0, 0] == 1 and np.isclose(r.tau_squared_hat[0, 0], agq["theta"][0] ** 2, rtol=1e-10)
 
 
 # ---- extra groupings under a GLM family (fit_glmm_general.c; ORACLE ONLY -- the device path refuses them) ----
