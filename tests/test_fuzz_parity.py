@@ -56,6 +56,30 @@ def test_device_matches_oracle_on_random_specs(family, seed, engine, oracle):
     assert np.array_equal(red.counters, dev.counters)
 
 
+@pytest.mark.gpu
+def test_seed_1098_of_the_first_deep_sweep_stays_a_regression_case(engine, oracle):
+    """The one device-vs-oracle mismatch of the 10 200-spec sweep: a random-intercept LMM under the `realistic` preset at
+    n = 35 / 42 with 7 clusters and a SAMPLED 4-level factor (proportions down to 0.15: ~5 rows expected).  Root cause,
+    asserted here instead of narrowing the generator around it: in the few replicates where the two sides differ a
+    sampled level is (nearly) empty or confounded with the clusters, the fitted design is numerically singular
+    (cond(X) > 1e7, i.e. cond(X'X) beyond double precision), both sides pass the reference's rank test EPS_RANK = 1e-12
+    on min|L_ii| / max|L_ii| (batch.rs:40-41) on rounding noise, and what they then return is unrelated by
+    construction -- the reference itself is not reproducible there.  Every well-conditioned replicate must agree."""
+    spec, ns, k, exact = random_spec(1098, "lme_scen", legacy_sizes=True)
+    assert ns == [35, 42] and spec.cluster.sizing == ("FixedClusters", 7) and spec.factor_n_levels == [4]
+    dev = engine.run_batch(spec, ns, k, BASE_SEED)
+    ora = oracle.run_batch(spec, ns, k, BASE_SEED, n_threads=16)
+    same = _same_replicates(dev, ora)
+    bad = np.flatnonzero(~same)
+    assert bad.size <= 6, bad
+    for sim in bad:
+        x, y, ids = oracle.generate_sim_data(spec, BASE_SEED, int(sim), ns[-1])
+        conds = [np.linalg.cond(np.asarray(x[:n], dtype=np.float64)) for n in ns]
+        assert max(conds) > 1e7, (int(sim), conds)
+    red = engine.run_batch(spec, ns, k, BASE_SEED, per_sim=False)
+    assert np.array_equal(red.counters, dev.counters)
+
+
 def test_oracle_is_thread_count_invariant_on_the_table_marginal(oracle):
     """The HighKurtosis marginal reads a lazily built t(3) table (marginals/t3.rs): replicate threads may ask for it
     at the same moment (the race this sweep found in the oracle's first version of the build)."""
