@@ -34,7 +34,7 @@ constexpr uint32_t GLMM_MAX_EVAL = 30000;
 constexpr double GLMM_THETA_MAX = 32.0;
 constexpr double GLMM_THETA_ZERO = 1e-6;
 constexpr double GLMM_NEAR_ZERO = 1e-30;
-constexpr int GLMM_ROW = 20;  // simplex row stride (d = n_theta + P <= 12 + 6)
+constexpr int GLMM_ROW = 20;  // simplex row stride (d = n_theta + P <= 12 + 8)
 constexpr uint32_t GG_MAX_TERMS = 3;
 
 typedef __attribute__((address_space(3))) double gdd;
@@ -43,7 +43,7 @@ typedef __attribute__((address_space(3))) float gdf;
 typedef __attribute__((address_space(3))) uint16_t gdu;
 
 struct GlmmLds {
-  gdd *eta0, *wrow, *res, *M, *u, *ut, *r, *un, *C, *T, *av, *simplex, *fv, *tail, *lx;
+  gdd *eta0, *wrow, *res, *M, *u, *ut, *r, *un, *C, *T, *av, *simplex, *fv, *tail;
   uint32_t ao[GG_MAX_TERMS];  // plane of term t's first entry in av (planes of n_pad rows)
   gdf *design, *draws;
   gdu* lvl;          // level of a row in extra term t at lvl[(t - 1) * n_pad + i]
@@ -54,6 +54,8 @@ struct GlmmLds {
   uint32_t R, RS;    // random effects in total, row stride of M (odd: lanes on different rows spread over the banks)
   uint32_t off[GG_MAX_TERMS], doff[GG_MAX_TERMS], diag_mask;
 };
+
+#include "mcp_glmm_tail.hpp"
 
 __device__ __forceinline__ void gq_sync() { __syncthreads(); }
 
@@ -561,8 +563,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     }
     m.simplex = q; q += (size_t)(dmax + 4u) * GLMM_ROW;
     m.fv = q; q += (dmax + 2u) & ~1u;
-    m.tail = q; q += 8;
-    m.lx = q; q += 36;  // P x P factor of the Wald precision (P <= 6)
+    m.tail = q; q += 8 + 64 + 64 + 64 + 8 + 8;  // the once-per-fit tail block of mcp_glmm_tail.hpp
     gdf* f = (gdf*)q;
     m.design = f; f += (size_t)P * n_pad;
     m.draws = (gdf*)m.av;
@@ -800,45 +801,6 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
     gdd* xe = xr + GLMM_ROW;
     gdd* Hm = sx + GLMM_ROW;  // H[a][b] at Hm[a * GLMM_ROW + b]
     const double inf = __builtin_inf(), dl = 1e-4;
-    // lower Cholesky factor of a packed precision matrix over the kept columns; a dropped column is an identity row /
-    // column: the kept block factors as the gathered system
-    auto factor = [&](const double (&Ap)[P * (P + 1) / 2], double (&L)[P][P]) -> bool {
-      bool fok = true;
-      int idx = 0;
-      double Af[P][P];
-#pragma unroll
-      for (int r = 0; r < P; ++r)
-#pragma unroll
-        for (int s2 = 0; s2 <= r; ++s2) {
-          const double v = Ap[idx++];
-          Af[r][s2] = (((keep >> r) & 1u) && ((keep >> s2) & 1u)) ? v : (r == s2 ? 1.0 : 0.0);
-        }
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        double dd = Af[j][j];
-#pragma unroll
-        for (int t = 0; t < j; ++t) dd -= L[j][t] * L[j][t];
-        fok = fok && (dd > 0.0) && (dd < __builtin_inf());
-        L[j][j] = __builtin_sqrt(dd);
-#pragma unroll
-        for (int i = j + 1; i < P; ++i) {
-          double v = Af[i][j];
-#pragma unroll
-          for (int t = 0; t < j; ++t) v -= L[i][t] * L[j][t];
-          L[i][j] = v / L[j][j];
-        }
-      }
-      return fok;
-    };
-    auto store_factor = [&](const double (&L)[P][P]) {
-      if (lane == 0u) {
-#pragma unroll
-        for (int r = 0; r < P; ++r)
-#pragma unroll
-          for (int s2 = 0; s2 < P; ++s2) m.lx[r * P + s2] = s2 <= r ? L[r][s2] : 0.0;
-      }
-      gq_sync();
-    };
     int st = S_NM_BEGIN, run = 0, restart = 0;
     uint32_t n_eval = 0, vi = 0, lo = 0, hi = 0, snap_k = 0, ha = 0, hb = 0, th_free = 0u, stat_k = 0;
     int hq = 0;
@@ -1154,9 +1116,17 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
 #pragma unroll
               for (int i = 0; i < P * (P + 1) / 2; ++i) A[i] = gq_wave_sum(A[i]) - gq_wave_sum(dd[i]);
             }
-            double Lr[P][P];
-            ok = factor(A, Lr) && ok;
-            store_factor(Lr);
+            // the factor of the "rx" precision, in the LDS tail (mcp_glmm_tail.hpp): nothing of size P^2 stays in registers
+            if (lane == 0u) {
+              int idx = 0;
+#pragma unroll
+              for (int r = 0; r < P; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 <= r; ++s2) m.tail[GT_LX + r * 8 + s2] = A[idx++];
+              m.tail[GT_SPARE] = glmm_tail_factor(m.tail + GT_LX, m.tail + GT_LX, (uint32_t)P, keep) ? 1.0 : 0.0;
+            }
+            gq_sync();
+            ok = (m.tail[GT_SPARE] != 0.0) && ok;
             if (prm.glmm_hessian && ok) {
               // Wald SE mode "hessian": lme4's deriv12 stencil (delta = 1e-4) over the FREE covariance parameters and beta
               // (a pinned diagonal is an even point of the deviance and drops out); a block that does not factor keeps "rx"
@@ -1258,23 +1228,8 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
             gq_sync();
             const bool okh = xe[0] != 0.0;
             gq_sync();
-            if (okh) {
-              double Ah[P * (P + 1) / 2], Lh[P][P];
-              int idx = 0;
-              uint32_t kr = 0;
-#pragma unroll
-              for (int r = 0; r < P; ++r) {
-                uint32_t kc = 0;
-#pragma unroll
-                for (int s2 = 0; s2 <= r; ++s2) {
-                  const bool both = ((keep >> r) & 1u) && ((keep >> s2) & 1u);
-                  Ah[idx++] = both ? Hm[(size_t)(nth + kr) * GLMM_ROW + nth + kc] : 0.0;
-                  kc += ((keep >> s2) & 1u) ? 1u : 0u;
-                }
-                kr += ((keep >> r) & 1u) ? 1u : 0u;
-              }
-              if (factor(Ah, Lh)) store_factor(Lh);
-            }
+            if (okh && lane == 0u) glmm_tail_take_hessian(m.tail, Hm, (uint32_t)GLMM_ROW, nth, (uint32_t)P, keep);
+            gq_sync();
             st = S_DECIDE;
           } break;
           default: st = S_DECIDE; break;
@@ -1296,11 +1251,6 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
       n_eval += count ? 1u : 0u;
       f = glmm_eval<P>(prm, m, pt, lane, n, ncl, n_pad, keep);
     }
-    double Lx[P][P];
-#pragma unroll
-    for (int r = 0; r < P; ++r)
-#pragma unroll
-      for (int s2 = 0; s2 < P; ++s2) Lx[r][s2] = m.lx[r * P + s2];
     bool conv = ok;
     bool at_upper = false;
     uint32_t pinned = 0u;
@@ -1322,108 +1272,17 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
       for (uint32_t k = 0; k < 12u; ++k) carry[k] = k < nth ? x0[k] : 0.0;
       has_prev = true;
     }
-    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions ----
-    double beta[P];
-    {
+    // ---- Wald z^2 (dispersion 1), joint Wald chi2 over the targets vs chi2_ppf(1 - alpha, k), decisions: ONE lane over
+    //      the LDS tail (mcp_glmm_tail.hpp) ----
+    if (lane == 0u) {
       uint32_t k = nth;
-#pragma unroll
-      for (int c = 0; c < P; ++c) {
+      for (uint32_t c = 0; c < (uint32_t)P; ++c) {
         const bool kept = (keep >> c) & 1u;
-        beta[c] = kept ? x0[k] : 0.0;
+        m.tail[GT_BETA + c] = kept ? x0[k] : 0.0;
         k += kept ? 1u : 0u;
       }
-    }
-    const double* crow = prm.crit + (size_t)g * prm.crit_stride;
-    double tsq[MAX_T_WAVE];
-    double U[MAX_T_WAVE][P];
-#pragma unroll
-    for (int t = 0; t < MAX_T_WAVE; ++t) {
-      tsq[t] = __builtin_nan("");
-#pragma unroll
-      for (int i = 0; i < P; ++i) U[t][i] = 0.0;
-      if ((uint32_t)t < nt && conv) {
-        const double* c = prm.contrast + t * MAX_P;
-        double est = 0.0, nq = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          est = __builtin_fma(c[i], beta[i], est);
-          double acc = c[i];
-#pragma unroll
-          for (int q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i][q], U[t][q], acc);
-          U[t][i] = acc / Lx[i][i];
-          nq = __builtin_fma(U[t][i], U[t][i], nq);
-        }
-        if (nq > GLMM_NEAR_ZERO && nq < __builtin_inf()) tsq[t] = est * est / nq;
-      }
-    }
-    bool joint_sig = false;
-    if (conv && nt != 0u) {
-      double Lc[MAX_T_WAVE][MAX_T_WAVE], cj[MAX_T_WAVE];
-      bool jok = true;
-      double qsum = 0.0;
-#pragma unroll
-      for (int j = 0; j < MAX_T_WAVE; ++j) {
-        if ((uint32_t)j < nt) {
-          double dd = 0.0;
-#pragma unroll
-          for (int i = 0; i < P; ++i) dd = __builtin_fma(U[j][i], U[j][i], dd);
-#pragma unroll
-          for (int t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j][t], Lc[j][t], dd);
-          jok = jok && (dd > 0.0);
-          Lc[j][j] = __builtin_sqrt(dd);
-#pragma unroll
-          for (int i2 = j + 1; i2 < MAX_T_WAVE; ++i2) {
-            if ((uint32_t)i2 < nt) {
-              double vv = 0.0;
-#pragma unroll
-              for (int i = 0; i < P; ++i) vv = __builtin_fma(U[i2][i], U[j][i], vv);
-#pragma unroll
-              for (int t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2][t], Lc[j][t], vv);
-              Lc[i2][j] = vv / Lc[j][j];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MAX_T_WAVE; ++i) {
-        if ((uint32_t)i < nt) {
-          const double* c = prm.contrast + i * MAX_P;
-          double vv = 0.0;
-#pragma unroll
-          for (int q = 0; q < P; ++q) vv = __builtin_fma(c[q], beta[q], vv);
-#pragma unroll
-          for (int t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i][t], cj[t], vv);
-          cj[i] = vv / Lc[i][i];
-          qsum = __builtin_fma(cj[i], cj[i], qsum);
-        }
-      }
-      joint_sig = jok && (qsum < __builtin_inf()) && (qsum > prm.joint_crit_k[nt]);
-    }
-    uint32_t unc_bits = 0, cor_bits = 0;
-    decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
-    if (!conv) {
-      unc_bits = 0;
-      cor_bits = 0;
-    }
-    if (lane == 0u) {
-      const size_t cell = (size_t)(prm.out_base + lsim) * prm.n_grid + g;
-#pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t)
-        if ((uint32_t)t < nt) {
-          prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
-          prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
-        }
-      prm.conv[cell] = conv ? 1 : 0;
-      prm.boundary[cell] = (uint8_t)bh;
-      prm.joint[cell] = joint_sig ? 1 : 0;
-      if (prm.pinned) prm.pinned[cell] = (uint16_t)pinned;
-      if (prm.tau_hat) prm.tau_hat[cell] = conv ? th0 * th0 : __builtin_nan("");
-      if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1750-1753
-      if (prm.stat && g == 0u) {
-#pragma unroll
-        for (int t = 0; t < MAX_T_WAVE; ++t)
-          if ((uint32_t)t < nt) prm.stat[(size_t)(prm.out_base + lsim) * nt + t] = tsq[t];
-      }
+      glmm_tail_decide(prm, m.tail, (uint32_t)P, nt, conv, bh, pinned, th0 * th0, prm.crit + (size_t)g * prm.crit_stride,
+                       (size_t)(prm.out_base + lsim) * prm.n_grid + g, (size_t)(prm.out_base + lsim), g == 0u);
     }
     gq_sync();
   }
@@ -1442,7 +1301,7 @@ size_t glmm_general_lds_bytes(const SimParams& prm) {
   // the av cache (na n_pad doubles) and the generator's draws + staging share one region
   const size_t av_d = na * n_pad, gen_d = (((nd + 1) & ~(size_t)1) + (size_t)4 * (P + 1) * QW + 1) / 2;
   const size_t dbl = 3 * n_pad + (av_d > gen_d ? av_d : gen_d) + R * RS + 4 * R + R * P + 28 + (dmax + 4) * GLMM_ROW +
-                     ((dmax + 2) & ~(size_t)1) + 8 + 36;
+                     ((dmax + 2) & ~(size_t)1) + 216;
   size_t so = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) so += (size_t)prm.lmg_levels[t] + 2;
   const size_t flt = P * n_pad + 2 * ((prm.lmg_n_terms - 1) * n_pad / 2 + 2) + (so + 3) / 2 + 1;
@@ -1463,7 +1322,7 @@ hipError_t launch_glmm_general(int P, const SimParams* d_prm, uint32_t n_sims, s
     else hipLaunchKernelGGL((glmm_general_kernel<PP, false>), grid, block, lds, st, d_prm);                            \
   } break;
   switch (P) {
-    GQ(2) GQ(3) GQ(4) GQ(5) GQ(6)
+    GQ(2) GQ(3) GQ(4) GQ(5) GQ(6) GQ(7) GQ(8)
     default: return hipErrorInvalidValue;
   }
 #undef GQ

@@ -706,7 +706,7 @@ hipError_t launch_glmm_slopes(int P, int Q, const SimParams* d_prm, uint32_t n_s
     else hipLaunchKernelGGL((glmm_slopes_kernel<PP, QQ, false>), grid, block, lds, st, d_prm);                         \
     return hipGetLastError();                                                                                          \
   }
-  GQ(2, 2) GQ(3, 2) GQ(3, 3) GQ(4, 2) GQ(4, 3) GQ(5, 2) GQ(5, 3) GQ(6, 2) GQ(6, 3)
+  GQ(2, 2) GQ(3, 2) GQ(3, 3) GQ(4, 2) GQ(4, 3) GQ(5, 2) GQ(5, 3) GQ(6, 2) GQ(6, 3) GQ(7, 2) GQ(7, 3) GQ(8, 2) GQ(8, 3)
 #undef GQ
   return hipErrorInvalidValue;
 }

@@ -477,7 +477,7 @@ __device__ __forceinline__ void lmg_clamp(const SimParams& prm, ldd* x, uint32_t
 template <int P, int Q0, bool SCEN>
 // (three random effects on the primary grouping -- and the general-path variants with a slope and four or more columns, 12 B over --
 // get 256 registers instead of 168, or the block algebra spills; those designs are LDS-bound below 3 waves per SIMD anyway)
-__global__ __launch_bounds__(GW, ((Q0 >= 3 || (SCEN && P >= 4 && Q0 == 2)) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
+__global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 == 2)) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;

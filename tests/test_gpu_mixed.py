@@ -178,3 +178,35 @@ def test_cluster_level_predictors_under_general_lmm_and_clustered_glm(engine, or
     assert same.sum() >= 47 and dev.converged.mean() > 0.9
     both = (dev.converged == 1) & (ora.converged == 1)
     assert np.allclose(dev.tau_squared_hat[both], ora.tau_squared_hat[both], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("family,k,structure", [("lmm", 6, "slope"), ("lmm", 7, "crossed"), ("lmm", 7, "multislope"),
+                                                ("logit", 6, "slope"), ("logit", 7, "multislope"), ("logit", 7, "crossed")])
+def test_seven_and_eight_design_columns_under_slopes_and_extra_groupings(family, k, structure, engine, oracle):
+    """The reference has no column limit on mixed models (spec.rs:251-417; only MAX_PRIMARY_Q / MAX_EXTRA_Q /
+    MAX_EXTRA_GROUPINGS, generation.rs:256-259).  Round 2 stopped the general LMM and the clustered GLM with slopes or extra
+    groupings at 6 design columns; the kernels are instantiated to 8 (= the wave-per-replicate estimators' width) now."""
+    from mcpower_amd.workloads import _mixed
+    eff = [(-0.85 if family == "logit" else 0.0)] + [0.25, 0.2, 0.0, 0.15, -0.2, 0.1, 0.0][:k]
+    corr = (np.eye(k) + 0.15 * (np.ones((k, k)) - np.eye(k))).ravel().tolist()
+    sl0 = {"column": 0, "variance": 0.12, "corr_with_intercept": 0.3, "corr_with": []}
+    sl1 = {"column": 1, "variance": 0.08, "corr_with_intercept": 0.0, "corr_with": [0.2]}
+    slopes = [sl0] if structure in ("slope", "crossed") else [sl0, sl1]
+    extra = [{"relation": {"Crossed": {"n_clusters": 6}}, "tau_squared": 0.15, "slopes": []}] if structure == "crossed" else []
+    tau2 = 0.8 if family == "logit" else 0.3
+    spec = _mixed(family, k, eff, 24, tau2, slopes=slopes, extra=extra, correlation=corr)
+    spec.target_indices = [1, 2, k]
+    assert spec.n_predictors == k + 1
+    n = 24 * 6 * 4 if structure == "crossed" else 480
+    n_sims = 24
+    dev, stat = engine.run_batch_st_capture(spec, [n], n_sims, BASE_SEED)
+    ora = oracle.run_batch(spec, [n], n_sims, BASE_SEED, n_threads=8, stat_capture=True)
+    assert dev.converged.mean() > 0.8
+    same = ((dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+            & (dev.boundary_hit == ora.boundary_hit).all(axis=1) & (dev.joint_unc == ora.joint_unc).all(axis=1)
+            & (dev.pinned_components == ora.pinned_components).all(axis=1))
+    assert same.sum() >= n_sims - 1, np.flatnonzero(~same)
+    both = (dev.converged[:, 0] == 1) & (ora.converged[:, 0] == 1) & same
+    assert np.allclose(stat[both], ora.stat_capture[both], rtol=2e-5, atol=1e-8)
+    red = engine.run_batch(spec, [n], n_sims, BASE_SEED, per_sim=False)
+    assert np.array_equal(red.counters, dev.counters)

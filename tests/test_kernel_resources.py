@@ -17,10 +17,10 @@ BUILD = os.path.join(ROOT, "mcpower_amd", "csrc", "_build")
 # object -> (kernel name, minimum number of instantiations expected in it)
 OBJECTS = {
     "glmm_kernels.o": ("glmm_kernel", 14),
-    "glmm_slopes_kernels.o": ("glmm_slopes_kernel", 18),
-    "glmm_general_kernels.o": ("glmm_general_kernel", 10),
-    "lmm_general_kernels.o": ("lmm_general_kernel", 14),
-    "lmm_general_scen_kernels.o": ("lmm_general_kernel", 14),
+    "glmm_slopes_kernels.o": ("glmm_slopes_kernel", 26),
+    "glmm_general_kernels.o": ("glmm_general_kernel", 14),
+    "lmm_general_kernels.o": ("lmm_general_kernel", 20),
+    "lmm_general_scen_kernels.o": ("lmm_general_kernel", 20),
 }
 
 
