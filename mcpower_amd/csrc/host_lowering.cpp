@@ -490,6 +490,29 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       prm.lmg_n_theta = toff;
       prm.lmg_R = roff;
       prm.lmg_W = roff + P + 1;
+      {
+        // fit view (mcp_params.hpp): eliminate the nested grouping with the most levels per parent when its random-effect
+        // width equals the primary's (the kernel is instantiated on one width); oracle/fit_lmm_general.c takes the same choice
+        uint32_t E = 0;
+        if (spec->estimator == MCP_EST_MLE)
+          for (uint32_t t = 1; t < prm.lmg_n_terms; ++t)
+            if (prm.lmg_relation[t] == 1u && prm.lmg_q[t] == prm.lmg_q[0] && prm.lmg_count[t] >= 2u &&
+                (E == 0u || prm.lmg_count[t] > prm.lmg_count[E])) E = t;
+        prm.lmg_elim = E;
+        prm.lmg_cpe = E ? prm.lmg_count[E] : 1u;
+        uint32_t fro = 0, nr = 0;
+        for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) {
+          if (t == E) continue;
+          prm.lmg_frest[nr++] = t;
+          prm.lmg_froff[t] = fro;
+          fro += prm.lmg_levels[t] * prm.lmg_q[t];
+          prm.lmg_frel[t] = t == 0u ? 1u : prm.lmg_relation[t];
+          prm.lmg_fcnt[t] = t == 0u ? 1u : prm.lmg_count[t];
+        }
+        prm.lmg_n_rest = nr;
+        prm.lmg_fR = fro;
+        prm.lmg_fW = fro + P + 1;
+      }
       // sequential-stream layout (data_gen.rs:146-284): primary intercepts, primary slopes, every extra grouping's
       // intercepts, then every extra grouping's slopes -- in units of one random-effect draw
       // (re_draws_per_cluster words each: 1 for Normal, df or 1 + df for the scenario's other shapes)
@@ -501,7 +524,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) { prm.lmg_seq[2 * t + 1] = seq; seq += prm.lmg_levels[t] * (prm.lmg_q[t] - 1); }
       prm.n_seq_pre = seq * prm.re_draws_per_cluster;
       if (prm.lmg_n_theta > (uint32_t)LMG_MAX_THETA) return unsupported("random-effect structures with more than 12 covariance parameters");
-      if (prm.lmg_W > 128u) return unsupported("extra groupings with more than ~120 random-effect columns in total");
+      if ((spec->estimator == MCP_EST_MLE ? prm.lmg_fW : prm.lmg_W) > 128u) return unsupported("extra groupings with more than ~120 random-effect columns in total");
     }
   }
   prm.truth_start = spec->scenario.truth_start ? 1u : 0u;

@@ -78,6 +78,13 @@ struct LmgLds {
   float* st;  // staging of the row generator (generic: shared with mcp_rows.hpp)
 };
 
+// fit view (mcp_params.hpp): the term that owns column i < fR of the dense rest block
+__device__ __forceinline__ uint32_t lmg_rest_term(const SimParams& prm, uint32_t i) {
+  uint32_t r = 0;
+  while (r + 1u < prm.lmg_n_rest && i >= prm.lmg_froff[prm.lmg_frest[r + 1u]]) ++r;
+  return prm.lmg_frest[r];
+}
+
 // template entries T_t[r][c] of every term from theta (column-major vech per term, mixed_workspace.rs:189-196)
 __device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* th, ldd* tm, uint32_t lane) {
   if (lane < 27u) {
@@ -98,7 +105,7 @@ __device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* t
 // when a pivot fails); leaves sigma^2 in misc[0], beta in tail[0..p), the lower factor of RX'RX in tail[8 + a*8 + b].
 template <int Q0>
 __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows) {
-  const uint32_t W = prm.lmg_W, R = prm.lmg_R, p = prm.P, L0 = prm.lmg_levels[0];
+  const uint32_t W = prm.lmg_fW, R = prm.lmg_fR, p = prm.P, E = prm.lmg_elim, L0 = prm.lmg_levels[E], cpe = prm.lmg_cpe;
   const double inf = __builtin_inf();
   lmg_templates(prm, th, m.tm, lane);
   lmg_sync();
@@ -107,20 +114,18 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
     // block of row index i
     uint32_t ti = 0, bi = 0, qi = 1, si = i;
     if (i < R) {
-      ti = 1;
-      while (ti + 1u < prm.lmg_n_terms && i >= prm.lmg_roff[ti + 1u]) ++ti;
+      ti = lmg_rest_term(prm, i);
       qi = prm.lmg_q[ti];
-      const uint32_t rel = i - prm.lmg_roff[ti];
+      const uint32_t rel = i - prm.lmg_froff[ti];
       bi = rel % qi;
       si = i - bi;
     }
     for (uint32_t j = lane; j <= i; j += GW) {
       uint32_t tj = 0, bj = 0, qj = 1, sj = j;
       if (j < R) {
-        tj = 1;
-        while (tj + 1u < prm.lmg_n_terms && j >= prm.lmg_roff[tj + 1u]) ++tj;
+        tj = lmg_rest_term(prm, j);
         qj = prm.lmg_q[tj];
-        const uint32_t rel = j - prm.lmg_roff[tj];
+        const uint32_t rel = j - prm.lmg_froff[tj];
         bj = rel % qj;
         sj = j - bj;
       }
@@ -151,7 +156,7 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
 #pragma unroll
   for (int r = 0; r < Q0; ++r)
 #pragma unroll
-    for (int c = 0; c < Q0; ++c) T0[r][c] = m.tm[r * 3 + c];
+    for (int c = 0; c < Q0; ++c) T0[r][c] = m.tm[E * 9u + r * 3 + c];
   for (uint32_t c = lane; c < L0; c += GW) {
     const ldd* G = m.gzz + (size_t)c * Q0 * Q0;
     double A[Q0][Q0], Lc[Q0][Q0], pdc = 1.0;
@@ -187,14 +192,16 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
         }
     }
     m.ld[c] = log(pdc);
-    // columns this level can meet: every crossed column, its own nested children, X and y
-    for (uint32_t tj = 1; tj <= prm.lmg_n_terms; ++tj) {
-      const bool xy = tj == prm.lmg_n_terms;
+    // columns this level can meet: every crossed column, the columns of its own primary level (nested children; the
+    // parent itself when a nested grouping is the eliminated one), X and y
+    for (uint32_t rj = 0; rj <= prm.lmg_n_rest; ++rj) {
+      const bool xy = rj == prm.lmg_n_rest;
+      const uint32_t tj = xy ? 0u : prm.lmg_frest[rj];
       const uint32_t qj = xy ? 1u : prm.lmg_q[tj];
       uint32_t jlo, jhi;
       if (xy) { jlo = R; jhi = W; }
-      else if (prm.lmg_relation[tj] == 1u) { jlo = prm.lmg_roff[tj] + c * prm.lmg_count[tj] * qj; jhi = jlo + prm.lmg_count[tj] * qj; }
-      else { jlo = prm.lmg_roff[tj]; jhi = jlo + prm.lmg_levels[tj] * qj; }
+      else if (prm.lmg_frel[tj] == 1u) { jlo = prm.lmg_froff[tj] + (c / cpe) * prm.lmg_fcnt[tj] * qj; jhi = jlo + prm.lmg_fcnt[tj] * qj; }
+      else { jlo = prm.lmg_froff[tj]; jhi = jlo + prm.lmg_levels[tj] * qj; }
       for (uint32_t sj = jlo; sj < jhi; sj += qj) {
         for (uint32_t bj = 0; bj < qj; ++bj) {
           const uint32_t j = sj + bj;
@@ -233,26 +240,25 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
   {
     const uint32_t KT = L0 * Q0;
     for (uint32_t i = 0; i < W; ++i) {
-      // a nested child column only meets its own parent's rows of B
+      // a column tied to one primary level only meets the rows of B of that level's eliminated blocks
       uint32_t pi = 0xffffffffu;
       if (i < R) {
-        uint32_t ti = 1;
-        while (ti + 1u < prm.lmg_n_terms && i >= prm.lmg_roff[ti + 1u]) ++ti;
-        if (prm.lmg_relation[ti] == 1u) pi = ((i - prm.lmg_roff[ti]) / prm.lmg_q[ti]) / prm.lmg_count[ti];
+        const uint32_t ti = lmg_rest_term(prm, i);
+        if (prm.lmg_frel[ti] == 1u) pi = ((i - prm.lmg_froff[ti]) / prm.lmg_q[ti]) / prm.lmg_fcnt[ti];
       }
       for (uint32_t j = lane; j <= i; j += GW) {
         uint32_t pj = 0xffffffffu;
         if (j < R) {
-          uint32_t tj = 1;
-          while (tj + 1u < prm.lmg_n_terms && j >= prm.lmg_roff[tj + 1u]) ++tj;
-          if (prm.lmg_relation[tj] == 1u) pj = ((j - prm.lmg_roff[tj]) / prm.lmg_q[tj]) / prm.lmg_count[tj];
+          const uint32_t tj = lmg_rest_term(prm, j);
+          if (prm.lmg_frel[tj] == 1u) pj = ((j - prm.lmg_froff[tj]) / prm.lmg_q[tj]) / prm.lmg_fcnt[tj];
         }
         uint32_t klo = 0, khi = KT;
-        if (pi != 0xffffffffu) { klo = pi * Q0; khi = klo + Q0; }
+        if (pi != 0xffffffffu) { klo = pi * cpe * Q0; khi = klo + cpe * Q0; }
         if (pj != 0xffffffffu) {
-          if (pi != 0xffffffffu && pi != pj) khi = klo;  // children of different parents never share a row
-          else { klo = pj * Q0; khi = klo + Q0; }
+          if (pi != 0xffffffffu && pi != pj) khi = klo;  // columns of different primary levels never share a row
+          else { klo = pj * cpe * Q0; khi = klo + cpe * Q0; }
         }
+        khi = khi < KT ? khi : KT;
         double sacc = m.S[lmg_tri(i, j)];
         for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
         m.S[lmg_tri(i, j)] = sacc;
@@ -324,19 +330,20 @@ struct LmgRed {
 // view column (reduced rest | X | y) -> column of the full layout
 __device__ __forceinline__ uint32_t lmg_red_col(const SimParams& prm, uint32_t i, uint32_t Rr, uint32_t& term) {
   term = 0u;
-  if (i >= Rr) return prm.lmg_R + (i - Rr);
-  uint32_t t = 1u, off = 0u;
-  while (t + 1u < prm.lmg_n_terms && i >= off + prm.lmg_levels[t]) { off += prm.lmg_levels[t]; ++t; }
+  if (i >= Rr) return prm.lmg_fR + (i - Rr);
+  uint32_t r = 0u, off = 0u;
+  while (r + 1u < prm.lmg_n_rest && i >= off + prm.lmg_levels[prm.lmg_frest[r]]) { off += prm.lmg_levels[prm.lmg_frest[r]]; ++r; }
+  const uint32_t t = prm.lmg_frest[r];
   term = t;
-  return prm.lmg_roff[t] + (i - off) * prm.lmg_q[t];
+  return prm.lmg_froff[t] + (i - off) * prm.lmg_q[t];
 }
 
 template <int Q0F>
 __device__ __forceinline__ double lmg_eval_red(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows,
                                             const LmgRed red) {
-  const uint32_t Wf = prm.lmg_W, p = prm.P, L0 = prm.lmg_levels[0], nterms = prm.lmg_n_terms;
+  const uint32_t Wf = prm.lmg_fW, p = prm.P, E = prm.lmg_elim, L0 = prm.lmg_levels[E];
   uint32_t Rr = 0;
-  for (uint32_t t = 1; t < nterms; ++t) Rr += prm.lmg_levels[t];
+  for (uint32_t r = 0; r < prm.lmg_n_rest; ++r) Rr += prm.lmg_levels[prm.lmg_frest[r]];
   const uint32_t W = Rr + p + 1u, M = Rr + p;
   const double inf = __builtin_inf();
   auto theta_of = [&](uint32_t term) { return th[term]; };
@@ -366,7 +373,7 @@ __device__ __forceinline__ double lmg_eval_red(const SimParams& prm, const LmgLd
   double logdet = 0.0, pd = 1.0;
   uint32_t npd = 0;
   bool ok = true;
-  const double t0 = th[0];
+  const double t0 = th[E];
   for (uint32_t c = lane; c < L0; c += GW) {
     const double g = m.gzz[(size_t)c * Q0F * Q0F];
     const double dd = 0.0 + t0 * g * t0 + 1.0;
@@ -475,9 +482,10 @@ __device__ __forceinline__ void lmg_clamp(const SimParams& prm, ldd* x, uint32_t
 // SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
 // heteroskedastic residuals) plus the LME knobs -- random-effect shape, one ICC jitter per grouping
 template <int P, int Q0, bool SCEN>
-// (three random effects on the primary grouping -- and the general-path variants with a slope and four or more columns, 12 B over --
-// get 256 registers instead of 168, or the block algebra spills; those designs are LDS-bound below 3 waves per SIMD anyway)
-__global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 == 2)) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
+// (three random effects on the eliminated grouping, seven or more design columns, and a slope on the general data path or with six
+// columns -- 12 B over -- get 256 registers instead of 168, or the block algebra spills; those designs are LDS-bound below 3 waves
+// per SIMD anyway)
+__global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >= 6))) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
@@ -486,13 +494,14 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 ==
   const uint64_t key = pcg_mix64(prm.base_seed, sim_id);
   const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
   const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
-  const uint32_t W = prm.lmg_W, R = prm.lmg_R, L0 = prm.lmg_levels[0], d = prm.lmg_n_theta, nterms = prm.lmg_n_terms;
+  const uint32_t W = prm.lmg_fW, R = prm.lmg_fR, L0 = prm.lmg_levels[0], d = prm.lmg_n_theta, nterms = prm.lmg_n_terms;
+  const uint32_t E = prm.lmg_elim, LE = prm.lmg_levels[E];  // fit view (mcp_params.hpp): the grouping eliminated block by block
   LmgLds m;
   {
     // persistent: the sufficient statistics, the sparse-row scratch of their accumulation, the theta carry, the design
     ldd* q = (ldd*)lds_d;
-    m.gzz = q; q += (size_t)L0 * Q0 * Q0;
-    m.gzw = q; q += (size_t)L0 * Q0 * W;
+    m.gzz = q; q += (size_t)LE * Q0 * Q0;
+    m.gzw = q; q += (size_t)LE * Q0 * W;
     m.gww = q; q += lmg_tri(W, 0u);  // lower triangles, packed by rows
     m.rval = q; q += LMG_MAX_NZ;
     m.carry = q; q += LMG_MAX_THETA;
@@ -505,8 +514,8 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 ==
     // occupancy of this latency-bound kernel: 24 -> 18 KB on the lmm_slope shape)
     ldd* e = (ldd*)f;
     m.S = e; e += lmg_tri(W, 0u);
-    m.B = e; e += (size_t)L0 * Q0 * W;
-    m.ld = e; e += L0;
+    m.B = e; e += (size_t)LE * Q0 * W;
+    m.ld = e; e += LE;
     m.simplex = e; e += (size_t)(d + 4u) * LMG_MAX_THETA;
     m.fv = e; e += d + 1u;
     m.tm = e; e += 27;
@@ -702,11 +711,11 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 ==
     }
   }
   // ---- 3. sufficient statistics, zeroed once and grown over the grid ----
-  for (size_t i = lane; i < (size_t)L0 * Q0 * Q0 + (size_t)L0 * Q0 * W + lmg_tri(W, 0u); i += GW) m.gzz[i] = 0.0;  // gzz | gzw | gww are contiguous
+  for (size_t i = lane; i < (size_t)LE * Q0 * Q0 + (size_t)LE * Q0 * W + lmg_tri(W, 0u); i += GW) m.gzz[i] = 0.0;  // gzz | gzw | gww are contiguous
   lmg_sync();
 
   uint32_t nzr = 0;  // non-zeros of the rest part of a row
-  for (uint32_t t = 1; t < nterms; ++t) nzr += prm.lmg_q[t];
+  for (uint32_t r = 0; r < prm.lmg_n_rest; ++r) nzr += prm.lmg_q[prm.lmg_frest[r]];
   const uint32_t nz = nzr + (uint32_t)P + 1u;
   bool has_prev = false;
   uint32_t prev_n = 0;
@@ -719,9 +728,10 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 ==
         uint32_t idx;
         double val;
         if (lane < nzr) {
-          uint32_t t = 1, e = lane;
-          while (e >= prm.lmg_q[t]) { e -= prm.lmg_q[t]; ++t; }
-          idx = prm.lmg_roff[t] + lmg_level_of_row(prm, t, i) * prm.lmg_q[t] + e;
+          uint32_t r = 0, e = lane;
+          while (e >= prm.lmg_q[prm.lmg_frest[r]]) { e -= prm.lmg_q[prm.lmg_frest[r]]; ++r; }
+          const uint32_t t = prm.lmg_frest[r];
+          idx = prm.lmg_froff[t] + lmg_level_of_row(prm, t, i) * prm.lmg_q[t] + e;
           val = e == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[t][e - 1u] - 1u) * dstride + di];
         } else {
           const uint32_t a = lane - nzr;  // 0..P-1 design column, P = outcome
@@ -732,7 +742,7 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 ==
         m.rval[lane] = val;
       }
       lmg_sync();
-      const uint32_t c = lmg_level_of_row(prm, 0u, i);
+      const uint32_t c = lmg_level_of_row(prm, E, i);
       for (uint32_t pr = lane; pr < nz * nz; pr += GW) {
         const uint32_t a = pr / nz, b = pr % nz;
         const uint32_t ia = m.ridx[a], ib = m.ridx[b];
@@ -740,14 +750,14 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (SCEN && P >= 4 && Q0 ==
       }
       for (uint32_t pr = lane; pr < (uint32_t)Q0 * nz; pr += GW) {
         const uint32_t a = pr / nz, b = pr % nz;
-        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * dstride + di];
+        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[E][a - 1u] - 1u) * dstride + di];
         ldd* cell = m.gzw + ((size_t)c * Q0 + a) * W + m.ridx[b];
         *cell = __builtin_fma(za, m.rval[b], *cell);
       }
       if (lane < (uint32_t)(Q0 * Q0)) {
         const uint32_t a = lane / Q0, b = lane % Q0;
-        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][a - 1u] - 1u) * dstride + di];
-        const double zb = b == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[0][b - 1u] - 1u) * dstride + di];
+        const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[E][a - 1u] - 1u) * dstride + di];
+        const double zb = b == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[E][b - 1u] - 1u) * dstride + di];
         ldd* cell = m.gzz + (size_t)c * Q0 * Q0 + lane;
         *cell = __builtin_fma(za, zb, *cell);
       }

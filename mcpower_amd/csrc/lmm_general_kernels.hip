@@ -8,7 +8,7 @@ namespace mcp {
 
 // LDS bytes of one replicate
 size_t lmg_lds_bytes(const SimParams& prm) {
-  const size_t W = prm.lmg_W, L0 = prm.lmg_levels[0], q0 = prm.lmg_q[0], d = prm.lmg_n_theta;
+  const size_t W = prm.lmg_fW, LG0 = prm.lmg_levels[0], L0 = prm.lmg_levels[prm.lmg_elim], q0 = prm.lmg_q[0], d = prm.lmg_n_theta;
   const size_t tri = W * (W + 1) / 2;
   // persistent: gzz | gzw | gww | rval | carry (doubles), ridx (u32, even count), the design (f32)
   const size_t n_pad = ((size_t)prm.max_n + 3u) & ~(size_t)3u;
@@ -18,7 +18,7 @@ size_t lmg_lds_bytes(const SimParams& prm) {
   const size_t eval_bytes = (tri + L0 * q0 * W + L0 + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (8 + 64 + 64 + 64 + 8 + 8)) * 8;
   size_t nlev = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) nlev += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
-  const size_t gen_bytes = (L0 + L0 * LMG_MAX_SLOPES + nlev + (size_t)4 * (prm.P + 1) * GW) * 4;
+  const size_t gen_bytes = (LG0 + LG0 * LMG_MAX_SLOPES + nlev + (size_t)4 * (prm.P + 1) * GW) * 4;
   return persistent + (eval_bytes > gen_bytes ? eval_bytes : gen_bytes) + 64;
 }
 

@@ -188,6 +188,19 @@ struct SimParams {
   uint32_t lmg_n_theta, lmg_R, lmg_W;  // theta length; rest width; W = R + P + 1
   uint32_t lmg_seq[2 * LMG_MAX_TERMS];   // first sequential-stream word of [intercepts of term t | slopes of term t]
   uint32_t _pad_lmg;
+  // fit view of the general LMM (lmm_general_impl.hpp): the likelihood does not care which grouping is "primary", so the
+  // kernel eliminates, block by block, the grouping with the MOST levels that still has block structure -- a grouping
+  // nested in the primary one when there is such (its parents then join the dense "rest" columns: lmm_nested 20 + 80
+  // levels: dense width 86 -> 26).  lmg_elim = 0 is the generator's own order; theta stays in declaration order.
+  uint32_t lmg_elim;                  // term whose levels are eliminated one block each
+  uint32_t lmg_cpe;                   // eliminated levels per primary level (1 when lmg_elim = 0)
+  uint32_t lmg_n_rest;                // = lmg_n_terms - 1
+  uint32_t lmg_frest[LMG_MAX_TERMS];  // the other terms, declaration order
+  uint32_t lmg_froff[LMG_MAX_TERMS];  // by term id: first column inside the dense rest block
+  uint32_t lmg_frel[LMG_MAX_TERMS];   // by term id: 0 = every eliminated level meets every level of it; 1 = only those of its own primary level
+  uint32_t lmg_fcnt[LMG_MAX_TERMS];   // by term id: levels per primary level (1 for the primary grouping itself)
+  uint32_t lmg_fR, lmg_fW;            // rest width and W = fR + P + 1 in this view
+  uint32_t _pad_lmg2;
   double lmg_tau[LMG_MAX_TERMS];     // sqrt(max(tau^2, 0)) per term
   double lmg_chol[LMG_MAX_TERMS][9]; // row-major lower chol(diag(tau) R diag(tau)) per term: the slope draws
   double lmg_tau_sq[LMG_MAX_TERMS];  // spec tau^2 per term (the ICC jitter of the general path starts from it)

@@ -17,8 +17,11 @@
  *     (Bates, Maechler, Bolker, Walker 2015, J. Stat. Softw. 67(1), eqs. 39-41), beta-hat = RX^-1 cb,
  *     Var(beta-hat) = sigma-hat^2 (RX'RX)^-1, sigma-hat^2 = r^2 / (n - p).
  *
- * Factorisation order here: [primary-term blocks | all extra-term columns | X | y].  The primary blocks
- * (one q0 x q0 block per primary level) are eliminated analytically, the extra terms form one dense block.
+ * Factorisation order here: [blocks of the ELIMINATED term | columns of the other terms | X | y].  One term's levels
+ * (one q x q block each) are eliminated analytically, the other terms form one dense block.  Which term: the likelihood
+ * does not depend on it, the cost does -- `elim` (mcpo_lmm_elim_term: the grouping nested in the primary one with the
+ * most levels per parent and the primary's random-effect width, else the primary itself) names it; theta stays in
+ * declaration order.  The device kernel (lmm_general_impl.hpp) takes the same choice and the same operation order.
  * The minimiser is a bound-constrained Nelder-Mead simplex (diagonal theta >= 0, off-diagonals free) with
  * restarts -- lme4 ships the same family of optimiser as `Nelder_Mead`; the reference uses BOBYQA.
  *
@@ -41,7 +44,8 @@
 typedef struct gen_model {
   uint32_t n, p, n_terms, n_theta;
   uint32_t q[MCPO_GEN_MAX_TERMS], levels[MCPO_GEN_MAX_TERMS], theta_off[MCPO_GEN_MAX_TERMS];
-  uint32_t L0, q0, R, W;     /* primary levels / width; rest width R; W = R + p + 1 */
+  uint32_t E, n_rest, rest[MCPO_GEN_MAX_TERMS];  /* eliminated term; the other terms in declaration order */
+  uint32_t L0, q0, R, W;     /* eliminated term's levels / width; rest width R; W = R + p + 1 */
   double* gzz;               /* L0 x q0 x q0      per-level Z0'Z0 */
   double* gzw;               /* L0 x q0 x W       per-level Z0'[Zr | X | y] */
   double* gww;               /* W x W             [Zr | X | y]'[Zr | X | y] */
@@ -62,19 +66,20 @@ static void gen_free(gen_model* m) {
 
 /* sufficient statistics of rows [0, n): every quantity the criterion needs, independent of theta */
 static int gen_build(gen_model* m, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
-                     const mcpo_re_term* terms, uint32_t n_terms) {
+                     const mcpo_re_term* terms, uint32_t n_terms, uint32_t elim) {
   memset(m, 0, sizeof *m);
-  if (n_terms == 0 || n_terms > MCPO_GEN_MAX_TERMS || p > MCPO_MAX_P) return MCP_ERR_UNSUPPORTED;
-  m->n = n; m->p = p; m->n_terms = n_terms;
+  if (n_terms == 0 || n_terms > MCPO_GEN_MAX_TERMS || p > MCPO_MAX_P || elim >= n_terms) return MCP_ERR_UNSUPPORTED;
+  m->n = n; m->p = p; m->n_terms = n_terms; m->E = elim;
+  const uint32_t E = elim;
   uint32_t off = 0, roff[MCPO_GEN_MAX_TERMS] = {0};
   for (uint32_t t = 0; t < n_terms; ++t) {
     m->q[t] = terms[t].q; m->levels[t] = terms[t].n_levels; m->theta_off[t] = off;
     off += terms[t].q * (terms[t].q + 1) / 2;
-    if (t >= 1) { roff[t] = m->R; m->R += terms[t].q * terms[t].n_levels; }
+    if (t != E) { m->rest[m->n_rest++] = t; roff[t] = m->R; m->R += terms[t].q * terms[t].n_levels; }
   }
   if (off > GEN_MAX_THETA) return MCP_ERR_UNSUPPORTED;
   m->n_theta = off;
-  m->L0 = terms[0].n_levels; m->q0 = terms[0].q; m->W = m->R + p + 1;
+  m->L0 = terms[E].n_levels; m->q0 = terms[E].q; m->W = m->R + p + 1;
   const uint32_t q0 = m->q0, W = m->W;
   m->gzz = (double*)calloc((size_t)m->L0 * q0 * q0 + 1, sizeof(double));
   m->gzw = (double*)calloc((size_t)m->L0 * q0 * W + 1, sizeof(double));
@@ -88,7 +93,8 @@ static int gen_build(gen_model* m, const float* x, const float* y, uint32_t n, u
   double val[MCPO_GEN_MAX_TERMS * (1 + MCP_MAX_RE_SLOPES) + MCPO_MAX_P + 1], z0[1 + MCP_MAX_RE_SLOPES];
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t nz = 0;
-    for (uint32_t t = 1; t < n_terms; ++t) {
+    for (uint32_t r = 0; r < m->n_rest; ++r) {
+      const uint32_t t = m->rest[r];
       uint32_t lvl = terms[t].ids[i];
       if (lvl >= terms[t].n_levels) { gen_free(m); return MCP_ERR_INVALID_SPEC; }
       for (uint32_t d = 0; d < terms[t].q; ++d) {
@@ -98,9 +104,9 @@ static int gen_build(gen_model* m, const float* x, const float* y, uint32_t n, u
     }
     for (uint32_t a = 0; a < p; ++a) { idx[nz] = m->R + a; val[nz++] = a == 0 ? 1.0 : (double)x[(size_t)a * ld + i]; }
     idx[nz] = m->R + p; val[nz++] = (double)y[i];
-    uint32_t c = terms[0].ids[i];
+    uint32_t c = terms[E].ids[i];
     if (c >= m->L0) { gen_free(m); return MCP_ERR_INVALID_SPEC; }
-    for (uint32_t d = 0; d < q0; ++d) z0[d] = d == 0 ? 1.0 : (double)x[(size_t)terms[0].cols[d - 1] * ld + i];
+    for (uint32_t d = 0; d < q0; ++d) z0[d] = d == 0 ? 1.0 : (double)x[(size_t)terms[E].cols[d - 1] * ld + i];
     for (uint32_t a = 0; a < q0; ++a) {
       for (uint32_t b = 0; b < q0; ++b) m->gzz[((size_t)c * q0 + a) * q0 + b] += z0[a] * z0[b];
       double* row = m->gzw + ((size_t)c * q0 + a) * W;
@@ -121,10 +127,11 @@ static void gen_template(const gen_model* m, uint32_t t, const double* theta, do
     for (uint32_t r = c; r < q; ++r) T[r][c] = th[k++];
 }
 
-/* the "rest" columns of a W-wide vector v (terms 1..): v <- Lambda_r' v, in place per level block */
+/* the "rest" columns of a W-wide vector v (every term but the eliminated one): v <- Lambda_r' v, in place per level block */
 static void gen_lambda_t_cols(const gen_model* m, const double* theta, double* v, size_t stride) {
   uint32_t base = 0;
-  for (uint32_t t = 1; t < m->n_terms; ++t) {
+  for (uint32_t r = 0; r < m->n_rest; ++r) {
+    const uint32_t t = m->rest[r];
     double T[3][3];
     gen_template(m, t, theta, T);
     uint32_t q = m->q[t];
@@ -157,7 +164,7 @@ static void gen_evaluate(gen_model* m, const double* theta, gen_eval* e) {
   double logdet = 0.0, pd = 1.0, T0[3][3];
   uint32_t npd = 0;
 #define GEN_PIVOT(dv) do { pd *= (dv); if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; } } while (0)
-  gen_template(m, 0, theta, T0);
+  gen_template(m, m->E, theta, T0);
   for (uint32_t c = 0; c < m->L0; ++c) {
     /* A = T0' Gzz T0 + I, lower Cholesky in place */
     const double* G = m->gzz + (size_t)c * q0 * q0;
@@ -404,10 +411,22 @@ uint32_t mcpo_truth_theta(const mcp_cluster* c, int include_slopes, double* thet
   return k;
 }
 
+/* the term whose levels are eliminated one block each (the fit view of lmm_general_impl.hpp / host_lowering.cpp): the
+ * grouping nested in the primary one with the most levels per parent, when its random-effect width equals the primary's */
+uint32_t mcpo_lmm_elim_term(const mcp_cluster* c) {
+  uint32_t E = 0;
+  for (uint32_t t = 1; t <= c->n_extra_groupings; ++t) {
+    const mcp_grouping* g = &c->extra[t - 1];
+    if (g->relation == MCP_GROUPING_NESTED_WITHIN && g->slopes.n_slopes == c->slopes.n_slopes && g->count >= 2u &&
+        (E == 0 || g->count > c->extra[E - 1].count)) E = t;
+  }
+  return E;
+}
+
 int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
-                               const mcpo_re_term* terms, uint32_t n_terms, const double* theta_start, mcpo_gen_fit* f) {
+                               const mcpo_re_term* terms, uint32_t n_terms, uint32_t elim, const double* theta_start, mcpo_gen_fit* f) {
   gen_model m;
-  int rc = gen_build(&m, x, y, n, ld, p, terms, n_terms);
+  int rc = gen_build(&m, x, y, n, ld, p, terms, n_terms, elim);
   if (rc) return rc;
   gen_minimise(&m, theta_start, f);
   f->p = p;
@@ -420,7 +439,7 @@ int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint3
  * vars_out: per term the q x q covariance sigma^2 Lambda Lambda' (row-major, MAX 3 x 3 each). */
 int mcpo_lmm_general_fit(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, uint32_t n_terms,
                          const uint32_t* term_q, const uint32_t* term_levels, const uint32_t* ids,
-                         const uint32_t* slope_cols, const double* theta_start, double* beta, double* se, double* z_sq,
+                         const uint32_t* slope_cols, uint32_t elim, const double* theta_start, double* beta, double* se, double* z_sq,
                          double* theta_hat, double* sigma_sq, double* vars_out, uint8_t* converged,
                          uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval) {
   if (n_terms == 0 || n_terms > MCPO_GEN_MAX_TERMS) return MCP_ERR_UNSUPPORTED;
@@ -431,7 +450,7 @@ int mcpo_lmm_general_fit(const float* x, const float* y, uint32_t n, uint32_t ld
     for (uint32_t d = 0; d < MCP_MAX_RE_SLOPES; ++d) terms[t].cols[d] = slope_cols[t * MCP_MAX_RE_SLOPES + d];
   }
   mcpo_gen_fit f;
-  int rc = mcpo_lmm_general_fit_terms(x, y, n, ld, p, terms, n_terms, theta_start, &f);
+  int rc = mcpo_lmm_general_fit_terms(x, y, n, ld, p, terms, n_terms, elim, theta_start, &f);
   if (rc) return rc;
   *converged = (uint8_t)f.converged; *boundary_hit = f.boundary_hit; *pinned = f.pinned; *n_eval = f.n_eval;
   *sigma_sq = f.sigma_sq;

@@ -91,10 +91,11 @@ int mcpo_generate_sim_data_ids(const mcp_spec* spec, uint64_t base_seed, uint64_
 
 /* ---- general LMM on provided bytes (fit_lmm_general.c): random slopes, crossed / nested groupings --------
  * ids: n_terms x ld level ids (term 0 = primary); slope_cols: n_terms x MCP_MAX_RE_SLOPES design columns;
+ * elim: the term whose levels are eliminated block by block (0 = the primary; the result does not depend on it beyond rounding);
  * theta_start may be NULL (blind start); vars_out: n_terms x 9, sigma^2 Lambda Lambda' per term, row-major 3 x 3 */
 int mcpo_lmm_general_fit(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p, uint32_t n_terms,
                          const uint32_t* term_q, const uint32_t* term_levels, const uint32_t* ids,
-                         const uint32_t* slope_cols, const double* theta_start, double* beta, double* se, double* z_sq,
+                         const uint32_t* slope_cols, uint32_t elim, const double* theta_start, double* beta, double* se, double* z_sq,
                          double* theta_hat, double* sigma_sq, double* vars_out, uint8_t* converged,
                          uint8_t* boundary_hit, uint64_t* pinned, uint32_t* n_eval);
 

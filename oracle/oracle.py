@@ -282,7 +282,7 @@ def truth_theta(spec: S.SimulationSpec, include_slopes: bool = True):
     return out
 
 
-def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, slope_cols, theta_start=None):
+def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, slope_cols, theta_start=None, elim: int = 0):
     """General REML LMM on provided bytes.  term_ids: list of (n,) 0-based level ids, primary first;
     term_q: RE width per term (1 + slopes); slope_cols: per term the design columns of its slopes."""
     n, p = design.shape
@@ -306,7 +306,7 @@ def lmm_general_fit(design: np.ndarray, outcome: np.ndarray, term_ids, term_q, s
     rc = lib().mcpo_lmm_general_fit(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)),
                                     C.c_uint32(n), C.c_uint32(n), C.c_uint32(p), C.c_uint32(nt), q.ctypes.data_as(pu),
                                     levels.ctypes.data_as(pu), ids.ctypes.data_as(pu), cols.ctypes.data_as(pu),
-                                    None if t0 is None else t0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
+                                    C.c_uint32(elim), None if t0 is None else t0.ctypes.data_as(pd), beta.ctypes.data_as(pd),
                                     se.ctypes.data_as(pd), zsq.ctypes.data_as(pd), theta.ctypes.data_as(pd),
                                     C.byref(s2), vars_out.ctypes.data_as(pd), C.byref(conv), C.byref(bh),
                                     C.byref(pinned), C.byref(ne))

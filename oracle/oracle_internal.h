@@ -58,8 +58,9 @@ typedef struct mcpo_gen_fit {
 } mcpo_gen_fit;
 void mcpo_slope_cholesky(const mcp_re_slopes* sl, double tau0, double* l);
 uint32_t mcpo_truth_theta(const mcp_cluster* c, int include_slopes, double* theta);
+uint32_t mcpo_lmm_elim_term(const mcp_cluster* c);
 int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
-                               const mcpo_re_term* terms, uint32_t n_terms, const double* theta_start, mcpo_gen_fit* f);
+                               const mcpo_re_term* terms, uint32_t n_terms, uint32_t elim, const double* theta_start, mcpo_gen_fit* f);
 
 /* GLM family kernel shared by fit_glm.c and fit_glmm.c: IRLS weight, working response, deviance contribution */
 void mcpo_fam_eval(int fam, double eta, double yi, double* w_out, double* z_out, double* dev_out);

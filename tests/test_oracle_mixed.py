@@ -86,3 +86,22 @@ def test_reduced_round_strips_slopes_but_keeps_extra_intercepts(oracle):
     f = oracle.lmm_general_fit(x[:, :2], y, [ids, ex[0]], [1, 1], [[], []])
     crit = oracle.build_crit_table(two, [480])
     assert bool(f["z_sq"][1] > crit[0, 0]) == bool(red.uncorrected[0, 0, 0])
+
+
+@pytest.mark.parametrize("name", mixed_case_names())
+def test_the_eliminated_grouping_is_a_cost_choice_not_a_model_choice(name, oracle):
+    """fit_lmm_general.c eliminates ONE grouping's levels block by block and factors the others densely; which one is
+    `elim` (the batch takes mcpo_lmm_elim_term: a nested grouping with the most levels per parent).  The profiled
+    criterion is the same function of theta whichever grouping is eliminated: every choice lands on the lme4 golden
+    and on the elim = 0 fit."""
+    spec, _, a, low = load_case(name)
+    ids, q, cols = _terms(spec, a)
+    base = oracle.lmm_general_fit(a["design"], a["outcome"], ids, q, cols, theta_start=oracle.truth_theta(spec))
+    for e in range(1, len(ids)):
+        r = oracle.lmm_general_fit(a["design"], a["outcome"], ids, q, cols, theta_start=oracle.truth_theta(spec), elim=e)
+        assert r["converged"] == base["converged"]
+        assert np.allclose(r["beta"], base["beta"], rtol=1e-6, atol=1e-8), (name, e)
+        assert np.allclose(r["se"], base["se"], rtol=1e-5), (name, e)
+        assert np.allclose(r["theta"], base["theta"], atol=2e-4), (name, e, r["theta"], base["theta"])
+        assert np.allclose(r["beta"], a["golden_beta"], rtol=1e-4, atol=1e-6)
+        assert np.allclose(r["beta"] / r["se"], a["golden_z"], rtol=1e-4, atol=1e-5)
