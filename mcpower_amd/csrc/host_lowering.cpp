@@ -292,7 +292,6 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     return unsupported("adaptive Gauss-Hermite quadrature (nagq > 1) for a clustered GLM with extra groupings (Laplace only)");
   if (lmm_general) {
     if (spec->estimator != MCP_EST_MLE && !glmm) return unsupported("random slopes / extra groupings outside the Mle / clustered Glm estimators");
-    if (P > (uint32_t)MAX_P_WAVE) return unsupported("random slopes / extra groupings with more than 8 design columns");
     for (uint32_t t = 0; t <= spec->cluster.n_extra_groupings; ++t) {
       const mcp_re_slopes& sl = t == 0 ? spec->cluster.slopes : spec->cluster.extra[t - 1].slopes;
       if (sl.n_slopes > MCP_MAX_RE_SLOPES) return unsupported("more than 2 random slopes per grouping");
