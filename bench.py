@@ -84,6 +84,8 @@ def kernel_name(workload, p):
         return f"lmm_general_kernel<{p}>"
     if workload.startswith("glmm"):
         return {"glmm": f"glmm_kernel<{p}>", "glmm_slope": f"glmm_slopes_kernel<{p},2>"}.get(workload, f"glmm_general_kernel<{p}>")
+    if workload in ("c5_realistic", "c5_doomer"):  # general data path: split launch (ols_sim_impl.hpp, SPLIT)
+        return f"ols_sim_kernel<{p},rows,general> + ols_fit_rec_kernel<{p}>"
     return f"ols_sim_kernel<{p},fused>" if p <= 12 else f"ols_wide_kernel<{p}>"
 
 

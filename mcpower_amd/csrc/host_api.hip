@@ -23,7 +23,8 @@
 #include "mcp_params.hpp"
 
 namespace mcp {
-hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, hipStream_t st);
+hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, uint32_t n_grid, hipStream_t st);
+size_t ols_rec_fields(int P);
 hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims, bool scen, hipStream_t st);
 hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
 hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
@@ -480,6 +481,14 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     }
     if (chunk > cap) chunk = (uint32_t)(cap & ~(size_t)63);
   }
+  // general path, OLS, narrow designs: the launch is split into a row kernel and a fit kernel (ols_kernels.hip, SPLIT) with the
+  // sufficient statistics of every (replicate, grid point) between them: keep one chunk's worth under 1 GiB
+  const bool ols_split = !glm && !reduced && !staged && prm.scen_active && P <= (uint32_t)mcp::MAX_P_WAVE;
+  if (ols_split) {
+    const size_t per_rep = mcp::ols_rec_fields((int)P) * n_ns * sizeof(double);
+    const size_t cap = ((size_t)1 << 30) / per_rep;
+    if (chunk > cap) chunk = (uint32_t)(cap & ~(size_t)255);
+  }
   if (chunk > n_sims) chunk = n_sims;
   const uint32_t n_chunks = (n_sims + chunk - 1) / chunk;
 
@@ -558,6 +567,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     DEV_TRY(ar.get(S_LMM_REC, mcp::lmm_rec_fields((int)P, prm.n_clusters_max) * n_ns * lmm_stride * sizeof(double), (void**)&d_lmm_rec));
     DEV_TRY(ar.get(S_LMM_FLAGS, (size_t)n_ns * lmm_stride * sizeof(uint32_t), (void**)&d_lmm_flags));
   }
+  if (ols_split) DEV_TRY(ar.get(S_LMM_REC, mcp::ols_rec_fields((int)P) * n_ns * lmm_stride * sizeof(double), (void**)&d_lmm_rec));
   if (want_stat) DEV_TRY(ar.get(S_STAT, ((size_t)n_sims * nt + 1) * sizeof(double), (void**)&d_stat));
   // design tile: [block of 256 replicates][P columns: x1..x_{P-1}, y][max_n rows][256] f32
   // general path: per-replicate design records (lower factor, marginal / residual codes, per-study effects)
@@ -697,7 +707,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
     } else if (!staged) {
-      DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, flavor, st));
+      DEV_TRY(mcp::launch_ols_fused((int)P, d_prm + c, h_prm[c].n_sims, n_ns == 1, flavor, n_ns, st));
       DEV_TRY(hipEventRecord(e1, st));
     } else {
       DEV_TRY(mcp::launch_ols_generate((int)P, d_prm + c, h_prm[c].n_sims, flavor, st));

@@ -168,7 +168,8 @@ struct SimParams {
   double joint_crit_k[MAX_T + 1];  // chi2_ppf(1 - alpha, k): joint Wald threshold over k kept targets (Mle arm)
 
   // LMM split path: per-(replicate, grid point) cluster sums between the prepare and optimise kernels
-  double* lmm_rec;                 // [field][n_grid][lmm_rec_stride]
+  double* lmm_rec;                 // [field][n_grid][lmm_rec_stride]; the general-path OLS launch parks its sufficient
+                                   // statistics here in the same layout between its row and fit kernels (ols_kernels.hip, SPLIT)
   uint32_t* lmm_rec_flags;         // [n_grid][lmm_rec_stride]: exclusion flag bits | LMM_FLAG_BALANCED
   uint32_t lmm_rec_stride;         // replicates per chunk, padded to 64
   uint32_t lmg_stream;             // general LMM, single-size call without cluster-level columns or factors: the design

@@ -248,7 +248,9 @@ __device__ __forceinline__ void row_ctx_init(const SimParams& prm, RowCtx<P>& cx
 }
 
 // the design row: continuous block, factor dummies, bootstrap copies, interactions; returns the residual draw
-template <int P, bool FACTORS, int STRIDE, bool SCEN>
+// PREMIXED (general path, lane-per-replicate kernel): the staging area already holds the mixed and transformed values
+// of the continuous columns (scen_premix_quad below)
+template <int P, bool FACTORS, int STRIDE, bool SCEN, bool PREMIXED = false>
 __device__ __forceinline__ float build_x(const SimParams& prm, const RowCtx<P>& cx, uint32_t k0, uint32_t k1,
                                          const float* st, int r, uint32_t row, float (&x)[P], const ScenLane<P>* sl) {
   const uint32_t K = cx.K;
@@ -295,14 +297,18 @@ __device__ __forceinline__ float build_x(const SimParams& prm, const RowCtx<P>& 
     float v = 0.0f;
     if ((uint32_t)(c - 1) < K) {
       if (SCEN) {  // per-replicate factor and marginal (data_gen.rs:334-363)
-        double acc = 0.0;
+        if (PREMIXED) {
+          v = z[c - 1];
+        } else {
+          double acc = 0.0;
 #pragma unroll
-        for (int t = 0; t < c; ++t) acc = acc + sl->Lp[(c - 1) * c / 2 + t] * (double)z[t];
-        v = (float)acc;
-        const uint32_t vt = (sl->meta >> (4 * (c - 1))) & 15u;
-        if (vt != 0u)
-          v = (float)apply_marginal(vt, (double)v, prm.var_params[c - 1], prm.t3_table, prm.upload_normal,
-                                    prm.upload_rows, K, (uint32_t)(c - 1));
+          for (int t = 0; t < c; ++t) acc = acc + sl->Lp[(c - 1) * c / 2 + t] * (double)z[t];
+          v = (float)acc;
+          const uint32_t vt = (sl->meta >> (4 * (c - 1))) & 15u;
+          if (vt != 0u)
+            v = (float)apply_marginal(vt, (double)v, prm.var_params[c - 1], prm.t3_table, prm.upload_normal,
+                                      prm.upload_rows, K, (uint32_t)(c - 1));
+        }
         if (prm.bootstrap && prm.boot_map[c - 1] >= 0) {  // strict mode copies the source row's value (data_gen.rs:566-589)
           double bv = prm.upload_data[(size_t)boot_row * prm.upload_data_cols + (uint32_t)prm.boot_map[c - 1]];
           if (prm.var_types[c - 1] == 7u) bv = (bv + prm.var_params[c - 1] >= 0.5) ? 1.0 : 0.0;  // stored = x - p
@@ -332,6 +338,43 @@ __device__ __forceinline__ float build_x(const SimParams& prm, const RowCtx<P>& 
     x[c] = v;
   }
   return e;
+}
+
+// General path, lane-per-replicate kernel: the per-replicate correlated mix x_c = f32(sum_{t < c} L[c-1][t] f64(z_t)) and the
+// marginal transform of every continuous column, for the four staged rows, in place: slot (c - 1, r) of the staging area
+// ends up holding what build_x<.., SCEN> computes for x[c] (same operations, same order; data_gen.rs:334-363).  Columns
+// descend, so the normals a column still needs are intact when its slot is overwritten.  The transform runs as ONE loop
+// over the 4 K slots: a single copy of apply_marginal in the instruction stream.
+template <int P, int STRIDE>
+__device__ __forceinline__ void scen_premix_quad(const SimParams& prm, float* st, const ScenLane<P>& sl) {
+  const uint32_t K = prm.K;
+  // (the factor stays in the lane's registers: re-read from the replicate's record in HBM at every quad it frees 30 VGPRs
+  // and costs 15 % of the kernel -- two waves per SIMD do not hide the loads)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float z[P - 1];
+#pragma unroll
+    for (int j = 0; j < P - 1; ++j) z[j] = ((uint32_t)j < K) ? st[(j * 4 + r) * STRIDE] : 0.0f;
+#pragma unroll
+    for (int c = P - 1; c >= 1; --c) {
+      if ((uint32_t)(c - 1) < K) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < c; ++t) acc = acc + sl.Lp[(c - 1) * c / 2 + t] * (double)z[t];
+        st[((c - 1) * 4 + r) * STRIDE] = (float)acc;
+      }
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64((sl.meta & 0x0fffffffu) != 0u) == 0ull) return;  // no lane of the wave holds a swapped marginal
+#pragma nounroll
+  for (uint32_t slot = 0; slot < 4u * K; ++slot) {
+    const uint32_t j = slot >> 2;
+    const uint32_t vt = (sl.meta >> (4u * j)) & 15u;
+    if (vt != 0u) {
+      const float v = st[slot * STRIDE];
+      st[slot * STRIDE] = (float)apply_marginal(vt, (double)v, prm.var_params[j], prm.t3_table, prm.upload_normal, prm.upload_rows, K, j);
+    }
+  }
 }
 
 // interaction columns recomputed from (possibly overwritten) component columns (data_gen.rs:643-649)
