@@ -481,9 +481,9 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     }
     if (chunk > cap) chunk = (uint32_t)(cap & ~(size_t)63);
   }
-  // general path, OLS, narrow designs: the launch is split into a row kernel and a fit kernel (ols_kernels.hip, SPLIT) with the
+  // OLS on the general path or over a grid of sample sizes, narrow designs: the launch is split into a row kernel and a fit kernel (ols_kernels.hip, SPLIT) with the
   // sufficient statistics of every (replicate, grid point) between them: keep one chunk's worth under 1 GiB
-  const bool ols_split = !glm && !reduced && !staged && prm.scen_active && P <= (uint32_t)mcp::MAX_P_WAVE;
+  const bool ols_split = !glm && !reduced && !staged && (prm.scen_active || n_ns > 1) && P <= (uint32_t)mcp::MAX_P_WAVE;
   if (ols_split) {
     const size_t per_rep = mcp::ols_rec_fields((int)P) * n_ns * sizeof(double);
     const size_t cap = ((size_t)1 << 30) / per_rep;

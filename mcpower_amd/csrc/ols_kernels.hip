@@ -140,7 +140,7 @@ static hipError_t launch_sim(int P, const SimParams* d_prm, uint32_t n_sims, boo
   if (MODE == MODE_FIT) flavor = 0;  // the fit kernel never builds rows
   if (flavor == 2) return launch_ols_scen(MODE, P, d_prm, n_sims, n_grid, st);  // ols_scen_kernels.hip
   if (grid1) return flavor ? launch_sim_pgf<MODE, true, 1>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, true, 0>(P, d_prm, n_sims, st);
-  return flavor ? launch_sim_pgf<MODE, false, 1>(P, d_prm, n_sims, st) : launch_sim_pgf<MODE, false, 0>(P, d_prm, n_sims, st);
+  return flavor ? launch_sim_pgf<MODE, false, 1>(P, d_prm, n_sims, st, n_grid) : launch_sim_pgf<MODE, false, 0>(P, d_prm, n_sims, st, n_grid);
 }
 
 hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, uint32_t n_grid, hipStream_t st) {

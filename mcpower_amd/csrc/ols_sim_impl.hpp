@@ -179,11 +179,11 @@ template <int P, int MODE, bool GRID1, int FLAVOR>
 __global__ __launch_bounds__(BLOCK, (FLAVOR == 2 && MODE == MODE_FUSED && P <= 7) ? MCP_LB_SCEN : MCP_LB_W) void ols_sim_kernel(const SimParams* __restrict__ pp) {
   constexpr bool FACTORS = FLAVOR >= 1;
   constexpr bool SCEN = FLAVOR == 2;
-  // General path, narrow designs: the launch is SPLIT -- this kernel leaves the sufficient statistics of every grid point in
+  // General path and every call with a grid of sample sizes, narrow designs: the launch is SPLIT -- this kernel leaves the sufficient statistics of every grid point in
   // HBM (prm.lmm_rec, 27 doubles per fit at P = 6) and ols_fit_rec_kernel runs the fits.  Inline, the fit's 160 registers
   // on top of the accumulators and the per-replicate scenario record put the kernel at 280 VGPRs = one wave per SIMD, and
   // its 20 KB of code between the row loops of two grid points; split, the row kernel keeps three waves per SIMD.
-  constexpr bool SPLIT = SCEN && MODE == MODE_FUSED && P <= MAX_P_WAVE;
+  constexpr bool SPLIT = MODE == MODE_FUSED && P <= MAX_P_WAVE && (SCEN || !GRID1);
   extern __shared__ float stage_lds[];
   const SimParams& prm = *pp;
   const uint32_t local = blockIdx.x * BLOCK + threadIdx.x;
@@ -364,7 +364,7 @@ static hipError_t launch_sim_pgf(int P, const SimParams* d_prm, uint32_t n_sims,
       if (MODE == MODE_FUSED) return launch_fused_wide<GRID1, FLAVOR>(P, d_prm, n_sims, lds, st);
       return hipErrorInvalidValue;
   }
-  if constexpr (MODE == MODE_FUSED && FLAVOR == 2) {  // split launch (ols_sim_kernel, SPLIT): the fits of every (replicate, grid point)
+  if constexpr (MODE == MODE_FUSED && (FLAVOR == 2 || !GRID1)) {  // split launch (ols_sim_kernel, SPLIT): the fits of every (replicate, grid point)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const dim3 fgrid((n_sims + BLOCK - 1u) / BLOCK, n_grid);
