@@ -80,9 +80,8 @@ struct LmgLds {
 
 // fit view (mcp_params.hpp): the term that owns column i < fR of the dense rest block
 __device__ __forceinline__ uint32_t lmg_rest_term(const SimParams& prm, uint32_t i) {
-  uint32_t r = 0;
-  while (r + 1u < prm.lmg_n_rest && i >= prm.lmg_froff[prm.lmg_frest[r + 1u]]) ++r;
-  return prm.lmg_frest[r];
+  const uint32_t t0 = prm.lmg_frest[0], t1 = prm.lmg_frest[1];  // at most two terms besides the eliminated one
+  return (prm.lmg_n_rest > 1u && i >= prm.lmg_froff[t1]) ? t1 : t0;
 }
 
 // template entries T_t[r][c] of every term from theta (column-major vech per term, mixed_workspace.rs:189-196)
@@ -200,7 +199,7 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
       const uint32_t qj = xy ? 1u : prm.lmg_q[tj];
       uint32_t jlo, jhi;
       if (xy) { jlo = R; jhi = W; }
-      else if (prm.lmg_frel[tj] == 1u) { jlo = prm.lmg_froff[tj] + (c / cpe) * prm.lmg_fcnt[tj] * qj; jhi = jlo + prm.lmg_fcnt[tj] * qj; }
+      else if (prm.lmg_frel[tj] == 1u) { jlo = prm.lmg_froff[tj] + (cpe == 1u ? c : c / cpe) * prm.lmg_fcnt[tj] * qj; jhi = jlo + prm.lmg_fcnt[tj] * qj; }
       else { jlo = prm.lmg_froff[tj]; jhi = jlo + prm.lmg_levels[tj] * qj; }
       for (uint32_t sj = jlo; sj < jhi; sj += qj) {
         for (uint32_t bj = 0; bj < qj; ++bj) {
