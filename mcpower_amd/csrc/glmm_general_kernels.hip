@@ -52,6 +52,7 @@ struct GlmmLds {
   uint32_t so[GG_MAX_TERMS];
   float* st;
   uint32_t R, RS;    // random effects in total, row stride of M (odd: lanes on different rows spread over the banks)
+  uint32_t R0, q0;   // the leading, block-diagonal part of the index layout: the columns of term prm.lmg_elim, its block width
   uint32_t off[GG_MAX_TERMS], doff[GG_MAX_TERMS], diag_mask;
 };
 
@@ -445,11 +446,17 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
             double a2[3];
             const uint32_t l2 = gg_row_term<P>(prm, m, t2, i, n_pad, a2);
             const uint32_t q2 = prm.lmg_q[t2], rowbase = pick3(m.off, t2) + l2 * q2;
+            // the lower triangle: the entry lives in the row of whichever term sits later in the index layout (this lane owns
+            // the indices colbase.. either way, so no two lanes touch one entry)
+            const bool mine_below = colbase > rowbase;
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2)
 #pragma unroll
               for (int b = 0; b < 3; ++b)
-                if ((uint32_t)b2 < q2 && (uint32_t)b < q) m.M[(size_t)(rowbase + (uint32_t)b2) * RS + colbase + (uint32_t)b] += w * a2[b2] * a[b];
+                if ((uint32_t)b2 < q2 && (uint32_t)b < q) {
+                  const uint32_t ra = rowbase + (uint32_t)b2, ca = colbase + (uint32_t)b;
+                  m.M[mine_below ? (size_t)ca * RS + ra : (size_t)ra * RS + ca] += w * a2[b2] * a[b];
+                }
           }
         }
 #pragma unroll
@@ -471,7 +478,7 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
       }
     }
     gq_sync();
-    ok = gg_chol(m.M, R, RS, m.off[1], prm.lmg_q[0], lane, m.un, logdet);
+    ok = gg_chol(m.M, R, RS, m.R0, m.q0, lane, m.un, logdet);
     if (!ok) break;
     const bool conv = __builtin_fabs(pd_acc - pd) <= tol;  // pd_acc = inf on the first pass: never
     for (uint32_t a = lane; a < R; a += QW) m.u[a] = m.ut[a];  // accept
@@ -480,8 +487,8 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
     pd_acc = pd;
     gq_sync();
     if (conv) break;
-    gg_forward(m.M, R, RS, m.off[1], prm.lmg_q[0], m.r, 1u, 1u, lane);
-    gg_backward(m.M, R, RS, m.off[1], prm.lmg_q[0], m.r, m.un, lane);
+    gg_forward(m.M, R, RS, m.R0, m.q0, m.r, 1u, 1u, lane);
+    gg_backward(m.M, R, RS, m.R0, m.q0, m.r, m.un, lane);
     bool same = true;
     for (uint32_t a = lane; a < R; a += QW) same = same && (m.un[a] == m.u[a]);
     same = __ballot(!same) == 0ull;
@@ -522,12 +529,17 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
   const uint32_t dmax = nth + (uint32_t)P;
   GlmmLds m;
   {
+    // index layout of the random effects: the term with the most columns (prm.lmg_elim, host_lowering.cpp) leads -- its levels
+    // are mutually exclusive, so that part of I + A'WA is block diagonal and gg_chol factors it one block per lane -- the
+    // others follow in declaration order (glmm_nested: 16 children lead, the dense block is the 8 parents)
+    const uint32_t E = prm.lmg_elim;
+    m.q0 = prm.lmg_q[E];
+    m.R0 = prm.lmg_levels[E] * m.q0;
     m.R = prm.lmg_levels[0] * prm.lmg_q[0] + prm.lmg_R;
     m.RS = m.R | 1u;
     uint32_t nd = 0, dm = 0, k = 0;
 #pragma unroll
     for (uint32_t t = 0; t < GG_MAX_TERMS; ++t) {
-      m.off[t] = t == 0u ? 0u : prm.lmg_levels[0] * prm.lmg_q[0] + prm.lmg_roff[t];
       m.doff[t] = nd;
       if (t < nterms) {
         nd += prm.lmg_levels[t] * prm.lmg_q[t];
@@ -536,6 +548,14 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
       }
     }
     m.diag_mask = dm;
+    {
+      uint32_t o = m.R0;
+#pragma unroll
+      for (uint32_t t = 0; t < GG_MAX_TERMS; ++t) {
+        m.off[t] = t == E ? 0u : o;
+        if (t != E && t < nterms) o += prm.lmg_levels[t] * prm.lmg_q[t];
+      }
+    }
     gdd* q = (gdd*)lds_q;
     m.eta0 = q; q += n_pad;
     m.wrow = q; q += n_pad;
@@ -1101,7 +1121,7 @@ __global__ __launch_bounds__(QW) void glmm_general_kernel(const SimParams* __res
               }
             }
             gq_sync();
-            gg_forward(m.M, m.R, m.RS, m.off[1], prm.lmg_q[0], m.C, (uint32_t)P, (uint32_t)P, lane);  // D = L^-1 C
+            gg_forward(m.M, m.R, m.RS, m.R0, m.q0, m.C, (uint32_t)P, (uint32_t)P, lane);  // D = L^-1 C
             {
               double dd[P * (P + 1) / 2];
 #pragma unroll

@@ -490,22 +490,28 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       prm.lmg_R = roff;
       prm.lmg_W = roff + P + 1;
       {
-        // fit view (mcp_params.hpp): eliminate the nested grouping with the most levels per parent when its random-effect
-        // width equals the primary's (the kernel is instantiated on one width); oracle/fit_lmm_general.c takes the same choice
-        uint32_t E = 0;
-        if (spec->estimator == MCP_EST_MLE)
-          for (uint32_t t = 1; t < prm.lmg_n_terms; ++t)
-            if (prm.lmg_relation[t] == 1u && prm.lmg_q[t] == prm.lmg_q[0] && prm.lmg_count[t] >= 2u &&
-                (E == 0u || prm.lmg_count[t] > prm.lmg_count[E])) E = t;
+        // fit view (mcp_params.hpp): any grouping's levels are mutually exclusive, so any term can be the one whose levels are
+        // eliminated block by block (LMM) / lead the index layout of the joint mode system (clustered GLM); the one with the
+        // most random-effect columns leaves the smallest dense block.  The LMM kernel is instantiated on one block width, so
+        // there only terms as wide as the primary one qualify.  oracle: mcpo_elim_term takes the same choice
+        uint32_t E = 0, best = prm.lmg_levels[0] * prm.lmg_q[0];
+        for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) {
+          if (spec->estimator == MCP_EST_MLE && prm.lmg_q[t] != prm.lmg_q[0]) continue;
+          const uint32_t cols = prm.lmg_levels[t] * prm.lmg_q[t];
+          if (cols > best) { best = cols; E = t; }
+        }
         prm.lmg_elim = E;
-        prm.lmg_cpe = E ? prm.lmg_count[E] : 1u;
+        const bool e_nested = E != 0u && prm.lmg_relation[E] == 1u;
+        prm.lmg_cpe = e_nested ? prm.lmg_count[E] : 1u;
         uint32_t fro = 0, nr = 0;
         for (uint32_t t = 0; t < prm.lmg_n_terms; ++t) {
           if (t == E) continue;
           prm.lmg_frest[nr++] = t;
           prm.lmg_froff[t] = fro;
           fro += prm.lmg_levels[t] * prm.lmg_q[t];
-          prm.lmg_frel[t] = t == 0u ? 1u : prm.lmg_relation[t];
+          // how an eliminated level meets term t: E primary -> the spec's relation; E nested in the primary -> the primary and the
+          // other nested groupings through the shared primary level, crossed ones fully; E crossed -> every term fully
+          prm.lmg_frel[t] = E == 0u ? prm.lmg_relation[t] : (e_nested ? (t == 0u ? 1u : prm.lmg_relation[t]) : 0u);
           prm.lmg_fcnt[t] = t == 0u ? 1u : prm.lmg_count[t];
         }
         prm.lmg_n_rest = nr;

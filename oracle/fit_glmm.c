@@ -693,7 +693,7 @@ int mcpo_glmm_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const
       const double* start = NULL;
       if (has_prev) start = carry_v;
       else if (spec->scenario.truth_start) { mcpo_truth_theta(cl, 1, tv); start = tv; }
-      rc = mcpo_glmm_general_fit_terms(fam, xfit, ws->y, n, max_n, p_fit, terms, 1 + cl->n_extra_groupings, start, beta0, mode, &f);
+      rc = mcpo_glmm_general_fit_terms(fam, xfit, ws->y, n, max_n, p_fit, terms, 1 + cl->n_extra_groupings, mcpo_elim_term(cl, max_n, 0), start, beta0, mode, &f);
     } else if (q == 1) {
       rc = mcpo_glmm_fit_ids(fam, xfit, ws->y, ids, n, max_n, p_fit, ncl, th0, beta0, mode, &f);
     } else {

@@ -241,16 +241,21 @@ static double gg_probe_cb(void* ctx, double* par) {  /* a probe of the stationar
 
 /* mode: MCPO_MODE_HESSIAN selects the finite-difference Hessian Wald covariance (fit_glmm.c) over the free parameters */
 int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
-                                const mcpo_re_term* terms, uint32_t n_terms, const double* theta0, const double* beta0,
+                                const mcpo_re_term* terms, uint32_t n_terms, uint32_t elim, const double* theta0, const double* beta0,
                                 uint32_t mode, mcpo_gen_fit* f) {
   if (p > MCPO_MAX_P || n_terms == 0 || n_terms > GG_MAX_TERMS) return MCP_ERR_UNSUPPORTED;
   gg_model m;
   memset(&m, 0, sizeof m);
   m.fam = fam; m.n = n; m.ld = ld; m.p = p; m.nt = n_terms; m.x = x; m.y = y;
+  if (elim >= n_terms) return MCP_ERR_UNSUPPORTED;
+  /* index layout of the random effects: the term `elim` leads (mcpo_elim_term: the one with the most columns -- its levels
+   * are mutually exclusive, so the leading part of I + A'WA is block diagonal and the device kernel factors it one block
+   * per lane), the others follow in declaration order; theta stays in declaration order */
+  m.roff[elim] = 0; m.R = terms[elim].q * terms[elim].n_levels;
   for (uint32_t t = 0; t < n_terms; ++t) {
     if (terms[t].q == 0 || terms[t].q > GG_MAX_Q) return MCP_ERR_UNSUPPORTED;
     m.terms[t] = terms[t];
-    m.roff[t] = m.R; m.R += terms[t].q * terms[t].n_levels;
+    if (t != elim) { m.roff[t] = m.R; m.R += terms[t].q * terms[t].n_levels; }
     m.toff[t] = m.nth;
     for (uint32_t c = 0; c < terms[t].q; ++c)
       for (uint32_t r = c; r < terms[t].q; ++r) m.is_diag[m.nth++] = r == c;
@@ -379,7 +384,8 @@ int mcpo_glmm_general_fit(int family, const float* x, const float* y, uint32_t n
     for (uint32_t d = 0; d < MCP_MAX_RE_SLOPES; ++d) terms[t].cols[d] = slope_cols[t * MCP_MAX_RE_SLOPES + d];
   }
   mcpo_gen_fit f;
-  int rc = mcpo_glmm_general_fit_terms(family, x, y, n, ld, p, terms, n_terms, theta_start, beta_start, mode, &f);
+  /* mode bits 16..17: the leading term of the index layout (mcpo_elim_term); the result does not depend on it beyond rounding */
+  int rc = mcpo_glmm_general_fit_terms(family, x, y, n, ld, p, terms, n_terms, (mode >> 16) & 3u, theta_start, beta_start, mode & 0xffffu, &f);
   if (rc) return rc;
   *converged = (uint8_t)f.converged; *boundary_hit = f.boundary_hit; *pinned = f.pinned; *n_eval = f.n_eval;
   memcpy(theta_hat, f.theta, sizeof(double) * f.n_theta);

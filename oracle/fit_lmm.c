@@ -383,7 +383,7 @@ int mcpo_mle_arm(const mcp_spec* spec, const mcpo_ws* ws, uint32_t max_n, const 
       if (!reduced && has_prev) start = gen_carry;
       else if (spec->scenario.truth_start) { mcpo_truth_theta(cl, !reduced, th0); start = th0; }
       mcpo_gen_fit gf;
-      rc = mcpo_lmm_general_fit_terms(xfit, ws->y, n, max_n, p_red, terms, n_terms, mcpo_lmm_elim_term(cl), start, &gf);
+      rc = mcpo_lmm_general_fit_terms(xfit, ws->y, n, max_n, p_red, terms, n_terms, mcpo_elim_term(cl, max_n, 1), start, &gf);
       if (rc) break;
       memset(&f, 0, sizeof f);
       f.converged = gf.converged; f.boundary_hit = gf.boundary_hit; f.sigma_sq = gf.sigma_sq;

@@ -19,8 +19,8 @@
  *
  * Factorisation order here: [blocks of the ELIMINATED term | columns of the other terms | X | y].  One term's levels
  * (one q x q block each) are eliminated analytically, the other terms form one dense block.  Which term: the likelihood
- * does not depend on it, the cost does -- `elim` (mcpo_lmm_elim_term: the grouping nested in the primary one with the
- * most levels per parent and the primary's random-effect width, else the primary itself) names it; theta stays in
+ * does not depend on it, the cost does -- `elim` (mcpo_elim_term: the grouping with the most random-effect
+ * columns among those as wide as the primary one) names it; theta stays in
  * declaration order.  The device kernel (lmm_general_impl.hpp) takes the same choice and the same operation order.
  * The minimiser is a bound-constrained Nelder-Mead simplex (diagonal theta >= 0, off-diagonals free) with
  * restarts -- lme4 ships the same family of optimiser as `Nelder_Mead`; the reference uses BOBYQA.
@@ -411,14 +411,17 @@ uint32_t mcpo_truth_theta(const mcp_cluster* c, int include_slopes, double* thet
   return k;
 }
 
-/* the term whose levels are eliminated one block each (the fit view of lmm_general_impl.hpp / host_lowering.cpp): the
- * grouping nested in the primary one with the most levels per parent, when its random-effect width equals the primary's */
-uint32_t mcpo_lmm_elim_term(const mcp_cluster* c) {
-  uint32_t E = 0;
+/* the term whose levels are eliminated one block each (the fit view of lmm_general_impl.hpp / glmm_general_kernels.hip,
+ * chosen by host_lowering.cpp the same way): any grouping's levels are mutually exclusive, so any term can lead; the one
+ * with the most random-effect columns at the call's largest sample size leaves the smallest dense block.  Ties keep the
+ * earlier term.  equal_q: only terms as wide as the primary one (the LMM kernel is instantiated on one block width). */
+uint32_t mcpo_elim_term(const mcp_cluster* c, uint32_t max_n, int equal_q) {
+  uint32_t E = 0, best = mcpo_n_clusters_at(c, max_n) * (1u + c->slopes.n_slopes);
   for (uint32_t t = 1; t <= c->n_extra_groupings; ++t) {
     const mcp_grouping* g = &c->extra[t - 1];
-    if (g->relation == MCP_GROUPING_NESTED_WITHIN && g->slopes.n_slopes == c->slopes.n_slopes && g->count >= 2u &&
-        (E == 0 || g->count > c->extra[E - 1].count)) E = t;
+    if (equal_q && g->slopes.n_slopes != c->slopes.n_slopes) continue;
+    const uint32_t cols = mcpo_extra_n_levels_at(c, t - 1, max_n) * (1u + g->slopes.n_slopes);
+    if (cols > best) { best = cols; E = t; }
   }
   return E;
 }

@@ -58,7 +58,7 @@ typedef struct mcpo_gen_fit {
 } mcpo_gen_fit;
 void mcpo_slope_cholesky(const mcp_re_slopes* sl, double tau0, double* l);
 uint32_t mcpo_truth_theta(const mcp_cluster* c, int include_slopes, double* theta);
-uint32_t mcpo_lmm_elim_term(const mcp_cluster* c);
+uint32_t mcpo_elim_term(const mcp_cluster* c, uint32_t max_n, int equal_q);
 int mcpo_lmm_general_fit_terms(const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
                                const mcpo_re_term* terms, uint32_t n_terms, uint32_t elim, const double* theta_start, mcpo_gen_fit* f);
 
@@ -70,7 +70,7 @@ int mcpo_glmm_fit_ids(int fam, const float* x, const float* y, const uint32_t* i
 #define MCPO_MODE_HESSIAN 1u  /* bits 8..15: nagq (0 / 1 = Laplace) */
 void mcpo_gh_rule(uint32_t k, double* z, double* w);
 int mcpo_glmm_general_fit_terms(int fam, const float* x, const float* y, uint32_t n, uint32_t ld, uint32_t p,
-                                const mcpo_re_term* terms, uint32_t n_terms, const double* theta0, const double* beta0,
+                                const mcpo_re_term* terms, uint32_t n_terms, uint32_t elim, const double* theta0, const double* beta0,
                                 uint32_t mode, mcpo_gen_fit* f);
 /* EXPERIMENT KNOBS (tools/oracle2_perdraw.py; DESIGN.md section 5, "oracle2 experiments"): environment variable
  * MCPO_KNOB_<NAME>, read at every call (the harness sets them per worker process); unset = the shipped constant, so the

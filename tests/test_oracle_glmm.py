@@ -338,6 +338,23 @@ def test_general_laplace_fit_matches_glmer(name, start, oracle):
     assert np.all(np.abs(r["beta"] / r["se"] / a["golden_z"] - 1.0) < 2e-3)
 
 
+@pytest.mark.parametrize("name", GENERAL_CASES)
+def test_the_leading_grouping_of_the_joint_mode_system_is_a_cost_choice(name, oracle):
+    """fit_glmm_general.c lays the random effects out with ONE grouping's levels first (block diagonal, so the device
+    factors it one block per lane) and the others behind it; the batch takes mcpo_elim_term (most columns).  The Laplace
+    deviance is the same function of (theta, beta) whichever grouping leads: every choice gives the glmer-pinned fit."""
+    spec, _, a, low = load_case(name)
+    ids, q, cols = _glmm_terms(spec, a)
+    kw = dict(theta_start=oracle.truth_theta(spec), beta_start=spec.effect_sizes)
+    base = oracle.glmm_general_fit(a["design"], a["outcome"], ids, q, cols, family="logit", **kw)
+    for e in range(1, len(ids)):
+        r = oracle.glmm_general_fit(a["design"], a["outcome"], ids, q, cols, family="logit", elim=e, **kw)
+        assert r["converged"] == base["converged"] and r["boundary_hit"] == base["boundary_hit"] and r["pinned"] == base["pinned"]
+        assert np.allclose(r["beta"], base["beta"], atol=5e-6), (name, e, r["beta"], base["beta"])
+        assert np.allclose(r["se"], base["se"], rtol=1e-4), (name, e)
+        assert np.allclose(r["theta"], base["theta"], atol=1e-3), (name, e, r["theta"], base["theta"])
+
+
 def test_general_fit_on_a_single_grouping_equals_the_per_cluster_fit(oracle):
     spec, _, a, low = load_case("glmm_multislope")
     v = oracle.glmm_slopes_fit(a["design"], a["outcome"], a["cluster_ids"], [1, 2], family="logit")
