@@ -493,7 +493,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
         // fit view (mcp_params.hpp): any grouping's levels are mutually exclusive, so any term can be the one whose levels are
         // eliminated block by block (LMM) / lead the index layout of the joint mode system (clustered GLM); the one with the
         // most random-effect columns leaves the smallest dense block.  The LMM kernel is instantiated on one block width, so
-        // there only terms as wide as the primary one qualify.  oracle: mcpo_elim_term takes the same choice
+        // there only terms as wide as the primary one qualify.  (the test oracle takes the same choice)
         uint32_t E = 0, best = prm.lmg_levels[0] * prm.lmg_q[0];
         for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) {
           if (spec->estimator == MCP_EST_MLE && prm.lmg_q[t] != prm.lmg_q[0]) continue;
