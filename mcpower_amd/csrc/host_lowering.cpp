@@ -331,7 +331,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
       }
     general = true;
   }
-  if (general && K > 6) return unsupported("general data-generating path with more than 6 continuous predictors");
+  if (general && K > 9) return unsupported("general data-generating path with more than 9 continuous predictors");
   if (spec->scenario.has_lme && spec->estimator != MCP_EST_MLE &&
       !(spec->estimator == MCP_EST_GLM && spec->cluster.present)) {  // validate.rs:458-474: Mle or clustered Glm
     err = "invalid spec: scenario.lme requires estimator == Mle";

@@ -123,7 +123,7 @@ struct SimParams {
   double var_params[MAX_K];
   double corr[MAX_K * MAX_K];      // base correlation, column-major
   double* scen_L;                  // [K(K+1)/2][scen_stride] row-major lower factor entries per replicate
-  uint32_t* scen_meta;             // [scen_stride]: 4 bits per predictor marginal | residual dist << 28 | status << 31
+  uint32_t* scen_meta;             // [scen_stride]: 3 bits per predictor marginal (K <= 9) | residual dist << 28 | status << 31
   double* scen_beta;               // [P][scen_stride] per-study effects (heterogeneity > 0) or null
   uint32_t scen_stride;
   uint32_t _pad_scen;

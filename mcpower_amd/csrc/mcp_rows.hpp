@@ -169,9 +169,9 @@ __device__ __forceinline__ void stage_group(const SimParams& prm, uint32_t k0, u
 #pragma unroll
       for (int r = 0; r < 4; ++r) chi_sk[r] = (double)z0[r] * (double)z0[r];  // skewed forms start at slot 0
       for (uint32_t s = 1; s <= dfi; ++s) {
-        mask_t pd = 0;
+        unsigned long long pd = 0;  // slot K + 1 is past bit 31 of the narrow mask once K >= 7
         stage_column<STRIDE>(st, K + 1u, planar_words(k0, k1, CLASS_RESID, s, ctr), pd);
-        fixup_tails<STRIDE, mask_t>(st, pd, nullptr);  // ~12 parked draws per wave: the loop is cheaper than a scan
+        fixup_tails<STRIDE, unsigned long long>(st, pd, nullptr);  // ~12 parked draws per wave: the loop is cheaper than a scan
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double g = (double)st[((K + 1u) * 4u + r) * STRIDE];
@@ -204,7 +204,7 @@ template <int P>
 struct ScenLane {
   double Lp[(P - 1) * P / 2 > 0 ? (P - 1) * P / 2 : 1];  // row-major lower factor: idx(j, t) = j(j+1)/2 + t
   double beta_eff[P];
-  uint32_t meta;  // 4 bits per predictor marginal | residual dist << 28
+  uint32_t meta;  // 3 bits per predictor marginal (K <= 9) | residual dist << 28 | not-PSD flag << 31
 };
 
 template <int P>
@@ -304,7 +304,7 @@ __device__ __forceinline__ float build_x(const SimParams& prm, const RowCtx<P>& 
 #pragma unroll
           for (int t = 0; t < c; ++t) acc = acc + sl->Lp[(c - 1) * c / 2 + t] * (double)z[t];
           v = (float)acc;
-          const uint32_t vt = (sl->meta >> (4 * (c - 1))) & 15u;
+          const uint32_t vt = (sl->meta >> (3 * (c - 1))) & 7u;
           if (vt != 0u)
             v = (float)apply_marginal(vt, (double)v, prm.var_params[c - 1], prm.t3_table, prm.upload_normal,
                                       prm.upload_rows, K, (uint32_t)(c - 1));
@@ -369,7 +369,7 @@ __device__ __forceinline__ void scen_premix_quad(const SimParams& prm, float* st
 #pragma nounroll
   for (uint32_t slot = 0; slot < 4u * K; ++slot) {
     const uint32_t j = slot >> 2;
-    const uint32_t vt = (sl.meta >> (4u * j)) & 15u;
+    const uint32_t vt = (sl.meta >> (3u * j)) & 7u;
     if (vt != 0u) {
       const float v = st[slot * STRIDE];
       st[slot * STRIDE] = (float)apply_marginal(vt, (double)v, prm.var_params[j], prm.t3_table, prm.upload_normal, prm.upload_rows, K, j);

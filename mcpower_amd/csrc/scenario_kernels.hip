@@ -27,7 +27,7 @@ namespace mcp {
 __device__ __forceinline__ uint32_t scen_class(uint32_t meta, uint32_t K) {
   uint32_t c = 0;
   for (uint32_t j = 0; j < K && j < 6u; ++j) {
-    const uint32_t vt = (meta >> (4u * j)) & 15u;
+    const uint32_t vt = (meta >> (3u * j)) & 7u;
     c |= (vt != 0u ? 1u : 0u) << j;
     c |= ((vt == 2u || vt == 3u) ? 1u : 0u) << (6u + j);
   }
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void scenario_design_kernel(const SimParams* _
     for (uint32_t t = 1; prm.lmg_active && t < prm.lmg_n_terms; ++t) prm.scen_tau_sq[(size_t)t * prm.scen_stride + lsim] = extra_tau_sq[t];
   }
   uint32_t meta = (rd & 7u) << 28;
-  for (uint32_t j = 0; j < K; ++j) meta |= (vt[j] & 15u) << (4u * j);
+  for (uint32_t j = 0; j < K; ++j) meta |= (vt[j] & 7u) << (3u * j);  // 3 bits per predictor (codes 0..7), K <= 9
   if (!ok) meta |= 0x80000000u;  // EngineError::CorrelationNotPSD for this replicate
   prm.scen_meta[lsim] = meta;
   if (prm.scen_hist) atomicAdd(&prm.scen_hist[scen_class(meta, K)], 1u);

@@ -571,6 +571,56 @@ def test_c5_grid_sweep_under_the_robustness_presets_matches_oracle(name, engine,
     assert ku[-1] > ku[0] and (np.diff(ku) >= -40).all()      # power rises along the grid (shared draws: nearly monotone)
 
 
+@pytest.mark.parametrize("k", [7, 8, 9])
+def test_seven_to_nine_continuous_predictors_on_the_general_path(k, engine, oracle):
+    """The per-replicate scenario record packs one 3-bit marginal code per continuous predictor: up to 9 of them (6 in round 2).
+    P = 8 runs the split fused launch, P = 9 the fused kernel, P = 10 the reduced-design kernel; the design bytes match the
+    oracle inside the general path's one-ulp band and the decisions of a grid call follow."""
+    from helpers import preset
+    spec = base_spec(k)
+    c = np.eye(k)
+    c[0, 1] = c[1, 0] = 0.35
+    c[2, k - 1] = c[k - 1, 2] = -0.3
+    spec.correlation = c.flatten().tolist()
+    spec.effect_sizes = [0.0] + [0.2, 0.15, 0.0, 0.1, -0.15, 0.0, 0.12, 0.1, -0.1][:k]
+    spec.target_indices = [1, 2, k]
+    for name in ("realistic", "doomer"):
+        spec.scenario = preset(name)
+        bx, by, worst, total = _design_mismatch(engine, oracle, spec, 90, 32)
+        assert bx + by <= max(2, total * 1e-5) and worst < 2.5e-7, (k, name, bx, by, worst)
+        g = engine.run_batch(spec, [80, 240], 1500, BASE_SEED)
+        o = oracle.run_batch(spec, [80, 240], 1500, BASE_SEED, n_threads=8)
+        assert (g.uncorrected != o.uncorrected).sum() <= 2 and np.array_equal(g.converged, o.converged), (k, name)
+        assert np.abs(g.counters.astype(np.int64) - o.counters.astype(np.int64)).max() <= 2
+    with pytest.raises(S.EngineError) as e:   # the tenth one is refused, loudly
+        wide = base_spec(10)
+        wide.scenario = preset("realistic")
+        engine.run_batch(wide, [100], 8, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "9 continuous predictors" in str(e.value)
+
+
+def test_seven_continuous_predictors_under_the_presets_glm_and_lmm(engine, oracle):
+    from helpers import preset
+    k = 7
+    spec = base_spec(k)
+    spec.effect_sizes = [0.0, 0.3, 0.2, 0.0, 0.1, -0.2, 0.0, 0.15]
+    spec.target_indices = [1, 2, 7]
+    spec.scenario = preset("realistic")
+    import copy
+    glm = copy.deepcopy(spec)
+    glm.estimator, glm.outcome_kind = S.EstimatorSpec.Glm, S.OutcomeKind.Binary
+    glm.intercept = glm.effect_sizes[0] = -0.4
+    g = engine.run_batch(glm, [300], 600, BASE_SEED)
+    o = oracle.run_batch(glm, [300], 600, BASE_SEED, n_threads=8)
+    assert (g.uncorrected != o.uncorrected).sum() <= 3 and (g.converged != o.converged).sum() <= 1
+    lmm = copy.deepcopy(spec)
+    lmm.estimator = S.EstimatorSpec.Mle
+    lmm.cluster = S.ClusterSpec(sizing=("FixedClusters", 12), tau_squared=0.25)
+    g = engine.run_batch(lmm, [240], 600, BASE_SEED)
+    o = oracle.run_batch(lmm, [240], 600, BASE_SEED, n_threads=8)
+    assert (g.uncorrected != o.uncorrected).sum() <= 3 and (g.converged != o.converged).sum() <= 1
+
+
 # ---------------------------------------------------------------------------------------------
 # probit / Poisson GLM families
 # ---------------------------------------------------------------------------------------------
