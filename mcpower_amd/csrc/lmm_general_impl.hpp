@@ -41,7 +41,10 @@ constexpr double LMG_THETA_ZERO = 1e-6;
 constexpr double LMG_THETA_MAX = 32.0;
 constexpr uint32_t LMG_MAX_EVAL = 6000;
 constexpr double LMG_NEAR_ZERO = 1e-30;
-constexpr int LMG_MAX_NZ = 2 * LMG_MAX_SLOPES + 2 + MAX_P_WAVE + 1;  // sparse row of [Zr | X | y]
+constexpr int LMG_MAX_P = 12;  // design columns: 9..12 with random intercepts only (one block width, see the launchers)
+constexpr int LMG_MAX_NZ = 2 * LMG_MAX_SLOPES + 2 + LMG_MAX_P + 1;  // sparse row of [Zr | X | y]
+// row stride of the p x p factor and of the per-test solves in the tail block: 8 up to 8 design columns, 16 beyond
+__device__ __forceinline__ uint32_t lmg_tail_stride(uint32_t p) { return p > 8u ? 16u : 8u; }
 
 __device__ __forceinline__ void lmg_sync() { __syncthreads(); }  // one wave per block
 
@@ -101,7 +104,7 @@ __device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* t
 }
 
 // one evaluation of the profiled REML criterion at theta `th` (LDS, n_theta doubles).  Returns the deviance (inf
-// when a pivot fails); leaves sigma^2 in misc[0], beta in tail[0..p), the lower factor of RX'RX in tail[8 + a*8 + b].
+// when a pivot fails); leaves sigma^2 in misc[0], beta in tail[0..p), the lower factor of RX'RX in tail[ts + a*ts + b], ts = lmg_tail_stride(p).
 template <int Q0>
 __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows) {
   const uint32_t W = prm.lmg_fW, R = prm.lmg_fR, p = prm.P, E = prm.lmg_elim, L0 = prm.lmg_levels[E], cpe = prm.lmg_cpe;
@@ -302,14 +305,15 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
   ok = ok && (pwrss > 0.0) && (dfr > 0.0) && (lmin / lmax >= 1e-12);
   if (!ok) return inf;
   const double dev = logdet + dfr * (1.0 + log(2.0 * 3.14159265358979323846 * pwrss / dfr));
+  const uint32_t ts = lmg_tail_stride(p);
   if (lane == 0u) {
     m.misc[0] = pwrss / dfr;
     for (uint32_t a = 0; a < p; ++a)
-      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[lmg_tri((R + a), R + b)] : 0.0;
+      for (uint32_t b = 0; b < p; ++b) m.tail[ts + a * ts + b] = b <= a ? m.S[lmg_tri((R + a), R + b)] : 0.0;
     for (int a = (int)p - 1; a >= 0; --a) {
       double v = m.S[lmg_tri(M, R + (uint32_t)a)];
-      for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[8u + k * 8u + (uint32_t)a] * m.tail[k];
-      m.tail[a] = v / m.tail[8u + (uint32_t)a * 8u + (uint32_t)a];
+      for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[ts + k * ts + (uint32_t)a] * m.tail[k];
+      m.tail[a] = v / m.tail[ts + (uint32_t)a * ts + (uint32_t)a];
     }
   }
   lmg_sync();
@@ -437,14 +441,15 @@ __device__ __forceinline__ double lmg_eval_red(const SimParams& prm, const LmgLd
   ok = ok && (pwrss > 0.0) && (dfr > 0.0) && (lmin / lmax >= 1e-12);
   if (!ok) return inf;
   const double dev = logdet + dfr * (1.0 + log(2.0 * 3.14159265358979323846 * pwrss / dfr));
+  const uint32_t ts = lmg_tail_stride(p);
   if (lane == 0u) {
     m.misc[0] = pwrss / dfr;
     for (uint32_t a = 0; a < p; ++a)
-      for (uint32_t b = 0; b < p; ++b) m.tail[8u + a * 8u + b] = b <= a ? m.S[lmg_tri((Rr + a), Rr + b)] : 0.0;
+      for (uint32_t b = 0; b < p; ++b) m.tail[ts + a * ts + b] = b <= a ? m.S[lmg_tri((Rr + a), Rr + b)] : 0.0;
     for (int a = (int)p - 1; a >= 0; --a) {
       double v = m.S[lmg_tri(M, Rr + (uint32_t)a)];
-      for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[8u + k * 8u + (uint32_t)a] * m.tail[k];
-      m.tail[a] = v / m.tail[8u + (uint32_t)a * 8u + (uint32_t)a];
+      for (uint32_t k = (uint32_t)a + 1u; k < p; ++k) v -= m.tail[ts + k * ts + (uint32_t)a] * m.tail[k];
+      m.tail[a] = v / m.tail[ts + (uint32_t)a * ts + (uint32_t)a];
     }
   }
   lmg_sync();
@@ -484,7 +489,7 @@ template <int P, int Q0, bool SCEN>
 // (three random effects on the eliminated grouping, seven or more design columns, and a slope on the general data path or with six
 // columns -- 12 B over -- get 256 registers instead of 168, or the block algebra spills; those designs are LDS-bound below 3 waves
 // per SIMD anyway)
-__global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >= 6))) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
+__global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >= 6))) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
@@ -519,7 +524,8 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >
     m.fv = e; e += d + 1u;
     m.tm = e; e += 27;
     m.misc = e; e += 8;
-    m.tail = e; e += 8 + 64 + 64 + 64 + 8 + 8;  // beta | L | U | Lc | cj | tsq
+    constexpr uint32_t TS = P > 8 ? 16u : 8u;
+    m.tail = e; e += TS + TS * TS + 8u * TS + 64 + 8 + 8;  // beta | L | U | Lc | cj | tsq
     m.u0 = f; f += L0;
     m.us = f; f += (size_t)L0 * LMG_MAX_SLOPES;
     m.ux = f;
@@ -877,10 +883,11 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >
     // ---- Wald z^2, joint Wald chi2, decisions: scalar work of one lane ----
     if (lane == 0u) {
       const uint32_t p = (uint32_t)P;
+      constexpr uint32_t TS = P > 8 ? 16u : 8u;
       const ldd* beta = m.tail;
-      const ldd* Lx = m.tail + 8;
-      ldd* U = m.tail + 8 + 64;
-      ldd* Lc = U + 64;
+      const ldd* Lx = m.tail + TS;
+      ldd* U = m.tail + TS + TS * TS;
+      ldd* Lc = U + 8u * TS;
       ldd* cj = Lc + 64;
       const double sigma_sq = m.misc[0];
       const double* crow = prm.crit + (size_t)g * prm.crit_stride;
@@ -892,16 +899,16 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >
 #pragma unroll
       for (int t = 0; t < MAX_T_WAVE; ++t) {
         tsq[t] = __builtin_nan("");
-        for (uint32_t i = 0; i < p; ++i) U[t * 8 + i] = 0.0;
+        for (uint32_t i = 0; i < p; ++i) U[t * TS + i] = 0.0;
         if (((tkeep >> t) & 1u) && conv) {
           const double* c = prm.contrast + t * MAX_P;
           double est = 0.0, nq = 0.0;
           for (uint32_t i = 0; i < p; ++i) {
             est = __builtin_fma(c[i], beta[i], est);
             double acc = c[i];
-            for (uint32_t q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i * 8u + q], U[t * 8 + q], acc);
-            U[t * 8 + i] = acc / Lx[i * 8u + i];
-            nq = __builtin_fma(U[t * 8 + i], U[t * 8 + i], nq);
+            for (uint32_t q = 0; q < i; ++q) acc = __builtin_fma(-Lx[i * TS + q], U[t * TS + q], acc);
+            U[t * TS + i] = acc / Lx[i * TS + i];
+            nq = __builtin_fma(U[t * TS + i], U[t * TS + i], nq);
           }
           const double var = sigma_sq * nq;
           if (var > LMG_NEAR_ZERO && var < __builtin_inf()) tsq[t] = est * est / var;
@@ -917,14 +924,14 @@ __global__ __launch_bounds__(GW, ((Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >
             continue;
           }
           double dd = 0.0;
-          for (uint32_t i = 0; i < p; ++i) dd = __builtin_fma(U[j * 8u + i], U[j * 8u + i], dd);
+          for (uint32_t i = 0; i < p; ++i) dd = __builtin_fma(U[j * TS + i], U[j * TS + i], dd);
           dd *= sigma_sq;
           for (uint32_t t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j * 8u + t], Lc[j * 8u + t], dd);
           jok = jok && (dd > 0.0);
           Lc[j * 8u + j] = __builtin_sqrt(dd);
           for (uint32_t i2 = j + 1u; i2 < nt; ++i2) {
             double vv = 0.0;
-            for (uint32_t i = 0; i < p; ++i) vv = __builtin_fma(U[i2 * 8u + i], U[j * 8u + i], vv);
+            for (uint32_t i = 0; i < p; ++i) vv = __builtin_fma(U[i2 * TS + i], U[j * TS + i], vv);
             vv *= sigma_sq;
             for (uint32_t t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2 * 8u + t], Lc[j * 8u + t], vv);
             Lc[i2 * 8u + j] = vv / Lc[j * 8u + j];

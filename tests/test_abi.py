@@ -162,7 +162,7 @@ def test_unsupported_fails_loudly_never_falls_back(engine):
         engine.run_batch(s, [100], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "design columns" in str(e.value)
     s = spec_c2b()
-    s.estimator = S.EstimatorSpec.Mle     # random slopes run on the device up to 8 design columns; this one has 9
+    s.estimator = S.EstimatorSpec.Mle     # random slopes run on the device up to 8 design columns (intercept-only groupings: 12); this one has 9
     s.n_factor_dummies, s.factor_n_levels, s.factor_proportions = 3, [4], [0.25, 0.25, 0.25, 0.25]
     s.effect_sizes = s.effect_sizes + [0.1, 0.1, 0.1]
     s.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2,

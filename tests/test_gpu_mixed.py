@@ -210,3 +210,35 @@ def test_seven_and_eight_design_columns_under_slopes_and_extra_groupings(family,
     assert np.allclose(stat[both], ora.stat_capture[both], rtol=2e-5, atol=1e-8)
     red = engine.run_batch(spec, [n], n_sims, BASE_SEED, per_sim=False)
     assert np.array_equal(red.counters, dev.counters)
+
+
+@pytest.mark.parametrize("k,extra,scen", [(8, False, False), (9, False, False), (10, True, False), (9, False, True), (11, False, False)])
+def test_random_intercept_lmm_with_nine_to_twelve_design_columns(k, extra, scen, engine, oracle):
+    """Mle with intercept-only groupings and 9 .. 12 design columns runs on the run-time-sized general mixed-model kernel
+    (round 3; the register-resident random-intercept kernels stop at 8).  Device vs oracle on the same seeds: decisions
+    and convergence equal up to one replicate, statistics to 2e-5, counters-only == fold."""
+    from helpers import base_spec, preset
+    from mcpower_amd import spec as S
+    spec = base_spec(k)
+    spec.estimator = S.EstimatorSpec.Mle
+    spec.effect_sizes = [0.0] + [0.25, 0.2, 0.0, 0.15, -0.2, 0.0, 0.1, 0.15, -0.1, 0.0, 0.12][:k]
+    spec.target_indices = [1, 2, 4, k]
+    if scen:   # the general data path carries 9 continuous predictors: a 3-level factor brings the design to 12 columns
+        spec.n_factor_dummies, spec.factor_n_levels, spec.factor_proportions, spec.factor_sampled = 2, [3], [0.4, 0.3, 0.3], [None]
+        spec.effect_sizes = spec.effect_sizes + [0.2, -0.15]
+    eg = [{"relation": {"Crossed": {"n_clusters": 6}}, "tau_squared": 0.15, "slopes": []}] if extra else []
+    spec.cluster = S.ClusterSpec(sizing=("FixedClusters", 12), tau_squared=0.3, extra_groupings=eg)
+    spec.extra_slope_cols = [[] for _ in eg]
+    spec.scenario = preset("realistic") if scen else S.ScenarioPerturbations(name="optimistic", truth_start=True)
+    ns = [360] if extra else [240, 480]
+    g = engine.run_batch(spec, ns, 400, BASE_SEED, stat_capture=True)
+    o = oracle.run_batch(spec, ns, 400, BASE_SEED, stat_capture=True, n_threads=16)
+    slack = 2 if scen else 1
+    assert (g.converged != o.converged).sum() <= slack and (g.uncorrected != o.uncorrected).sum() <= 2 * slack
+    assert (g.joint_unc != o.joint_unc).sum() <= slack
+    m = ~np.isnan(o.stat_capture) & ~np.isnan(g.stat_capture)
+    if not scen:
+        assert np.quantile(np.abs(g.stat_capture[m] - o.stat_capture[m]) / np.maximum(np.abs(o.stat_capture[m]), 1e-12), 0.99) < 2e-5
+    c = engine.run_batch(spec, ns, 400, BASE_SEED, per_sim=False)
+    assert np.array_equal(c.counters, g.counters)
+    assert g.uncorrected[:, -1, 0].mean() > 0.5
