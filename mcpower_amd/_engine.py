@@ -493,7 +493,7 @@ MIN_ROWS_PER_CLUSTER = 2          # configs/config.json limits.min_rows_per_clus
 Z_GATE = 2.0                      # fit.rs:27
 MIN_HINT_POWER = 0.5              # fit.rs:33
 EXTRAPOLATION_CAP = 2.0           # fit.rs:38
-MAX_GRID_PER_CALL = 64            # device limit of one run_batch call (mcp_params.hpp MAX_GRID)
+MAX_GRID_PER_CALL = 256           # device limit of one run_batch call (mcp_params.hpp MAX_GRID)
 
 
 def _ceil_to(x: int, a: int) -> int:

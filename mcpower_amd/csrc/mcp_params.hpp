@@ -13,7 +13,7 @@ namespace mcp {
 constexpr int MAX_P = 16;        // design columns incl. intercept handled by the register-resident OLS kernels
 constexpr int MAX_P_WAVE = 8;    // ... by the wave-per-replicate GLM kernels (Mle: 6)
 constexpr int MAX_K = 15;        // continuous predictors
-constexpr int MAX_GRID = 64;     // sample-size grid points per call
+constexpr int MAX_GRID = 256;    // sample-size grid points per call (64 until round 3; only SimParams::ns is sized by it)
 constexpr int MAX_T = 16;        // tests per fit (marginal targets + contrast pairs)
 constexpr int MAX_P_FUSED = 12;   // ... by the fused lane-per-replicate OLS kernel (P = 9..12: Cholesky in place, <= 12 tests)
 constexpr int MAX_T_WAVE = 8;    // ... in the GLM / LMM kernels (no contrast pairs there, targets <= P - 1)

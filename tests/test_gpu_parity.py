@@ -571,6 +571,25 @@ def test_c5_grid_sweep_under_the_robustness_presets_matches_oracle(name, engine,
     assert ku[-1] > ku[0] and (np.diff(ku) >= -40).all()      # power rises along the grid (shared draws: nearly monotone)
 
 
+def test_grids_longer_than_64_sample_sizes_in_one_call(engine, oracle):
+    """One call carries up to 256 sample sizes (64 until round 3): a 150-point OLS grid and a 90-point clustered LMM grid --
+    the fit state of a clustered grid (theta carried from N to N) cannot be split over calls."""
+    spec = spec_c2b()
+    grid = list(range(30, 30 + 150 * 6, 6))
+    g, o = _both(engine, oracle, spec, grid, 300)
+    _assert_batch_equal(g, o)
+    from helpers import spec_c4
+    lmm = spec_c4()
+    sizes = [30 * v for v in range(4, 94)]
+    g = engine.run_batch(lmm, sizes, 64, BASE_SEED)
+    o = oracle.run_batch(lmm, sizes, 64, BASE_SEED, n_threads=16)
+    assert g.uncorrected.shape == (64, 90, lmm.n_targets)
+    assert (g.uncorrected != o.uncorrected).sum() <= 3 and (g.converged != o.converged).sum() <= 1
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, list(range(30, 30 + 257)), 8, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and "256 sample sizes" in str(e.value)
+
+
 @pytest.mark.parametrize("k", [7, 8, 9])
 def test_seven_to_nine_continuous_predictors_on_the_general_path(k, engine, oracle):
     """The per-replicate scenario record packs one 3-bit marginal code per continuous predictor: up to 9 of them (6 in round 2).
