@@ -287,8 +287,8 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
     for (uint32_t e = 0; e < spec->cluster.n_extra_groupings; ++e) mle_wide = mle_wide && spec->cluster.extra[e].slopes.n_slopes == 0;
   }
   if (mle_wide) lmm_general = true;
-  if (spec->estimator != MCP_EST_OLS && !glm_plain && ((P > (uint32_t)MAX_P_WAVE && !mle_wide) || nt > (uint32_t)MAX_T_WAVE))
-    return unsupported("Mle / clustered Glm with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests (Mle with random intercepts only: 12 columns)");
+  if (spec->estimator != MCP_EST_OLS && !glm_plain && ((P > (uint32_t)MAX_P_WAVE && !mle_wide) || nt > (mle_wide ? 12u : (uint32_t)MAX_T_WAVE)))
+    return unsupported("Mle / clustered Glm with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests (Mle with random intercepts only: 12 columns, 12 tests from 9 columns on)");
   if (spec->estimator == MCP_EST_GLM) {
     if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS) return unsupported("Glm on a Continuous outcome");
     if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL)
@@ -786,7 +786,7 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   // keep the 8 / 8 of their own kernels)
   // (general data path: 9 columns -- the scenario variant of the fused kernel spills from P = 10)
   const uint32_t hot_limit = spec->estimator == MCP_EST_OLS ? (general ? 9u : (uint32_t)MAX_P_FUSED) : (mle_wide ? 12u : (uint32_t)MAX_P_WAVE);
-  const bool wide = P > hot_limit || nt > (spec->estimator == MCP_EST_OLS ? (uint32_t)MAX_P_FUSED : (uint32_t)MAX_T_WAVE);
+  const bool wide = P > hot_limit || nt > (spec->estimator == MCP_EST_OLS ? (uint32_t)MAX_P_FUSED : (mle_wide ? 12u : (uint32_t)MAX_T_WAVE));
   // clustered data fitted by OLS ignoring the clustering (orchestrator tests/clustered_ols_smoke.rs): the random
   // intercept of a row's cluster is re-drawn per row on the reduced-design kernel
   const bool ols_cluster = spec->cluster.present && spec->estimator == MCP_EST_OLS;

@@ -486,10 +486,10 @@ __device__ __forceinline__ void lmg_clamp(const SimParams& prm, ldd* x, uint32_t
 // SCEN: general data path (scenario design records, non-normal marginals / residuals, per-study effects,
 // heteroskedastic residuals) plus the LME knobs -- random-effect shape, one ICC jitter per grouping
 template <int P, int Q0, bool SCEN>
-// (three random effects on the eliminated grouping, seven or more design columns, and a slope on the general data path or with six
-// columns -- 12 B over -- get 256 registers instead of 168, or the block algebra spills; those designs are LDS-bound below 3 waves
-// per SIMD anyway)
-__global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || (Q0 == 2 && (SCEN || P >= 6))) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
+// (three random effects on the eliminated grouping, nine or more design columns and the general data path from seven columns on get 256
+// registers instead of 168, or the block algebra spills -- 20-108 B; the two widest general-path variants take all 512.  Those designs
+// are LDS-bound below 3 waves per SIMD anyway)
+__global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 9 || (SCEN && P >= 7)) ? 2 : MCP_LMG_WAVES)) void lmm_general_kernel(const SimParams* __restrict__ pp) {
   extern __shared__ double lds_d[];
   const SimParams& prm = *pp;
   const uint32_t lane = threadIdx.x;
@@ -525,7 +525,8 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || 
     m.tm = e; e += 27;
     m.misc = e; e += 8;
     constexpr uint32_t TS = P > 8 ? 16u : 8u;
-    m.tail = e; e += TS + TS * TS + 8u * TS + 64 + 8 + 8;  // beta | L | U | Lc | cj | tsq
+    constexpr uint32_t MTL = P > 8 ? 12u : 8u, TCL = P > 8 ? 16u : 8u;  // tests per fit, stride of their joint factor
+    m.tail = e; e += TS + TS * TS + MTL * TS + TCL * TCL + TCL + 8;  // beta | L | U | Lc | cj | spare
     m.u0 = f; f += L0;
     m.us = f; f += (size_t)L0 * LMG_MAX_SLOPES;
     m.ux = f;
@@ -824,7 +825,11 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || 
       if (lane < d) {
         double v;
         if (has_prev) v = m.carry[lane];  // theta-hat of the last converged grid point
-        else if (prm.truth_start) v = prm.lmg_theta_truth[lane];
+        else if (prm.truth_start) {
+          uint32_t li = lane;
+          asm volatile("" : "+v"(li));  // opaque per grid point: hoisted out of the grid loop, the table address sat in two VGPRs for the whole kernel (12 B of scratch at the 168-register cap)
+          v = prm.lmg_theta_truth[li];
+        }
         else v = lmg_is_diag(prm, lane) ? 1.0 : 0.0;
         if ((has_prev || prm.truth_start) && v < 0.01) v = 0.01;  // THETA_TRUTH_FLOOR on every component of a given start
         x0[lane] = v;
@@ -887,17 +892,19 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || 
       const ldd* beta = m.tail;
       const ldd* Lx = m.tail + TS;
       ldd* U = m.tail + TS + TS * TS;
-      ldd* Lc = U + 8u * TS;
-      ldd* cj = Lc + 64;
+      constexpr int MT = P > 8 ? 12 : MAX_T_WAVE;      // tests per fit: the wide designs test up to 12
+      constexpr uint32_t TC = P > 8 ? 16u : 8u;        // row stride of the joint-test factor
+      ldd* Lc = U + (uint32_t)MT * TS;
+      ldd* cj = Lc + TC * TC;
       const double sigma_sq = m.misc[0];
       const double* crow = prm.crit + (size_t)g * prm.crit_stride;
-      double tsq[MAX_T_WAVE];
+      double tsq[MT];
       uint32_t tkeep = 0;  // targets whose column is in the fitted model
 #pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t)
+      for (int t = 0; t < MT; ++t)
         if ((uint32_t)t < nt && ((keep >> prm.test_pos[t]) & 1u)) tkeep |= 1u << t;
 #pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t) {
+      for (int t = 0; t < MT; ++t) {
         tsq[t] = __builtin_nan("");
         for (uint32_t i = 0; i < p; ++i) U[t * TS + i] = 0.0;
         if (((tkeep >> t) & 1u) && conv) {
@@ -920,29 +927,29 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || 
         double qsum = 0.0;
         for (uint32_t j = 0; j < nt; ++j) {
           if (!((tkeep >> j) & 1u)) {  // untestable target: identity row, no contribution
-            for (uint32_t i2 = j; i2 < nt; ++i2) Lc[i2 * 8u + j] = i2 == j ? 1.0 : 0.0;
+            for (uint32_t i2 = j; i2 < nt; ++i2) Lc[i2 * TC + j] = i2 == j ? 1.0 : 0.0;
             continue;
           }
           double dd = 0.0;
           for (uint32_t i = 0; i < p; ++i) dd = __builtin_fma(U[j * TS + i], U[j * TS + i], dd);
           dd *= sigma_sq;
-          for (uint32_t t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j * 8u + t], Lc[j * 8u + t], dd);
+          for (uint32_t t = 0; t < j; ++t) dd = __builtin_fma(-Lc[j * TC + t], Lc[j * TC + t], dd);
           jok = jok && (dd > 0.0);
-          Lc[j * 8u + j] = __builtin_sqrt(dd);
+          Lc[j * TC + j] = __builtin_sqrt(dd);
           for (uint32_t i2 = j + 1u; i2 < nt; ++i2) {
             double vv = 0.0;
             for (uint32_t i = 0; i < p; ++i) vv = __builtin_fma(U[i2 * TS + i], U[j * TS + i], vv);
             vv *= sigma_sq;
-            for (uint32_t t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2 * 8u + t], Lc[j * 8u + t], vv);
-            Lc[i2 * 8u + j] = vv / Lc[j * 8u + j];
+            for (uint32_t t = 0; t < j; ++t) vv = __builtin_fma(-Lc[i2 * TC + t], Lc[j * TC + t], vv);
+            Lc[i2 * TC + j] = vv / Lc[j * TC + j];
           }
         }
         for (uint32_t i = 0; i < nt; ++i) {
           const double* c = prm.contrast + i * MAX_P;
           double vv = 0.0;
           for (uint32_t q = 0; q < p; ++q) vv = __builtin_fma(((tkeep >> i) & 1u) ? c[q] : 0.0, beta[q], vv);
-          for (uint32_t t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i * 8u + t], cj[t], vv);
-          cj[i] = vv / Lc[i * 8u + i];
+          for (uint32_t t = 0; t < i; ++t) vv = __builtin_fma(-Lc[i * TC + t], cj[t], vv);
+          cj[i] = vv / Lc[i * TC + i];
           qsum = __builtin_fma(cj[i], cj[i], qsum);
         }
         // the table row holds chi2(n_targets); a reduced round tests its kept targets (batch.rs:1456-1468)
@@ -950,14 +957,14 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || 
         joint_sig = jok && (qsum < __builtin_inf()) && (qsum > joint_crit);
       }
       uint32_t unc_bits = 0, cor_bits = 0;
-      decide_tests<MAX_T_WAVE>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
+      decide_tests<MT>(tsq, nt, crow, prm.correction, unc_bits, cor_bits);
       if (!conv) {
         unc_bits = 0;
         cor_bits = 0;
       }
       const size_t cell = (size_t)(prm.out_base + lsim) * prm.n_grid + g;
 #pragma unroll
-      for (int t = 0; t < MAX_T_WAVE; ++t)
+      for (int t = 0; t < MT; ++t)
         if ((uint32_t)t < nt) {
           prm.unc[cell * nt + t] = (uint8_t)((unc_bits >> t) & 1u);
           prm.cor[cell * nt + t] = (uint8_t)((cor_bits >> t) & 1u);
@@ -971,7 +978,7 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 7 || 
       if (prm.overall) prm.overall[cell] = 0;  // batch.rs:1449-1451
       if (prm.stat && g == 0u) {
 #pragma unroll
-        for (int t = 0; t < MAX_T_WAVE; ++t)
+        for (int t = 0; t < MT; ++t)
           if ((uint32_t)t < nt) prm.stat[(size_t)(prm.out_base + lsim) * nt + t] = tsq[t];
       }
     }

@@ -222,7 +222,7 @@ def test_random_intercept_lmm_with_nine_to_twelve_design_columns(k, extra, scen,
     spec = base_spec(k)
     spec.estimator = S.EstimatorSpec.Mle
     spec.effect_sizes = [0.0] + [0.25, 0.2, 0.0, 0.15, -0.2, 0.0, 0.1, 0.15, -0.1, 0.0, 0.12][:k]
-    spec.target_indices = [1, 2, 4, k]
+    spec.target_indices = [1, 2, 4, k] if k < 11 else list(range(1, k + 1))   # the widest design tests every effect: 11 tests
     if scen:   # the general data path carries 9 continuous predictors: a 3-level factor brings the design to 12 columns
         spec.n_factor_dummies, spec.factor_n_levels, spec.factor_proportions, spec.factor_sampled = 2, [3], [0.4, 0.3, 0.3], [None]
         spec.effect_sizes = spec.effect_sizes + [0.2, -0.15]
