@@ -26,7 +26,7 @@ namespace mcp {
 hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, uint32_t n_grid, hipStream_t st);
 size_t ols_rec_fields(int P);
 hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims, bool scen, hipStream_t st);
-hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
+hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, uint32_t between_floats, hipStream_t st);
 hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
 hipError_t launch_scenario_design(const SimParams* d_prm, uint32_t n_sims, hipStream_t st, uint32_t* d_hist = nullptr);
 hipError_t launch_ols_fit(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, hipStream_t st);
@@ -702,7 +702,10 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));
     } else if (reduced) {
-      DEV_TRY(mcp::launch_ols_reduced((int)P, d_prm + c, h_prm[c].n_sims, flavor, st));
+      // cluster-level predictors under OLS, FixedClusters sizing: the first v rows park their marked values in LDS
+      const uint32_t between_floats = (prm.has_cluster && prm.between_mask && prm.cluster_fixed_clusters)
+                                          ? prm.cluster_v * (uint32_t)__builtin_popcount(prm.between_mask) : 0u;
+      DEV_TRY(mcp::launch_ols_reduced((int)P, d_prm + c, h_prm[c].n_sims, flavor, between_floats, st));
       DEV_TRY(hipEventRecord(e1, st));
       DEV_TRY(mcp::launch_fold_flags(d_prm + c, h_prm[c].n_sims, st));
       DEV_TRY(hipEventRecord(e2, st));

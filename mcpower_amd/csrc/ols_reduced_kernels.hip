@@ -243,6 +243,17 @@ __global__ __launch_bounds__(BLOCK) void ols_reduced_kernel(const SimParams* __r
     const double t2 = prm.scen_tau_sq[lsim];
     tau_rep = __builtin_sqrt(t2 > 0.0 ? t2 : 0.0);
   }
+  // cluster-level (between) predictors under OLS on clustered data (data_gen.rs:606-636): a row takes the marked columns from
+  // its cluster's representative row, then interactions and the outcome follow from the broadcast values.  Rows come in
+  // order and the representative never comes after the row, so one lane can do it on the fly: FixedSize clusters are
+  // contiguous (the current cluster's values stay in registers), FixedClusters interleave (row i belongs to cluster
+  // i mod v, its representative is row i mod v: the first v rows park their marked values in LDS behind the staging area)
+  const uint32_t bmask = prm.has_cluster ? prm.between_mask : 0u;
+  const uint32_t nb = (uint32_t)__popc(bmask);
+  float xrep[P];
+#pragma unroll
+  for (int c = 0; c < P; ++c) xrep[c] = 0.0f;
+  float* bl = stage_lds + (size_t)(SCEN ? (P + 1) : P) * 4u * BLOCK + threadIdx.x;
   Suff<P> s;
   suff_reset(s);
   unsigned long long level_counts[MAX_FACTORS] = {0ull, 0ull, 0ull, 0ull};  // 4-bit saturating count per level
@@ -263,7 +274,30 @@ __global__ __launch_bounds__(BLOCK) void ols_reduced_kernel(const SimParams* __r
             const uint32_t cid = prm.cluster_fixed_clusters ? rr % prm.cluster_v : rr / prm.cluster_v;
             u_re = (double)(float)(draw_cluster_effect(prm, k0, k1, cid < prm.n_clusters_max ? cid : 0u) * tau_rep);
           }
-          build_row<P, true, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
+          if (bmask == 0u) {
+            build_row<P, true, BLOCK, 0, SCEN>(prm, cx, k0, k1, st, r, rr, x, y, u_re, &sl);
+          } else {
+            const float e = build_x<P, true, BLOCK, SCEN>(prm, cx, k0, k1, st, r, rr, x, &sl);
+            const uint32_t cvb = prm.cluster_v;
+            const bool fixed = prm.cluster_fixed_clusters != 0u;
+            const uint32_t repr = fixed ? rr % cvb : rr - rr % cvb;
+            uint32_t slot = 0;
+#pragma unroll
+            for (int c = 1; c < P; ++c)
+              if ((bmask >> c) & 1u) {
+                if (fixed) {
+                  float* cell = bl + (size_t)(repr * nb + slot) * BLOCK;
+                  if (rr == repr) *cell = x[c];
+                  else x[c] = *cell;
+                } else {
+                  if (rr == repr) xrep[c] = x[c];
+                  else x[c] = xrep[c];
+                }
+                ++slot;
+              }
+            rebuild_interactions<P>(cx, x);
+            finish_row<P, 0, SCEN>(prm, cx, x, e, y, u_re, &sl);
+          }
           suff_add_row<P>(s, x, y);
           if (min_c) {  // level of every factor read back from its dummy block (exact 0.0 / 1.0)
 #pragma unroll
@@ -371,12 +405,18 @@ hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims,
   return hipGetLastError();
 }
 
+// between_floats: floats per lane of the cluster-level predictor park (clusters x marked columns under FixedClusters, else 0)
 template <int FLAVOR>
-static hipError_t launch_reduced_f(int P, const SimParams* d_prm, uint32_t n_sims, hipStream_t st) {
+static hipError_t launch_reduced_f(int P, const SimParams* d_prm, uint32_t n_sims, uint32_t between_floats, hipStream_t st) {
   const dim3 block(BLOCK), grid((n_sims + BLOCK - 1) / BLOCK);
 #define LR(PP)                                                                                                   \
   case PP: {                                                                                                     \
-    const size_t lds = (size_t)(FLAVOR == 2 ? (PP + 1) : PP) * 4u * BLOCK * sizeof(float);                       \
+    const size_t lds = ((size_t)(FLAVOR == 2 ? (PP + 1) : PP) * 4u + between_floats) * BLOCK * sizeof(float);    \
+    if (lds > 48 * 1024) {                                                                                       \
+      hipError_t e = hipFuncSetAttribute((const void*)ols_reduced_kernel<PP, FLAVOR>,                            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      if (e != hipSuccess) return e;                                                                             \
+    }                                                                                                            \
     hipLaunchKernelGGL((ols_reduced_kernel<PP, FLAVOR>), grid, block, lds, st, d_prm);                           \
   } break;
   switch (P) {
@@ -387,8 +427,8 @@ static hipError_t launch_reduced_f(int P, const SimParams* d_prm, uint32_t n_sim
   return hipGetLastError();
 }
 
-hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st) {
-  return flavor == 2 ? launch_reduced_f<2>(P, d_prm, n_sims, st) : launch_reduced_f<1>(P, d_prm, n_sims, st);
+hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, uint32_t between_floats, hipStream_t st) {
+  return flavor == 2 ? launch_reduced_f<2>(P, d_prm, n_sims, between_floats, st) : launch_reduced_f<1>(P, d_prm, n_sims, between_floats, st);
 }
 
 }  // namespace mcp

@@ -472,6 +472,33 @@ def test_lmm_cluster_level_predictors_are_broadcast(engine, oracle):
         assert np.allclose(rows[:, 4], rows[:, 1] * rows[:, 2])
 
 
+def test_ols_on_clustered_data_with_cluster_level_predictors(engine, oracle):
+    """OLS ignoring the clustering (orchestrator tests/clustered_ols_smoke.rs) with cluster-level (between) predictors -- refused
+    until round 3.  The lane-per-replicate kernel broadcasts on the fly (the representative never comes after the row):
+    same data as the oracle, so the decisions follow; both sizings, plain and scenario data path, a cross-level interaction."""
+    from helpers import preset
+    spec = S.SimulationSpec(n_non_factor=2, n_factor_dummies=1, correlation=[1.0, 0.2, 0.2, 1.0],
+                            var_types=[S.Distribution.Normal] * 2, var_params=[0.0, 0.0], factor_n_levels=[2],
+                            factor_proportions=[0.5, 0.5], factor_sampled=[True], interactions=[[1, 2]],
+                            effect_sizes=[0.0, 0.3, 0.4, 0.5, 0.2], target_indices=[1, 2, 3, 4],
+                            between_var_indices=[2, 3], estimator=S.EstimatorSpec.Ols,
+                            cluster=S.ClusterSpec(sizing=("FixedClusters", 12), tau_squared=0.3))
+    for sizing in (("FixedClusters", 12), ("FixedSize", 8)):
+        for scen in (None, "realistic"):
+            spec.cluster = S.ClusterSpec(sizing=sizing, tau_squared=0.3)
+            spec.scenario = preset(scen) if scen else S.ScenarioPerturbations(name="optimistic")
+            g = engine.run_batch(spec, [96, 240], 1500, 83, stat_capture=True)
+            o = oracle.run_batch(spec, [96, 240], 1500, 83, stat_capture=True, n_threads=8)
+            m = ~np.isnan(o.stat_capture)
+            assert np.array_equal(np.isnan(g.stat_capture), ~m), (sizing, scen)
+            bad = np.abs(g.stat_capture - o.stat_capture) > 1e-6 * np.abs(o.stat_capture) + 1e-9
+            assert (bad & m).any(axis=1).sum() <= (4 if scen else 0), (sizing, scen)
+            for f in ("uncorrected", "corrected", "converged"):
+                assert (getattr(g, f) != getattr(o, f)).sum() <= (3 if scen else 0), (sizing, scen, f)
+            c = engine.run_batch(spec, [96, 240], 1500, 83, per_sim=False)
+            assert np.array_equal(c.counters, g.counters)
+
+
 def test_lmm_with_eight_design_columns(engine, oracle):
     spec = S.SimulationSpec(n_non_factor=3, n_factor_dummies=2, correlation=[1.0, 0.3, 0.0, 0.3, 1.0, 0.1, 0.0, 0.1, 1.0],
                             var_types=[S.Distribution.Normal] * 3, var_params=[0.0] * 3, factor_n_levels=[3],
