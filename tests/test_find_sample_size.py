@@ -215,9 +215,9 @@ def test_long_grid_splits_into_device_sized_calls(oracle):
         calls.append(list(ns))
         return inner(spec, ns, n_sims, seed, sink)
 
-    out = E.find_sample_size(_blob("ols_contract"), 0.8, 30, 129, 120, 5, "grid", by=1, _runner=runner)
+    out = E.find_sample_size(_blob("ols_contract"), 0.8, 30, 329, 120, 5, "grid", by=1, _runner=runner)
     res = out["scenarios"]["optimistic"]
-    assert [len(c) for c in calls] == [64, 36] and res["sample_sizes"] == list(range(30, 130))
+    assert [len(c) for c in calls] == [256, 44] and res["sample_sizes"] == list(range(30, 330))   # 256 sample sizes per device call
     (sc,) = E.lower_contracts(K.decode_contracts(_blob("ols_contract")), 5)
     # rows are prefix-stable, so a sub-grid reproduces the same flags as the full grid in one call
     part = oracle.run_batch(sc["spec"], [40, 100, 129], 120, sc["base_seed"])
@@ -228,7 +228,7 @@ def test_long_grid_splits_into_device_sized_calls(oracle):
                                   "extra_groupings": []}
     c["test"]["targets"] = [{"kind": "marginal", "term": 1}]
     with pytest.raises(S.EngineError):
-        E.find_sample_size(_pack(c), 0.8, 10, 1000, 50, 5, "grid", by=5, _runner=runner)
+        E.find_sample_size(_pack(c), 0.8, 10, 2000, 50, 5, "grid", by=5, _runner=runner)   # 399 clustered sizes: not splittable
 
 
 @pytest.mark.gpu
