@@ -33,13 +33,14 @@ def random_spec(seed: int, family: str, legacy_sizes: bool = False):
     scen = family.endswith("_scen")
     clustered = family in ("lme", "lme_scen", "glmm")
     # general OLS path: up to 9 continuous predictors; random-intercept LMMs: up to 12 design columns (9 .. 12 on the general kernel)
-    k = int(rng.integers(1, (8 if family in ("lme", "lme_scen") else 4) if clustered else (10 if family in ("ols_scen", "ols_general") else 6)))
+    wide_lme = family in ("lme", "lme_scen") and not legacy_sizes   # (the legacy generator keeps its ranges: seed 1098 is pinned to it)
+    k = int(rng.integers(1, (8 if wide_lme else 4) if clustered else (10 if family in ("ols_scen", "ols_general") else 6)))
     n_fac = int(rng.integers(0, 2 if clustered or family == "glmm" else 3))
     if family == "glmm":
         k, n_fac = int(rng.integers(1, 3)), 0
     levels = [int(rng.integers(2, 5)) for _ in range(n_fac)]
     dummies = sum(l - 1 for l in levels)
-    max_p = 12 if family in ("ols", "ols_scen", "ols_general", "lme", "lme_scen") else 8
+    max_p = 12 if (family in ("ols", "ols_scen", "ols_general") or wide_lme) else 8
     while 1 + k + dummies > max_p - 1 and levels:
         levels.pop()
         dummies = sum(l - 1 for l in levels)
