@@ -161,6 +161,10 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: without it RCCL's bring-up fails
+    # with hipIpcGetMemHandle: invalid argument); the launcher's environment normally carries it already
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
     import torch
     import torch.distributed as dist
 
