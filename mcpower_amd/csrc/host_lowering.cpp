@@ -279,16 +279,14 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   const bool glm_plain = spec->estimator == MCP_EST_GLM && !spec->cluster.present;
   if (glm_plain && (P > (uint32_t)MAX_P || nt > (uint32_t)MAX_T))
     return unsupported("Glm with more than " + std::to_string(MAX_P) + " design columns or tests");
-  // Mle with intercept-only groupings: 9 .. 12 design columns run on the run-time-sized general mixed-model kernel
-  // (lmm_general_impl.hpp, instantiated for them at block width 1); everything else of this family stays at 8
+  // Mle with at most one random slope on the primary grouping: 9 .. 12 design columns run on the run-time-sized general
+  // mixed-model kernel (lmm_general_impl.hpp, instantiated for them at block widths 1 and 2); the rest of this family stays at 8
   bool mle_wide = false;
-  if (spec->estimator == MCP_EST_MLE && spec->cluster.present && P > (uint32_t)MAX_P_WAVE && P <= 12u) {
-    mle_wide = spec->cluster.slopes.n_slopes == 0;
-    for (uint32_t e = 0; e < spec->cluster.n_extra_groupings; ++e) mle_wide = mle_wide && spec->cluster.extra[e].slopes.n_slopes == 0;
-  }
+  if (spec->estimator == MCP_EST_MLE && spec->cluster.present && P > (uint32_t)MAX_P_WAVE && P <= 12u)
+    mle_wide = spec->cluster.slopes.n_slopes <= 1;   // the extras may carry slopes of their own: only the eliminated block width is compiled in
   if (mle_wide) lmm_general = true;
   if (spec->estimator != MCP_EST_OLS && !glm_plain && ((P > (uint32_t)MAX_P_WAVE && !mle_wide) || nt > (mle_wide ? 12u : (uint32_t)MAX_T_WAVE)))
-    return unsupported("Mle / clustered Glm with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests (Mle with random intercepts only: 12 columns, 12 tests from 9 columns on)");
+    return unsupported("Mle / clustered Glm with more than " + std::to_string(MAX_P_WAVE) + " design columns or tests (Mle with at most one random slope on the primary grouping: 12 columns, 12 tests from 9 columns on)");
   if (spec->estimator == MCP_EST_GLM) {
     if (spec->outcome_kind == MCP_OUTCOME_CONTINUOUS) return unsupported("Glm on a Continuous outcome");
     if (spec->outcome_kind == MCP_OUTCOME_COUNT && spec->link != MCP_LINK_CANONICAL)

@@ -35,7 +35,7 @@ hipError_t launch_lmm_general(int P, int q0, const SimParams* d_prm, uint32_t n_
     hipLaunchKernelGGL((lmm_general_kernel<PP, QQ, false>), grid, block, lds, st, d_prm);                                 \
     return hipGetLastError();                                                                                          \
   }
-  LG(2, 1) LG(2, 2) LG(3, 1) LG(3, 2) LG(3, 3) LG(4, 1) LG(4, 2) LG(4, 3) LG(5, 1) LG(5, 2) LG(5, 3) LG(6, 1) LG(6, 2) LG(6, 3) LG(7, 1) LG(7, 2) LG(7, 3) LG(8, 1) LG(8, 2) LG(8, 3) LG(9, 1) LG(10, 1) LG(11, 1) LG(12, 1)
+  LG(2, 1) LG(2, 2) LG(3, 1) LG(3, 2) LG(3, 3) LG(4, 1) LG(4, 2) LG(4, 3) LG(5, 1) LG(5, 2) LG(5, 3) LG(6, 1) LG(6, 2) LG(6, 3) LG(7, 1) LG(7, 2) LG(7, 3) LG(8, 1) LG(8, 2) LG(8, 3) LG(9, 1) LG(10, 1) LG(11, 1) LG(12, 1) LG(9, 2) LG(10, 2) LG(11, 2) LG(12, 2)
 #undef LG
   return hipErrorInvalidValue;
 }

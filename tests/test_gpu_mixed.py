@@ -212,8 +212,9 @@ def test_seven_and_eight_design_columns_under_slopes_and_extra_groupings(family,
     assert np.array_equal(red.counters, dev.counters)
 
 
-@pytest.mark.parametrize("k,extra,scen", [(8, False, False), (9, False, False), (10, True, False), (9, False, True), (11, False, False)])
-def test_random_intercept_lmm_with_nine_to_twelve_design_columns(k, extra, scen, engine, oracle):
+@pytest.mark.parametrize("k,extra,scen,slope", [(8, False, False, False), (9, False, False, False), (10, True, False, False), (9, False, True, False),
+                                                (11, False, False, False), (9, False, False, True), (10, True, False, True)])
+def test_random_intercept_lmm_with_nine_to_twelve_design_columns(k, extra, scen, slope, engine, oracle):
     """Mle with intercept-only groupings and 9 .. 12 design columns runs on the run-time-sized general mixed-model kernel
     (round 3; the register-resident random-intercept kernels stop at 8).  Device vs oracle on the same seeds: decisions
     and convergence equal up to one replicate, statistics to 2e-5, counters-only == fold."""
@@ -227,13 +228,15 @@ def test_random_intercept_lmm_with_nine_to_twelve_design_columns(k, extra, scen,
         spec.n_factor_dummies, spec.factor_n_levels, spec.factor_proportions, spec.factor_sampled = 2, [3], [0.4, 0.3, 0.3], [None]
         spec.effect_sizes = spec.effect_sizes + [0.2, -0.15]
     eg = [{"relation": {"Crossed": {"n_clusters": 6}}, "tau_squared": 0.15, "slopes": []}] if extra else []
-    spec.cluster = S.ClusterSpec(sizing=("FixedClusters", 12), tau_squared=0.3, extra_groupings=eg)
+    sl = [{"column": 0, "variance": 0.08, "corr_with_intercept": 0.2, "corr_with": []}] if slope else []   # one random slope: block width 2
+    spec.cluster = S.ClusterSpec(sizing=("FixedClusters", 12), tau_squared=0.3, slopes=sl, extra_groupings=eg)
+    spec.cluster_slope_design_cols = [1] if slope else []
     spec.extra_slope_cols = [[] for _ in eg]
     spec.scenario = preset("realistic") if scen else S.ScenarioPerturbations(name="optimistic", truth_start=True)
     ns = [360] if extra else [240, 480]
     g = engine.run_batch(spec, ns, 400, BASE_SEED, stat_capture=True)
     o = oracle.run_batch(spec, ns, 400, BASE_SEED, stat_capture=True, n_threads=16)
-    slack = 2 if scen else 1
+    slack = 2 if (scen or slope) else 1
     assert (g.converged != o.converged).sum() <= slack and (g.uncorrected != o.uncorrected).sum() <= 2 * slack
     assert (g.joint_unc != o.joint_unc).sum() <= slack
     m = ~np.isnan(o.stat_capture) & ~np.isnan(g.stat_capture)

@@ -19,8 +19,8 @@ OBJECTS = {
     "glmm_kernels.o": ("glmm_kernel", 14),
     "glmm_slopes_kernels.o": ("glmm_slopes_kernel", 26),
     "glmm_general_kernels.o": ("glmm_general_kernel", 14),
-    "lmm_general_kernels.o": ("lmm_general_kernel", 24),
-    "lmm_general_scen_kernels.o": ("lmm_general_kernel", 24),
+    "lmm_general_kernels.o": ("lmm_general_kernel", 28),
+    "lmm_general_scen_kernels.o": ("lmm_general_kernel", 28),
 }
 
 
