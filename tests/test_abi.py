@@ -162,12 +162,13 @@ def test_unsupported_fails_loudly_never_falls_back(engine):
         engine.run_batch(s, [100], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "design columns" in str(e.value)
     s = spec_c2b()
-    s.estimator = S.EstimatorSpec.Mle     # random slopes run on the device up to 8 design columns (intercept-only groupings: 12); this one has 9
+    s.estimator = S.EstimatorSpec.Mle     # two random slopes run on the device up to 8 design columns (at most one slope: 12); this one has 9
     s.n_factor_dummies, s.factor_n_levels, s.factor_proportions = 3, [4], [0.25, 0.25, 0.25, 0.25]
     s.effect_sizes = s.effect_sizes + [0.1, 0.1, 0.1]
     s.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2,
-                              slopes=[{"column": 0, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": []}])
-    s.cluster_slope_design_cols = [1]
+                              slopes=[{"column": 0, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": [0.0]},
+                                      {"column": 1, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": [0.0]}])
+    s.cluster_slope_design_cols = [1, 2]
     with pytest.raises(S.EngineError) as e:
         engine.run_batch(s, [100], 4, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "more than 8 design columns" in str(e.value)
