@@ -197,3 +197,63 @@ def test_design_capture_refuses_structures_it_does_not_draw(engine):
     with pytest.raises(S.EngineError) as e:
         engine.generate_design(spec, 100, 1, BASE_SEED)
     assert e.value.status == S.Status.Unsupported and "design capture" in str(e.value)
+
+
+def _accepted(engine, spec, ns):
+    """The host lowering takes the spec: on a box without a device the call then stops at the device check."""
+    try:
+        engine.run_batch(spec, ns, 4, BASE_SEED)
+    except S.EngineError as e:
+        assert e.status == S.Status.Device, str(e)
+
+
+def _refused(engine, spec, ns, needle):
+    with pytest.raises(S.EngineError) as e:
+        engine.run_batch(spec, ns, 4, BASE_SEED)
+    assert e.value.status == S.Status.Unsupported and needle in str(e.value), str(e.value)
+
+
+def test_structural_limits_of_the_device_path(engine):
+    """DESIGN.md section 8, "limits", as the host lowering enforces them (no device needed): what round 3 widened is accepted,
+    the first size past each limit is refused with a message naming it."""
+    import copy
+    from helpers import base_spec, preset
+    # general data path: 9 continuous predictors
+    s = base_spec(9)
+    s.scenario = preset("realistic")
+    _accepted(engine, s, [120])
+    s = base_spec(10)
+    s.scenario = preset("realistic")
+    _refused(engine, s, [120], "9 continuous predictors")
+    # sample sizes per call
+    _accepted(engine, spec_c2b(), list(range(30, 30 + 256)))
+    _refused(engine, spec_c2b(), list(range(30, 30 + 257)), "256 sample sizes")
+    # Mle: 12 design columns with at most one random slope on the primary grouping, 12 tests there; 8 otherwise
+    m = base_spec(11)
+    m.estimator = S.EstimatorSpec.Mle
+    m.target_indices = list(range(1, 12))
+    m.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2)
+    _accepted(engine, m, [200])
+    one = copy.deepcopy(m)
+    one.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2,
+                                slopes=[{"column": 0, "variance": 0.1, "corr_with_intercept": 0.0, "corr_with": []}])
+    one.cluster_slope_design_cols = [1]
+    _accepted(engine, one, [200])
+    wide = base_spec(12)
+    wide.estimator = S.EstimatorSpec.Mle
+    wide.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.2)
+    _refused(engine, wide, [200], "design columns")
+    # clustered GLM stays at 8 design columns
+    g = base_spec(8)
+    g.estimator, g.outcome_kind = S.EstimatorSpec.Glm, S.OutcomeKind.Binary
+    g.cluster = S.ClusterSpec(sizing=("FixedClusters", 10), tau_squared=0.3)
+    _refused(engine, g, [200], "more than 8 design columns")
+    # OLS on clustered data with cluster-level predictors: accepted up to 96 cluster x column values under FixedClusters sizing
+    o = base_spec(3)
+    o.between_var_indices = [2]
+    o.cluster = S.ClusterSpec(sizing=("FixedClusters", 40), tau_squared=0.2)
+    _accepted(engine, o, [400])
+    o.cluster = S.ClusterSpec(sizing=("FixedClusters", 120), tau_squared=0.2)
+    _refused(engine, o, [480], "cluster-level")
+    o.cluster = S.ClusterSpec(sizing=("FixedSize", 4), tau_squared=0.2)   # contiguous clusters: no limit
+    _accepted(engine, o, [480])
