@@ -487,7 +487,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   if (ols_split) {
     const size_t per_rep = mcp::ols_rec_fields((int)P) * n_ns * sizeof(double);
     const size_t cap = ((size_t)1 << 30) / per_rep;
-    if (chunk > cap) chunk = (uint32_t)(cap & ~(size_t)255);
+    if (chunk > cap) chunk = cap >= 256 ? (uint32_t)(cap & ~(size_t)255) : 256u;  // (44 fields x 256 sizes x 8 B = 90 KB per replicate at most: cap >= 11 000)
   }
   if (chunk > n_sims) chunk = n_sims;
   const uint32_t n_chunks = (n_sims + chunk - 1) / chunk;

@@ -346,8 +346,10 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   if (spec->n_between_var_indices && spec->cluster.present && spec->estimator == MCP_EST_OLS &&
       spec->cluster.sizing == MCP_CLUSTER_FIXED_CLUSTERS) {
     // the lane-per-replicate kernel parks the representatives' marked values in LDS: clusters x marked columns x 1 KiB per block
+    // (next to the staging area, (P + 1) KiB x 4 rows per block, inside the 160 KB of a CU)
     const size_t park = (size_t)spec->cluster.sizing_value * spec->n_between_var_indices * 1024u;
-    if (park > 96u * 1024u) return unsupported("cluster-level (between) predictors under the OLS estimator with more than 96 cluster x column values");
+    if (park > 96u * 1024u || park + (size_t)(P + 1u) * 4096u > 150u * 1024u)
+      return unsupported("cluster-level (between) predictors under the OLS estimator with more than 96 cluster x column values");
   }
   for (uint32_t b = 0; b < spec->n_between_var_indices; ++b)
     if (spec->between_var_indices[b] == 0 || spec->between_var_indices[b] >= 1 + K + spec->n_factor_dummies) {
