@@ -25,6 +25,7 @@
 namespace mcp {
 hipError_t launch_ols_fused(int P, const SimParams* d_prm, uint32_t n_sims, bool grid1, int flavor, uint32_t n_grid, hipStream_t st);
 size_t ols_rec_fields(int P);
+size_t ols_wide_rec_fields(int P);  // ols_wide_kernels.hip: the whole triangle of [1 | X | y]'[1 | X | y]
 hipError_t launch_design_capture(int P, const SimParams* d_prm, uint32_t n_sims, bool scen, hipStream_t st);
 hipError_t launch_ols_reduced(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, uint32_t between_floats, hipStream_t st);
 hipError_t launch_ols_generate(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);
@@ -483,9 +484,11 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   }
   // OLS on the general path or over a grid of sample sizes, narrow designs: the launch is split into a row kernel and a fit kernel (ols_kernels.hip, SPLIT) with the
   // sufficient statistics of every (replicate, grid point) between them: keep one chunk's worth under 1 GiB
-  const bool ols_split = !glm && !reduced && !staged && (prm.scen_active || n_ns > 1) && P <= (uint32_t)mcp::MAX_P_WAVE;
+  const bool ols_wide_split = !glm && !reduced && !staged && !prm.scen_active && n_ns > 1 && P >= 13u;  // ols_wide_kernel over a grid
+  const bool ols_split = (!glm && !reduced && !staged && (prm.scen_active || n_ns > 1) && P <= (uint32_t)mcp::MAX_P_WAVE) || ols_wide_split;
+  const size_t ols_fields = ols_wide_split ? mcp::ols_wide_rec_fields((int)P) : mcp::ols_rec_fields((int)P);
   if (ols_split) {
-    const size_t per_rep = mcp::ols_rec_fields((int)P) * n_ns * sizeof(double);
+    const size_t per_rep = ols_fields * n_ns * sizeof(double);
     const size_t cap = ((size_t)1 << 30) / per_rep;
     if (chunk > cap) chunk = cap >= 256 ? (uint32_t)(cap & ~(size_t)255) : 256u;  // (44 fields x 256 sizes x 8 B = 90 KB per replicate at most: cap >= 11 000)
   }
@@ -567,7 +570,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
     DEV_TRY(ar.get(S_LMM_REC, mcp::lmm_rec_fields((int)P, prm.n_clusters_max) * n_ns * lmm_stride * sizeof(double), (void**)&d_lmm_rec));
     DEV_TRY(ar.get(S_LMM_FLAGS, (size_t)n_ns * lmm_stride * sizeof(uint32_t), (void**)&d_lmm_flags));
   }
-  if (ols_split) DEV_TRY(ar.get(S_LMM_REC, mcp::ols_rec_fields((int)P) * n_ns * lmm_stride * sizeof(double), (void**)&d_lmm_rec));
+  if (ols_split) DEV_TRY(ar.get(S_LMM_REC, ols_fields * n_ns * lmm_stride * sizeof(double), (void**)&d_lmm_rec));
   if (want_stat) DEV_TRY(ar.get(S_STAT, ((size_t)n_sims * nt + 1) * sizeof(double), (void**)&d_stat));
   // design tile: [block of 256 replicates][P columns: x1..x_{P-1}, y][max_n rows][256] f32
   // general path: per-replicate design records (lower factor, marginal / residual codes, per-study effects)

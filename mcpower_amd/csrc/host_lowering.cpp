@@ -794,10 +794,10 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   // clustered data fitted by OLS ignoring the clustering (orchestrator tests/clustered_ols_smoke.rs): the random
   // intercept of a row's cluster is re-drawn per row on the reduced-design kernel
   const bool ols_cluster = spec->cluster.present && spec->estimator == MCP_EST_OLS;
-  // ... except the plain wide OLS design on ONE sample size (P = 13 .. 16, <= 16 tests: the reference bench's ols_wide),
-  // which has a kernel of its own: two waves share 64 replicates, every accumulator in an architectural register
-  // (ols_wide_kernels.hip)
-  const bool wide_pair = wide && spec->estimator == MCP_EST_OLS && !general && n_ns == 1u && P >= 13u && P <= (uint32_t)MAX_P &&
+  // ... except the plain wide OLS design (P = 13 .. 16, <= 16 tests: the reference bench's ols_wide), which has a kernel of
+  // its own: four waves share 64 replicates, every accumulator in an architectural register; a grid of sample sizes runs as
+  // its split launch (ols_wide_kernels.hip)
+  const bool wide_pair = wide && spec->estimator == MCP_EST_OLS && !general && P >= 13u && P <= (uint32_t)MAX_P &&
                          nt <= (uint32_t)MAX_T && npc == 0 && !test_reduces && !any_excl_possible && !ols_cluster;
   prm.red_active = (npc > 0 || test_reduces || any_excl_possible || (wide && !wide_pair) || ols_cluster) ? 1u : 0u;
   if (glmm) {

@@ -321,11 +321,11 @@ __global__ __launch_bounds__(BLOCK) void ols_fit_rec_kernel(const SimParams* __r
 // ---- launcher templates: each translation unit instantiates the flavours it owns ----
 namespace mcp {
 
-hipError_t launch_ols_wide(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st);  // ols_wide_kernels.hip
+hipError_t launch_ols_wide(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, uint32_t n_grid, hipStream_t st);  // ols_wide_kernels.hip
 
 // fused kernel, P = 9..12 (MAX_P_FUSED): the staging area passes 48 KB at P = 12
 template <bool GRID1, int FLAVOR>
-static hipError_t launch_fused_wide(int P, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st) {
+static hipError_t launch_fused_wide(int P, const SimParams* d_prm, uint32_t n_sims, size_t lds, hipStream_t st, uint32_t n_grid) {
   const dim3 block(BLOCK), grid((n_sims + BLOCK - 1u) / BLOCK);
 #define LFW(PP)                                                                                                         \
   case PP: {                                                                                                            \
@@ -338,8 +338,8 @@ static hipError_t launch_fused_wide(int P, const SimParams* d_prm, uint32_t n_si
   } break;
   switch (P) {
     LFW(9) LFW(10) LFW(11) LFW(12)
-    // P = 13 .. 16, one sample size, plain data path: two waves share 64 replicates (ols_wide_kernels.hip)
-    default: return (GRID1 && FLAVOR != 2 && P >= 13 && P <= MAX_P) ? launch_ols_wide(P, d_prm, n_sims, FLAVOR, st) : hipErrorInvalidValue;
+    // P = 13 .. 16, plain data path: four waves share 64 replicates (ols_wide_kernels.hip); a grid of sizes = its split launch
+    default: return (FLAVOR != 2 && P >= 13 && P <= MAX_P) ? launch_ols_wide(P, d_prm, n_sims, FLAVOR, GRID1 ? 1u : n_grid, st) : hipErrorInvalidValue;
   }
 #undef LFW
   return hipGetLastError();
@@ -361,7 +361,7 @@ static hipError_t launch_sim_pgf(int P, const SimParams* d_prm, uint32_t n_sims,
     case 7: hipLaunchKernelGGL((ols_sim_kernel<7, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
     case 8: hipLaunchKernelGGL((ols_sim_kernel<8, MODE, GRID1, FLAVOR>), grid, block, lds, st, d_prm); break;
     default:
-      if (MODE == MODE_FUSED) return launch_fused_wide<GRID1, FLAVOR>(P, d_prm, n_sims, lds, st);
+      if (MODE == MODE_FUSED) return launch_fused_wide<GRID1, FLAVOR>(P, d_prm, n_sims, lds, st, n_grid);
       return hipErrorInvalidValue;
   }
   if constexpr (MODE == MODE_FUSED && (FLAVOR == 2 || !GRID1)) {  // split launch (ols_sim_kernel, SPLIT): the fits of every (replicate, grid point)

@@ -120,7 +120,7 @@ struct WideRole {
 //   solve phase  : beta_i at [i], the running right-hand side w_i at [P + i]
 //   test phase   : u of two tests at [tt * P + i], the squared statistics at [2 * P + t]
 template <int P, int ROLE, int NACC>
-__device__ __forceinline__ void wide_fit(const SimParams& prm, double (&acc)[NACC], double* xb, uint32_t n, bool active, uint32_t out_row) {
+__device__ __forceinline__ void wide_fit(const SimParams& prm, double (&acc)[NACC], double* xb, uint32_t n, uint32_t g, bool active, uint32_t out_row) {
   typedef WideRole<P, ROLE> RL;
   constexpr int LO = RL::LO, HI = RL::HI, HIP = RL::HIP, V = P + 1;
   constexpr int MT = MAX_T;
@@ -298,7 +298,7 @@ __device__ __forceinline__ void wide_fit(const SimParams& prm, double (&acc)[NAC
     double tsq[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) tsq[t] = (uint32_t)t < nt ? xb[(2 * P + t) * WL] : __builtin_nan("");
-    ols_finish<MT>(prm, tsq, conv, rss, sst, df, (double)(P - 1), 0u, active, out_row);
+    ols_finish<MT>(prm, tsq, conv, rss, sst, df, (double)(P - 1), g, active, out_row);
   }
 #undef LR
 }
@@ -312,8 +312,23 @@ struct WideMaxNE<P, K1, K1> {
   static constexpr int value = 0;
 };
 
-template <int P, bool FACTORS>
-__global__ __launch_bounds__(WB, 2) void ols_wide_kernel(const SimParams* __restrict__ pp) {
+// A grid of sample sizes (GRID): the fit consumes the accumulators, so the launch is split like the narrow designs' (ols_sim_impl.hpp,
+// SPLIT): the row kernel leaves every role's band of the triangle in HBM at each grid point -- prm.lmm_rec[(g * tri(V) + entry) *
+// lmm_rec_stride + replicate], 153 doubles per fit at P = 16, coalesced across the replicates -- and ols_wide_fit_rec_kernel reloads
+// them into the same four roles and runs wide_fit.
+template <int P, int ROLE, int NACC>
+__device__ __forceinline__ void wide_store(const SimParams& prm, const double (&acc)[NACC], uint32_t g, uint32_t local, bool active) {
+  typedef WideRole<P, ROLE> RL;
+  if (!active) return;
+  double* p = prm.lmm_rec + ((size_t)g * tri(P + 1) + tri(RL::LO)) * prm.lmm_rec_stride + local;
+#pragma unroll
+  for (int k = 0; k < RL::NE; ++k) p[(size_t)k * prm.lmm_rec_stride] = acc[k];
+}
+
+template <int P, bool FACTORS, bool GRID>
+// (the row-only kernel of a split launch fits 168 registers = three waves per SIMD at P = 14 and at P = 13 without factors; capped there,
+// P = 15 / 16 spill 64-170 B and stay at two)
+__global__ __launch_bounds__(WB, (GRID && (P == 14 || (P == 13 && !FACTORS))) ? 3 : 2) void ols_wide_kernel(const SimParams* __restrict__ pp) {
   constexpr int V = P + 1;                                   // variables: intercept, x_1 .. x_{P-1}, y
   constexpr int NACC = WideMaxNE<P, 0, WR>::value;
   constexpr int SLOTS = 4 * P;                               // 4 rows x (K + 1 <= P) draw columns
@@ -328,7 +343,8 @@ __global__ __launch_bounds__(WB, 2) void ols_wide_kernel(const SimParams* __rest
   const uint64_t key = pcg_mix64(prm.base_seed, sim_id);  // rng.rs:61-69
   const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
   const uint32_t out_row = prm.out_base + lsim;
-  const uint32_t n = prm.ns[0], K = prm.K;
+  const uint32_t n_grid = GRID ? prm.n_grid : 1u;
+  const uint32_t n = prm.ns[n_grid - 1u], K = prm.K;  // rows of the largest sample size; the smaller ones are prefixes
   // LDS: rows area [row of the quad][variable 1 .. P][lane] f64 (= the exchange area of the fit: 64 doubles per lane),
   // the staging area [slot = 4 * column + row][lane] f32, then the waves' tail queues
   constexpr int ROWS_DOUBLES = 4 * P * WL > 64 * WL ? 4 * P * WL : 64 * WL;
@@ -352,6 +368,7 @@ __global__ __launch_bounds__(WB, 2) void ols_wide_kernel(const SimParams* __rest
     typedef typename PendMask<P>::type mask_t;
     const uint32_t n_quads = (n + 3u) >> 2;
     float* st = stage + lane;
+    uint32_t g = 0, next = GRID ? prm.ns[0] : 0xffffffffu;  // rows [0, next) make up grid point g
     for (uint32_t q = 0; q < n_quads; ++q) {
       mask_t pend = 0;
 #pragma unroll
@@ -377,6 +394,11 @@ __global__ __launch_bounds__(WB, 2) void ols_wide_kernel(const SimParams* __rest
       __syncthreads();  // (2) the four rows of the block are built
 #pragma unroll 2  // two rows in flight: the next row's LDS reads overlap this row's multiply-adds
       for (int r = 0; r < 4; ++r) {
+        if (GRID && 4u * q + (uint32_t)r == next && g + 1u < n_grid) {  // every row of grid point g is in: park the band
+          wide_store<P, ROLE>(prm, acc, g, local, active);
+          ++g;
+          next = prm.ns[g];
+        }
         if (4u * q + (uint32_t)r < n) {
           const double* row = rows_d + (size_t)r * P * WL + lane;
           double v[V];
@@ -387,17 +409,49 @@ __global__ __launch_bounds__(WB, 2) void ols_wide_kernel(const SimParams* __rest
         }
       }
     }
+    if (GRID) wide_store<P, ROLE>(prm, acc, n_grid - 1u, local, active);  // the largest sample size
   };
   if (role == 0u) rows(std::integral_constant<int, 0>());
   else if (role == 1u) rows(std::integral_constant<int, 1>());
   else if (role == 2u) rows(std::integral_constant<int, 2>());
   else rows(std::integral_constant<int, 3>());
+  if (GRID) return;  // the fits run in ols_wide_fit_rec_kernel
   __syncthreads();  // the staging area becomes the exchange area of the fit
   // ---- the fit (batch.rs:956-1142), in place on the roles' rows; every role passes the same barriers ----
-  if (role == 0u) wide_fit<P, 0>(prm, acc, xb, n, active, out_row);
-  else if (role == 1u) wide_fit<P, 1>(prm, acc, xb, n, active, out_row);
-  else if (role == 2u) wide_fit<P, 2>(prm, acc, xb, n, active, out_row);
-  else wide_fit<P, 3>(prm, acc, xb, n, active, out_row);
+  if (role == 0u) wide_fit<P, 0>(prm, acc, xb, n, 0u, active, out_row);
+  else if (role == 1u) wide_fit<P, 1>(prm, acc, xb, n, 0u, active, out_row);
+  else if (role == 2u) wide_fit<P, 2>(prm, acc, xb, n, 0u, active, out_row);
+  else wide_fit<P, 3>(prm, acc, xb, n, 0u, active, out_row);
+}
+
+// second half of a split wide launch: blockIdx.y = grid point; the four roles reload their bands and fit
+template <int P>
+__global__ __launch_bounds__(WB, 2) void ols_wide_fit_rec_kernel(const SimParams* __restrict__ pp) {
+  constexpr int NACC = WideMaxNE<P, 0, WR>::value;
+  extern __shared__ float wide_lds[];
+  const SimParams& prm = *pp;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t local = blockIdx.x * WL + lane;
+  const bool active = local < prm.n_sims;
+  const uint32_t src = active ? local : (prm.n_sims - 1u);
+  const uint32_t g = blockIdx.y;
+  double* xb = reinterpret_cast<double*>(wide_lds) + lane;
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+  auto fit = [&](auto tag) {
+    constexpr int ROLE = decltype(tag)::value;
+    typedef WideRole<P, ROLE> RL;
+    const double* p = prm.lmm_rec + ((size_t)g * tri(P + 1) + tri(RL::LO)) * prm.lmm_rec_stride + src;
+#pragma unroll
+    for (int k = 0; k < RL::NE; ++k) acc[k] = p[(size_t)k * prm.lmm_rec_stride];
+    wide_fit<P, ROLE>(prm, acc, xb, prm.ns[g], g, active, prm.out_base + src);
+  };
+  if (role == 0u) fit(std::integral_constant<int, 0>());
+  else if (role == 1u) fit(std::integral_constant<int, 1>());
+  else if (role == 2u) fit(std::integral_constant<int, 2>());
+  else fit(std::integral_constant<int, 3>());
 }
 
 }  // namespace
@@ -407,25 +461,38 @@ size_t ols_wide_lds_bytes(int P) {
   return (rows > exch ? rows : exch) + (size_t)4 * P * WL * sizeof(float) + WR * TAIL_QUEUE * sizeof(uint32_t);
 }
 
-// P = 13 .. 16, plain data path (flavor 0 / 1), one sample size, <= 16 tests: the host routes exactly these here
-hipError_t launch_ols_wide(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, hipStream_t st) {
+size_t ols_wide_rec_fields(int P) { return (size_t)tri(P + 1); }
+
+// P = 13 .. 16, plain data path (flavor 0 / 1), <= 16 tests: the host routes exactly these here; n_grid > 1 = the split launch
+hipError_t launch_ols_wide(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, uint32_t n_grid, hipStream_t st) {
   const dim3 block(WB), grid((n_sims + WL - 1u) / WL);
   const size_t lds = ols_wide_lds_bytes(P);
-#define LW(PP)                                                                                                          \
-  case PP: {                                                                                                            \
+  const bool split = n_grid > 1u;
+#define LWK(PP, FF, GG)                                                                                                 \
+  {                                                                                                                     \
     if (lds > 48 * 1024) {                                                                                              \
-      hipError_t e = hipFuncSetAttribute(flavor ? (const void*)ols_wide_kernel<PP, true> : (const void*)ols_wide_kernel<PP, false>, \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      hipError_t e = hipFuncSetAttribute((const void*)ols_wide_kernel<PP, FF, GG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       if (e != hipSuccess) return e;                                                                                    \
     }                                                                                                                   \
-    if (flavor) hipLaunchKernelGGL((ols_wide_kernel<PP, true>), grid, block, lds, st, d_prm);                           \
-    else hipLaunchKernelGGL((ols_wide_kernel<PP, false>), grid, block, lds, st, d_prm);                                 \
+    hipLaunchKernelGGL((ols_wide_kernel<PP, FF, GG>), grid, block, lds, st, d_prm);                                     \
+  }
+#define LW(PP)                                                                                                          \
+  case PP: {                                                                                                            \
+    if (split) { if (flavor) LWK(PP, true, true) else LWK(PP, false, true) }                                            \
+    else { if (flavor) LWK(PP, true, false) else LWK(PP, false, false) }                                                \
+    if (split) {                                                                                                        \
+      hipError_t e = hipGetLastError();                                                                                 \
+      if (e != hipSuccess) return e;                                                                                    \
+      const size_t flds = (size_t)64 * WL * sizeof(double);                                                             \
+      hipLaunchKernelGGL((ols_wide_fit_rec_kernel<PP>), dim3((n_sims + WL - 1u) / WL, n_grid), block, flds, st, d_prm); \
+    }                                                                                                                   \
   } break;
   switch (P) {
     LW(13) LW(14) LW(15) LW(16)
     default: return hipErrorInvalidValue;
   }
 #undef LW
+#undef LWK
   return hipGetLastError();
 }
 

@@ -107,8 +107,25 @@ def test_wide_design_with_factors_interactions_contrasts_holm(engine, oracle):
     _assert_batch_equal(g, o)
 
 
+@pytest.mark.parametrize("k", [12, 13, 15])
+def test_a_grid_of_sample_sizes_runs_as_the_split_wide_launch(k, engine, oracle):
+    """Since round 3 a grid of sample sizes stays on ols_wide_kernel: the row kernel parks every role's band of the triangle
+    in HBM at each grid point (ragged sizes: the boundary falls inside a row quad) and ols_wide_fit_rec_kernel runs the fits."""
+    spec = _continuous(k)
+    spec.target_indices = list(range(1, k + 1))[:15]
+    spec.correction_method = S.CorrectionMethod.Holm
+    spec.report_overall = True
+    ns = [3 * k, 41 + k, 100, 203, 400]
+    g, o = _both(engine, oracle, spec, ns, 1500, 311)
+    _assert_batch_equal(g, o)
+    c = engine.run_batch(spec, ns, 1500, 311, per_sim=False)
+    assert np.array_equal(c.counters, g.counters)
+    one = engine.run_batch(spec, [203], 1500, 311)          # the single-size launch of the same kernel family
+    assert np.array_equal(one.uncorrected[:, 0], g.uncorrected[:, 3]) and np.array_equal(one.converged[:, 0], g.converged[:, 3])
+
+
 def test_single_size_call_equals_the_same_point_of_a_grid_call(engine, oracle):
-    """One sample size runs on ols_wide_kernel, a grid on the reduced-design kernel: the shared point must agree with the
+    """One sample size runs ols_wide_kernel fused, a grid its split launch: the shared point must agree with the
     oracle on both (and so with each other) -- the prefix property of the data plane (rng.rs:1-13)."""
     spec = _continuous(15)
     spec.target_indices = list(range(1, 9))
