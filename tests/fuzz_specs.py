@@ -10,7 +10,8 @@ import numpy as np
 from mcpower_amd import spec as S
 from mcpower_amd.workloads import preset
 
-FAMILIES = ("ols", "ols_scen", "logit", "probit", "poisson", "glm_scen", "lme", "lme_scen", "glmm", "ols_general", "ols_posthoc", "lmm_general", "glmm_general")
+FAMILIES = ("ols", "ols_scen", "logit", "probit", "poisson", "glm_scen", "lme", "lme_scen", "glmm", "ols_general", "ols_posthoc", "lmm_general", "glmm_general",
+            "ols_wide")   # new families go at the END: the per-family seed offset is the index
 
 
 def _correlation(rng, k):
@@ -33,6 +34,8 @@ def random_spec(seed: int, family: str, legacy_sizes: bool = False):
     scen = family.endswith("_scen")
     clustered = family in ("lme", "lme_scen", "glmm")
     # general OLS path: up to 9 continuous predictors; random-intercept LMMs: up to 12 design columns (9 .. 12 on the general kernel)
+    if family == "ols_wide":
+        return _ols_wide(rng)
     wide_lme = family in ("lme", "lme_scen") and not legacy_sizes   # (the legacy generator keeps its ranges: seed 1098 is pinned to it)
     k = int(rng.integers(1, (8 if wide_lme else 4) if clustered else (10 if family in ("ols_scen", "ols_general") else 6)))
     n_fac = int(rng.integers(0, 2 if clustered or family == "glmm" else 3))
@@ -140,6 +143,45 @@ def random_spec(seed: int, family: str, legacy_sizes: bool = False):
         return _mixed_general(rng, family)
     exact = family in ("ols", "logit", "probit", "poisson", "ols_posthoc")
     return s, sizes, n_sims, exact
+
+
+def _ols_wide(rng):
+    """Plain OLS on 13 .. 16 design columns (ols_wide_kernels.hip: one size fused, a grid as the split launch; with an
+    exclusion threshold the reduced-design kernel): 9 .. 13 continuous predictors, at most one factor, interactions up to
+    the target width, ragged 1 .. 3-point grids."""
+    p_target = int(rng.integers(13, 17))
+    levels = [int(rng.integers(2, 4))] if rng.integers(0, 2) else []
+    dummies = sum(l - 1 for l in levels)
+    k = int(rng.integers(9, min(13, p_target - 1 - dummies) + 1))
+    cols = k + dummies
+    owner = [-1] * k + [0] * dummies
+    inter = []
+    while 1 + cols + len(inter) < p_target:
+        a, b = sorted(int(v) for v in rng.choice(cols, size=2, replace=False))
+        if owner[a] >= 0 and owner[a] == owner[b]:
+            continue
+        if [a + 1, b + 1] not in inter:
+            inter.append([a + 1, b + 1])
+    p = 1 + cols + len(inter)
+    props = []
+    for l in levels:
+        w = rng.uniform(0.7, 1.3, size=l)
+        props += (w / w.sum()).tolist()
+    effects = rng.uniform(-0.3, 0.3, size=p).round(3).tolist()
+    effects[0] = 0.0
+    n_t = int(rng.integers(1, min(p, 16)))
+    targets = sorted(int(v) for v in rng.choice(np.arange(1, p), size=n_t, replace=False))
+    s = S.SimulationSpec(
+        n_non_factor=k, n_factor_dummies=dummies, correlation=_correlation(rng, k),
+        var_types=[S.Distribution.Normal] * k, var_params=[0.0] * k, factor_n_levels=levels, factor_proportions=props,
+        factor_sampled=[None] * len(levels), effect_sizes=effects, target_indices=targets, interactions=inter,
+        correction_method=S.CorrectionMethod(int(rng.integers(0, 4))), report_overall=bool(rng.integers(0, 2)),
+        max_failed_fraction=1.0,
+    )
+    if levels and rng.integers(0, 3) == 0:
+        s.factor_min_level_count = int(rng.integers(2, 6))     # exclusion rounds: the reduced-design kernel
+    sizes = sorted({int(v) for v in rng.integers(3 * p, 400, size=int(rng.integers(1, 4)))})
+    return s, sizes, 256, True
 
 
 def _mixed_general(rng, family):
