@@ -484,7 +484,7 @@ int run_batch_impl(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, uint
   }
   // OLS on the general path or over a grid of sample sizes, narrow designs: the launch is split into a row kernel and a fit kernel (ols_kernels.hip, SPLIT) with the
   // sufficient statistics of every (replicate, grid point) between them: keep one chunk's worth under 1 GiB
-  const bool ols_wide_split = !glm && !reduced && !staged && !prm.scen_active && n_ns > 1 && P >= 13u;  // ols_wide_kernel over a grid
+  const bool ols_wide_split = !glm && !reduced && !staged && !prm.scen_active && (n_ns > 1 || P == 14u) && P >= 13u;  // ols_wide_kernel over a grid (P = 14: always)
   const bool ols_split = (!glm && !reduced && !staged && (prm.scen_active || n_ns > 1) && P <= (uint32_t)mcp::MAX_P_WAVE) || ols_wide_split;
   const size_t ols_fields = ols_wide_split ? mcp::ols_wide_rec_fields((int)P) : mcp::ols_rec_fields((int)P);
   if (ols_split) {

@@ -467,7 +467,9 @@ size_t ols_wide_rec_fields(int P) { return (size_t)tri(P + 1); }
 hipError_t launch_ols_wide(int P, const SimParams* d_prm, uint32_t n_sims, int flavor, uint32_t n_grid, hipStream_t st) {
   const dim3 block(WB), grid((n_sims + WL - 1u) / WL);
   const size_t lds = ols_wide_lds_bytes(P);
-  const bool split = n_grid > 1u;
+  // P = 14 takes the split launch on one sample size too: its row-only kernel fits 168 registers (three waves per SIMD), the fused
+  // one 195 (two) -- 6.9 -> 6.1 ms per 10^6 fits with TWO fits per replicate; at P = 15 / 16 both forms hold two waves and fused wins
+  const bool split = n_grid > 1u || P == 14;
 #define LWK(PP, FF, GG)                                                                                                 \
   {                                                                                                                     \
     if (lds > 48 * 1024) {                                                                                              \
