@@ -529,6 +529,15 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
         prm.lmg_n_rest = nr;
         prm.lmg_fR = fro;
         prm.lmg_fW = fro + P + 1;
+        prm.lmg_compact = 0;   // decided below, once it is known whether reduced rounds can occur
+        prm.lmg_Wc = prm.lmg_fW;
+        uint32_t co = 0;
+        for (uint32_t r = 0; r < nr; ++r) {
+          const uint32_t t = prm.lmg_frest[r];
+          prm.lmg_coff[t] = co;
+          co += (prm.lmg_frel[t] == 1u ? prm.lmg_fcnt[t] : prm.lmg_levels[t]) * prm.lmg_q[t];
+        }
+        prm.lmg_coff_xy = co;
       }
       // sequential-stream layout (data_gen.rs:146-284): primary intercepts, primary slopes, every extra grouping's
       // intercepts, then every extra grouping's slopes -- in units of one random-effect draw
@@ -826,6 +835,11 @@ int lower_spec(const mcp_spec* spec, const uint32_t* ns, uint32_t n_ns, SimParam
   }
   if (prm.red_active && spec->estimator != MCP_EST_OLS && !((prm.keep_mask[0] >> 0) & 1u))
     return unsupported("intercept-free reduced fit under Glm / Mle");
+  // general LMM: compact strips (mcp_params.hpp) unless a reduced round can occur -- that round reads whole strips
+  if (spec->estimator == MCP_EST_MLE && prm.lmg_active && !prm.red_active && prm.lmg_coff_xy + P + 1 < prm.lmg_fW) {
+    prm.lmg_compact = 1;
+    prm.lmg_Wc = prm.lmg_coff_xy + P + 1;
+  }
   for (uint32_t k = 0; k <= (uint32_t)MAX_T; ++k)
     prm.joint_crit_k[k] = k == 0 ? std::numeric_limits<double>::infinity() : chi2_ppf(1.0 - spec->alpha, (double)k);
   low.P = P;

@@ -87,6 +87,17 @@ __device__ __forceinline__ uint32_t lmg_rest_term(const SimParams& prm, uint32_t
   return (prm.lmg_n_rest > 1u && i >= prm.lmg_froff[t1]) ? t1 : t0;
 }
 
+// compact position of column i of [Zr | X | y] inside an eliminated level's strip (mcp_params.hpp, lmg_compact): the columns of
+// a grouped term are counted within the level's own primary level -- the caller only pairs a level with columns it meets
+// (`compact` is the caller's register copy of prm.lmg_compact: read through prm at every call it was a scalar load inside the
+// per-row fold and the Schur loops -- 11 % of lmm_multislope at two waves per SIMD)
+__device__ __forceinline__ uint32_t lmg_cpos(const SimParams& prm, uint32_t compact, uint32_t i) {
+  if (!compact) return i;
+  if (i >= prm.lmg_fR) return prm.lmg_coff_xy + (i - prm.lmg_fR);
+  const uint32_t t = lmg_rest_term(prm, i), o = i - prm.lmg_froff[t];
+  return prm.lmg_coff[t] + (prm.lmg_frel[t] == 1u ? o % (prm.lmg_fcnt[t] * prm.lmg_q[t]) : o);
+}
+
 // template entries T_t[r][c] of every term from theta (column-major vech per term, mixed_workspace.rs:189-196)
 __device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* th, ldd* tm, uint32_t lane) {
   if (lane < 27u) {
@@ -108,6 +119,7 @@ __device__ __forceinline__ void lmg_templates(const SimParams& prm, const ldd* t
 template <int Q0>
 __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m, const ldd* th, uint32_t lane, double n_rows) {
   const uint32_t W = prm.lmg_fW, R = prm.lmg_fR, p = prm.P, E = prm.lmg_elim, L0 = prm.lmg_levels[E], cpe = prm.lmg_cpe;
+  const uint32_t Wc = prm.lmg_Wc, compact = prm.lmg_compact;  // stride of the strips (gzw, B): W, or the columns a level meets when compact
   const double inf = __builtin_inf();
   lmg_templates(prm, th, m.tm, lane);
   lmg_sync();
@@ -204,13 +216,15 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
       if (xy) { jlo = R; jhi = W; }
       else if (prm.lmg_frel[tj] == 1u) { jlo = prm.lmg_froff[tj] + (cpe == 1u ? c : c / cpe) * prm.lmg_fcnt[tj] * qj; jhi = jlo + prm.lmg_fcnt[tj] * qj; }
       else { jlo = prm.lmg_froff[tj]; jhi = jlo + prm.lmg_levels[tj] * qj; }
+      // compact strips: the columns [jlo, jhi) sit at [coff, ..) of the level's strip
+      const uint32_t cshift = compact ? jlo - (xy ? prm.lmg_coff_xy : prm.lmg_coff[tj]) : 0u;
       for (uint32_t sj = jlo; sj < jhi; sj += qj) {
         for (uint32_t bj = 0; bj < qj; ++bj) {
           const uint32_t j = sj + bj;
           double zw[Q0];
 #pragma unroll
           for (int r = 0; r < Q0; ++r) {
-            const ldd* row = m.gzw + ((size_t)c * Q0 + r) * W;
+            const ldd* row = m.gzw + ((size_t)c * Q0 + r) * Wc - cshift;
             double sacc = 0.0;
             if (!xy) {
               for (uint32_t d = bj; d < qj; ++d) sacc += m.tm[tj * 9u + d * 3u + bj] * row[sj + d];
@@ -230,7 +244,7 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
             for (int k = 0; k < Q0; ++k)
               if (k < a) sacc -= Lc[a][k] * bcol[k];
             bcol[a] = sacc / Lc[a][a];
-            m.B[((size_t)c * Q0 + a) * W + j] = bcol[a];
+            m.B[((size_t)c * Q0 + a) * Wc + (j - cshift)] = bcol[a];
           }
         }
       }
@@ -248,6 +262,7 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
         const uint32_t ti = lmg_rest_term(prm, i);
         if (prm.lmg_frel[ti] == 1u) pi = ((i - prm.lmg_froff[ti]) / prm.lmg_q[ti]) / prm.lmg_fcnt[ti];
       }
+      const uint32_t ci2 = lmg_cpos(prm, compact, i);
       for (uint32_t j = lane; j <= i; j += GW) {
         uint32_t pj = 0xffffffffu;
         if (j < R) {
@@ -262,7 +277,8 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
         }
         khi = khi < KT ? khi : KT;
         double sacc = m.S[lmg_tri(i, j)];
-        for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
+        const uint32_t cj2 = lmg_cpos(prm, compact, j);
+        for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * Wc + ci2] * m.B[(size_t)k * Wc + cj2];
         m.S[lmg_tri(i, j)] = sacc;
       }
     }
@@ -500,12 +516,13 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 9 || 
   const uint32_t max_n = prm.max_n, n_pad = (max_n + 3u) & ~3u;
   const uint32_t W = prm.lmg_fW, R = prm.lmg_fR, L0 = prm.lmg_levels[0], d = prm.lmg_n_theta, nterms = prm.lmg_n_terms;
   const uint32_t E = prm.lmg_elim, LE = prm.lmg_levels[E];  // fit view (mcp_params.hpp): the grouping eliminated block by block
+  const uint32_t Wc = prm.lmg_Wc, compact = prm.lmg_compact;  // strips of the eliminated levels: stride, compact positions
   LmgLds m;
   {
     // persistent: the sufficient statistics, the sparse-row scratch of their accumulation, the theta carry, the design
     ldd* q = (ldd*)lds_d;
     m.gzz = q; q += (size_t)LE * Q0 * Q0;
-    m.gzw = q; q += (size_t)LE * Q0 * W;
+    m.gzw = q; q += (size_t)LE * Q0 * Wc;
     m.gww = q; q += lmg_tri(W, 0u);  // lower triangles, packed by rows
     m.rval = q; q += LMG_MAX_NZ;
     m.carry = q; q += LMG_MAX_THETA;
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 9 || 
     // occupancy of this latency-bound kernel: 24 -> 18 KB on the lmm_slope shape)
     ldd* e = (ldd*)f;
     m.S = e; e += lmg_tri(W, 0u);
-    m.B = e; e += (size_t)LE * Q0 * W;
+    m.B = e; e += (size_t)LE * Q0 * Wc;
     m.ld = e; e += LE;
     m.simplex = e; e += (size_t)(d + 4u) * LMG_MAX_THETA;
     m.fv = e; e += d + 1u;
@@ -717,7 +734,7 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 9 || 
     }
   }
   // ---- 3. sufficient statistics, zeroed once and grown over the grid ----
-  for (size_t i = lane; i < (size_t)LE * Q0 * Q0 + (size_t)LE * Q0 * W + lmg_tri(W, 0u); i += GW) m.gzz[i] = 0.0;  // gzz | gzw | gww are contiguous
+  for (size_t i = lane; i < (size_t)LE * Q0 * Q0 + (size_t)LE * Q0 * Wc + lmg_tri(W, 0u); i += GW) m.gzz[i] = 0.0;  // gzz | gzw | gww are contiguous
   lmg_sync();
 
   uint32_t nzr = 0;  // non-zeros of the rest part of a row
@@ -757,7 +774,7 @@ __global__ __launch_bounds__(GW, ((SCEN && P >= 11) ? 1 : (Q0 >= 3 || P >= 9 || 
       for (uint32_t pr = lane; pr < (uint32_t)Q0 * nz; pr += GW) {
         const uint32_t a = pr / nz, b = pr % nz;
         const double za = a == 0u ? 1.0 : (double)m.design[(size_t)(prm.lmg_cols[E][a - 1u] - 1u) * dstride + di];
-        ldd* cell = m.gzw + ((size_t)c * Q0 + a) * W + m.ridx[b];
+        ldd* cell = m.gzw + ((size_t)c * Q0 + a) * Wc + lmg_cpos(prm, compact, m.ridx[b]);
         *cell = __builtin_fma(za, m.rval[b], *cell);
       }
       if (lane < (uint32_t)(Q0 * Q0)) {

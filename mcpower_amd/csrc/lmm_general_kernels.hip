@@ -12,10 +12,10 @@ size_t lmg_lds_bytes(const SimParams& prm) {
   const size_t tri = W * (W + 1) / 2, ts = prm.P > 8u ? 16 : 8;  // tail strides (lmg_tail_stride)
   // persistent: gzz | gzw | gww | rval | carry (doubles), ridx (u32, even count), the design (f32)
   const size_t n_pad = ((size_t)prm.max_n + 3u) & ~(size_t)3u;
-  const size_t persistent = (L0 * q0 * q0 + L0 * q0 * W + tri + LMG_MAX_NZ + LMG_MAX_THETA) * 8 + (((size_t)LMG_MAX_NZ + 1) & ~(size_t)1) * 4 +
+  const size_t persistent = (L0 * q0 * q0 + L0 * q0 * (size_t)prm.lmg_Wc + tri + LMG_MAX_NZ + LMG_MAX_THETA) * 8 + (((size_t)LMG_MAX_NZ + 1) & ~(size_t)1) * 4 +
                             (size_t)prm.P * (prm.lmg_stream ? (size_t)256 : n_pad) * 4;  // the design, or its 256-row window
   // the shared region: the evaluation's S | B | ld | simplex | fv | tm | misc | tail over the generator's u0 | us | ux | staging
-  const size_t eval_bytes = (tri + L0 * q0 * W + L0 + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (ts + ts * ts + (ts == 16 ? 12 : 8) * ts + ts * ts + ts + 8)) * 8;
+  const size_t eval_bytes = (tri + L0 * q0 * (size_t)prm.lmg_Wc + L0 + (d + 4) * LMG_MAX_THETA + (d + 1) + 27 + 8 + (ts + ts * ts + (ts == 16 ? 12 : 8) * ts + ts * ts + ts + 8)) * 8;
   size_t nlev = 0;
   for (uint32_t t = 1; t < prm.lmg_n_terms; ++t) nlev += (size_t)prm.lmg_levels[t] * prm.lmg_q[t];
   const size_t gen_bytes = (LG0 + LG0 * LMG_MAX_SLOPES + nlev + (size_t)4 * (prm.P + 1) * GW) * 4;

@@ -201,7 +201,12 @@ struct SimParams {
   uint32_t lmg_frel[LMG_MAX_TERMS];   // by term id: 0 = every eliminated level meets every level of it; 1 = only those of its own primary level
   uint32_t lmg_fcnt[LMG_MAX_TERMS];   // by term id: levels per primary level (1 for the primary grouping itself)
   uint32_t lmg_fR, lmg_fW;            // rest width and W = fR + P + 1 in this view
-  uint32_t _pad_lmg2;
+  // compact strips: an eliminated level only meets the columns of its own primary level in a grouped term (frel = 1), every
+  // column of the others, X and y -- its strip in Z0'[Zr | X | y] (gzw) and in the eliminated factor (B) is stored that wide
+  // (lmm_nested: 7 of 26 columns).  lmg_Wc = lmg_fW and identity positions when lmg_compact = 0 (reduced rounds need full strips)
+  uint32_t lmg_compact, lmg_Wc;
+  uint32_t lmg_coff[LMG_MAX_TERMS];   // by term id: first compact position of the term's columns
+  uint32_t lmg_coff_xy;               // first compact position of X | y
   double lmg_tau[LMG_MAX_TERMS];     // sqrt(max(tau^2, 0)) per term
   double lmg_chol[LMG_MAX_TERMS][9]; // row-major lower chol(diag(tau) R diag(tau)) per term: the slope draws
   double lmg_tau_sq[LMG_MAX_TERMS];  // spec tau^2 per term (the ICC jitter of the general path starts from it)
