@@ -245,3 +245,34 @@ def test_random_intercept_lmm_with_nine_to_twelve_design_columns(k, extra, scen,
     c = engine.run_batch(spec, ns, 400, BASE_SEED, per_sim=False)
     assert np.array_equal(c.counters, g.counters)
     assert g.uncorrected[:, -1, 0].mean() > 0.5
+
+
+@pytest.mark.parametrize("sizing", [("FixedClusters", 10), ("FixedSize", 12)])
+@pytest.mark.parametrize("both", [False, True])
+def test_nested_groupings_over_a_grid_under_both_sizings(sizing, both, engine, oracle):
+    """The general LMM eliminates the nested grouping's levels (fit view) and stores their strips compactly: under FixedSize
+    sizing the number of parents grows along the grid, so the smaller sample sizes see levels that are still empty (identity
+    blocks); `both` adds a crossed grouping beside the nested one.  Device vs oracle on the same seeds."""
+    from mcpower_amd import spec as S
+    if both and sizing[0] == "FixedSize":
+        pytest.skip("a crossed grouping needs FixedClusters sizing (the reference's validation)")
+    eg = [{"relation": {"NestedWithin": {"n_per_parent": 3}}, "tau_squared": 0.2, "slopes": []}]
+    if both:
+        eg.append({"relation": {"Crossed": {"n_clusters": 4}}, "tau_squared": 0.15, "slopes": []})
+    spec = S.SimulationSpec(n_non_factor=2, correlation=[1.0, 0.25, 0.25, 1.0], var_types=[S.Distribution.Normal] * 2,
+                            var_params=[0.0, 0.0], effect_sizes=[0.0, 0.3, 0.2], target_indices=[1, 2],
+                            estimator=S.EstimatorSpec.Mle, max_failed_fraction=1.0,
+                            cluster=S.ClusterSpec(sizing=sizing, tau_squared=0.3, extra_groupings=eg),
+                            extra_slope_cols=[[] for _ in eg],
+                            scenario=S.ScenarioPerturbations(name="optimistic", truth_start=True))
+    atom = (10 * 3 * (4 if both else 1)) if sizing[0] == "FixedClusters" else 12
+    ns = [atom * m for m in ((2, 4) if sizing[0] == "FixedClusters" else (10, 25))]
+    dev = engine.run_batch(spec, ns, 96, BASE_SEED, stat_capture=True)
+    ora = oracle.run_batch(spec, ns, 96, BASE_SEED, stat_capture=True, n_threads=16)
+    same = ((dev.uncorrected == ora.uncorrected).all(axis=(1, 2)) & (dev.converged == ora.converged).all(axis=1)
+            & (dev.pinned_components == ora.pinned_components).all(axis=1) & (dev.joint_unc == ora.joint_unc).all(axis=1))
+    assert same.sum() >= 94 and dev.converged.mean() > 0.9, (sizing, both, int(same.sum()))
+    m = ~np.isnan(ora.stat_capture) & ~np.isnan(dev.stat_capture) & same[:, None]
+    assert np.quantile(np.abs(dev.stat_capture[m] - ora.stat_capture[m]) / np.maximum(np.abs(ora.stat_capture[m]), 1e-12), 0.98) < 5e-5
+    c = engine.run_batch(spec, ns, 96, BASE_SEED, per_sim=False)
+    assert np.array_equal(c.counters, dev.counters)
