@@ -87,6 +87,16 @@ __device__ __forceinline__ uint32_t lmg_rest_term(const SimParams& prm, uint32_t
   return (prm.lmg_n_rest > 1u && i >= prm.lmg_froff[t1]) ? t1 : t0;
 }
 
+// (i, j <= i) of entry e of a packed lower triangle (lmg_tri(i, j) = e): the loops over the triangle hand one ENTRY to a lane --
+// row by row with lanes over the columns, a W x W triangle took W serial trips of at most W / 64 busy waves each
+__device__ __forceinline__ void lmg_tri_decode(uint32_t e, uint32_t& i, uint32_t& j) {
+  uint32_t r = (uint32_t)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+  while (r * (r + 1u) / 2u > e) --r;
+  while ((r + 1u) * (r + 2u) / 2u <= e) ++r;
+  i = r;
+  j = e - r * (r + 1u) / 2u;
+}
+
 // compact position of column i of [Zr | X | y] inside an eliminated level's strip (mcp_params.hpp, lmg_compact): the columns of
 // a grouped term are counted within the level's own primary level -- the caller only pairs a level with columns it meets
 // (`compact` is the caller's register copy of prm.lmg_compact: read through prm at every call it was a scalar load inside the
@@ -123,10 +133,11 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
   const double inf = __builtin_inf();
   lmg_templates(prm, th, m.tm, lane);
   lmg_sync();
-  // ---- S (lower triangle) = Lambda~' Gww Lambda~ (+ I on the rest block), Lambda~ = diag(Lambda_rest, I) ----
-  for (uint32_t i = 0; i < W; ++i) {
-    // block of row index i
-    uint32_t ti = 0, bi = 0, qi = 1, si = i;
+  // ---- S (lower triangle) = Lambda~' Gww Lambda~ (+ I on the rest block), Lambda~ = diag(Lambda_rest, I): lane = entry ----
+  for (uint32_t en = lane; en < (uint32_t)lmg_tri(W, 0u); en += GW) {
+    uint32_t i, j;
+    lmg_tri_decode(en, i, j);
+    uint32_t ti = 0, bi = 0, qi = 1, si = i;  // block of the row index
     if (i < R) {
       ti = lmg_rest_term(prm, i);
       qi = prm.lmg_q[ti];
@@ -134,29 +145,27 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
       bi = rel % qi;
       si = i - bi;
     }
-    for (uint32_t j = lane; j <= i; j += GW) {
-      uint32_t tj = 0, bj = 0, qj = 1, sj = j;
-      if (j < R) {
-        tj = lmg_rest_term(prm, j);
-        qj = prm.lmg_q[tj];
-        const uint32_t rel = j - prm.lmg_froff[tj];
-        bj = rel % qj;
-        sj = j - bj;
-      }
-      // the oracle applies Lambda' along the row index first, then along the column index: keep that association
-      double acc = 0.0;
-      for (uint32_t e = bj; e < qj; ++e) {
-        double inner = 0.0;
-        for (uint32_t d = bi; d < qi; ++d) {
-          const uint32_t a = si + d, b = sj + e;
-          const double g = a >= b ? m.gww[lmg_tri(a, b)] : m.gww[lmg_tri(b, a)];
-          inner = i < R ? inner + m.tm[ti * 9u + d * 3u + bi] * g : g;
-        }
-        acc = j < R ? acc + m.tm[tj * 9u + e * 3u + bj] * inner : inner;
-      }
-      if (i == j && i < R) acc += 1.0;
-      m.S[lmg_tri(i, j)] = acc;
+    uint32_t tj = 0, bj = 0, qj = 1, sj = j;  // ... and of the column index
+    if (j < R) {
+      tj = lmg_rest_term(prm, j);
+      qj = prm.lmg_q[tj];
+      const uint32_t rel = j - prm.lmg_froff[tj];
+      bj = rel % qj;
+      sj = j - bj;
     }
+    // the oracle applies Lambda' along the row index first, then along the column index: keep that association
+    double acc = 0.0;
+    for (uint32_t e = bj; e < qj; ++e) {
+      double inner = 0.0;
+      for (uint32_t d = bi; d < qi; ++d) {
+        const uint32_t a = si + d, b = sj + e;
+        const double g = a >= b ? m.gww[lmg_tri(a, b)] : m.gww[lmg_tri(b, a)];
+        inner = i < R ? inner + m.tm[ti * 9u + d * 3u + bi] * g : g;
+      }
+      acc = j < R ? acc + m.tm[tj * 9u + e * 3u + bj] * inner : inner;
+    }
+    if (i == j && i < R) acc += 1.0;
+    m.S[en] = acc;
   }
   lmg_sync();
   // ---- eliminate the primary blocks: lane = level ----
@@ -255,32 +264,31 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
   for (uint32_t c = 0; c < L0; ++c) logdet += m.ld[c];  // level order, as the oracle sums
   {
     const uint32_t KT = L0 * Q0;
-    for (uint32_t i = 0; i < W; ++i) {
+    // S -= sum_k B[k]' B[k], k = (level, a) ascending -- the oracle's summation order per entry; lane = entry
+    for (uint32_t en = lane; en < (uint32_t)lmg_tri(W, 0u); en += GW) {
+      uint32_t i, j;
+      lmg_tri_decode(en, i, j);
       // a column tied to one primary level only meets the rows of B of that level's eliminated blocks
-      uint32_t pi = 0xffffffffu;
+      uint32_t pi = 0xffffffffu, pj = 0xffffffffu;
       if (i < R) {
         const uint32_t ti = lmg_rest_term(prm, i);
         if (prm.lmg_frel[ti] == 1u) pi = ((i - prm.lmg_froff[ti]) / prm.lmg_q[ti]) / prm.lmg_fcnt[ti];
       }
-      const uint32_t ci2 = lmg_cpos(prm, compact, i);
-      for (uint32_t j = lane; j <= i; j += GW) {
-        uint32_t pj = 0xffffffffu;
-        if (j < R) {
-          const uint32_t tj = lmg_rest_term(prm, j);
-          if (prm.lmg_frel[tj] == 1u) pj = ((j - prm.lmg_froff[tj]) / prm.lmg_q[tj]) / prm.lmg_fcnt[tj];
-        }
-        uint32_t klo = 0, khi = KT;
-        if (pi != 0xffffffffu) { klo = pi * cpe * Q0; khi = klo + cpe * Q0; }
-        if (pj != 0xffffffffu) {
-          if (pi != 0xffffffffu && pi != pj) khi = klo;  // columns of different primary levels never share a row
-          else { klo = pj * cpe * Q0; khi = klo + cpe * Q0; }
-        }
-        khi = khi < KT ? khi : KT;
-        double sacc = m.S[lmg_tri(i, j)];
-        const uint32_t cj2 = lmg_cpos(prm, compact, j);
-        for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * Wc + ci2] * m.B[(size_t)k * Wc + cj2];
-        m.S[lmg_tri(i, j)] = sacc;
+      if (j < R) {
+        const uint32_t tj = lmg_rest_term(prm, j);
+        if (prm.lmg_frel[tj] == 1u) pj = ((j - prm.lmg_froff[tj]) / prm.lmg_q[tj]) / prm.lmg_fcnt[tj];
       }
+      uint32_t klo = 0, khi = KT;
+      if (pi != 0xffffffffu) { klo = pi * cpe * Q0; khi = klo + cpe * Q0; }
+      if (pj != 0xffffffffu) {
+        if (pi != 0xffffffffu && pi != pj) khi = klo;  // columns of different primary levels never share a row
+        else { klo = pj * cpe * Q0; khi = klo + cpe * Q0; }
+      }
+      khi = khi < KT ? khi : KT;
+      const uint32_t ci2 = lmg_cpos(prm, compact, i), cj2 = lmg_cpos(prm, compact, j);
+      double sacc = m.S[en];
+      for (uint32_t k = klo; k < khi; ++k) sacc -= m.B[(size_t)k * Wc + ci2] * m.B[(size_t)k * Wc + cj2];
+      m.S[en] = sacc;
     }
   }
   lmg_sync();
@@ -368,24 +376,21 @@ __device__ __forceinline__ double lmg_eval_red(const SimParams& prm, const LmgLd
   auto theta_of = [&](uint32_t term) { return th[term]; };
   auto dropped = [&](uint32_t i) { return i >= Rr && i < M && !((red.keep >> (i - Rr)) & 1u); };
   // ---- S (lower triangle): theta_tj (theta_ti G) on the rest block + I, pass-through elsewhere, identity for dropped X ----
-  for (uint32_t i = 0; i < W; ++i) {
-    uint32_t ti;
+  for (uint32_t en = lane; en < (uint32_t)lmg_tri(W, 0u); en += GW) {  // lane = entry (lmg_tri_decode)
+    uint32_t i, j, ti, tj;
+    lmg_tri_decode(en, i, j);
     const uint32_t fi = lmg_red_col(prm, i, Rr, ti);
-    const bool di = dropped(i);
-    for (uint32_t j = lane; j <= i; j += GW) {
-      uint32_t tj;
-      const uint32_t fj = lmg_red_col(prm, j, Rr, tj);
-      double acc;
-      if (di || dropped(j)) {
-        acc = i == j ? 1.0 : 0.0;
-      } else {
-        const double g = fi >= fj ? m.gww[lmg_tri(fi, fj)] : m.gww[lmg_tri(fj, fi)];
-        const double inner = i < Rr ? 0.0 + theta_of(ti) * g : g;
-        acc = j < Rr ? 0.0 + theta_of(tj) * inner : inner;
-        if (i == j && i < Rr) acc += 1.0;
-      }
-      m.S[lmg_tri(i, j)] = acc;
+    const uint32_t fj = lmg_red_col(prm, j, Rr, tj);
+    double acc;
+    if (dropped(i) || dropped(j)) {
+      acc = i == j ? 1.0 : 0.0;
+    } else {
+      const double g = fi >= fj ? m.gww[lmg_tri(fi, fj)] : m.gww[lmg_tri(fj, fi)];
+      const double inner = i < Rr ? 0.0 + theta_of(ti) * g : g;
+      acc = j < Rr ? 0.0 + theta_of(tj) * inner : inner;
+      if (i == j && i < Rr) acc += 1.0;
     }
+    m.S[en] = acc;
   }
   lmg_sync();
   // ---- primary blocks (scalars): lane = level ----
@@ -411,12 +416,13 @@ __device__ __forceinline__ double lmg_eval_red(const SimParams& prm, const LmgLd
   ok = __ballot(!ok) == 0ull;
   lmg_sync();
   for (uint32_t c = 0; c < L0; ++c) logdet += m.ld[c];
-  for (uint32_t i = 0; i < W; ++i)
-    for (uint32_t j = lane; j <= i; j += GW) {
-      double sacc = m.S[lmg_tri(i, j)];
-      for (uint32_t k = 0; k < L0; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
-      m.S[lmg_tri(i, j)] = sacc;
-    }
+  for (uint32_t en = lane; en < (uint32_t)lmg_tri(W, 0u); en += GW) {
+    uint32_t i, j;
+    lmg_tri_decode(en, i, j);
+    double sacc = m.S[en];
+    for (uint32_t k = 0; k < L0; ++k) sacc -= m.B[(size_t)k * W + i] * m.B[(size_t)k * W + j];
+    m.S[en] = sacc;
+  }
   lmg_sync();
   // ---- dense Cholesky over [rest | X]; dropped columns are identities and stay out of the pivot products ----
   for (uint32_t j = 0; j < M; ++j) {
