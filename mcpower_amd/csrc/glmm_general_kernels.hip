@@ -364,22 +364,40 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
     }
     for (uint32_t e = lane; e < R * RS; e += QW) m.M[e] = 0.0;
     gq_sync();
-    // ---- lane = level of term t: the columns of I + A'WA (and the entries of A'W(z - eta0)) that level owns ----
+    // ---- (a) per level of every term: its diagonal block of I + A'WA and its entries of A'W(z - eta0).  2^k lanes share a level
+    //      (contiguous chunks of its rows; the first lane adds the partial sums of the others in lane order: a fixed
+    //      association).  Until round 3 one lane per level walked the level's 30-80 rows AND updated the strips against the
+    //      later terms: 6-16 busy lanes, ~10^4 wave-instructions per Fisher step -- nine tenths of an evaluation ----
+    const bool fixedc = prm.cluster_fixed_clusters != 0u;
+    // rows of level l of term t: slot s of [0, cnt) -> row (ascending); extra terms list rows past this grid point's n last
+    auto level_rows = [&](uint32_t t, uint32_t l, uint32_t& first, uint32_t& step, uint32_t& cnt) {
+      if (t == 0u) {
+        first = fixedc ? l : l * cv;
+        step = fixedc ? cv : 1u;
+        const uint32_t last = fixedc ? n : ((l + 1u) * cv < n ? (l + 1u) * cv : n);
+        cnt = first < last ? (last - first + step - 1u) / step : 0u;
+      } else {
+        first = (uint32_t)m.lstart[pick3(m.so, t) + l];
+        step = 1u;
+        cnt = (uint32_t)m.lstart[pick3(m.so, t) + l + 1u] - first;
+      }
+    };
     for (uint32_t t = 0; t < nterms; ++t) {
       const uint32_t q = prm.lmg_q[t], nl = t == 0u ? ncl : prm.lmg_levels[t];
-      uint32_t ns = 1u;  // the LAST extra term owns no strips: with few levels its rows are split over 2^k lanes per level
-      if (t != 0u && t + 1u == nterms)
-        while (nl * ns * 2u <= (uint32_t)QW && ns < 16u) ns *= 2u;
-      if (ns > 1u) {
-        const uint32_t l = lane / ns, sub = lane % ns;
+      uint32_t ns = 1u;
+      while (nl * ns * 2u <= (uint32_t)QW && ns < 16u) ns *= 2u;
+      const uint32_t per_pass = (uint32_t)QW / ns;
+      for (uint32_t lb = 0; lb < nl; lb += per_pass) {
+        const uint32_t l = lb + lane / ns, sub = lane % ns;
         double rl[3] = {0.0, 0.0, 0.0}, bl[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
         if (l < nl) {
-          const uint32_t first = (uint32_t)m.lstart[pick3(m.so, t) + l], last = (uint32_t)m.lstart[pick3(m.so, t) + l + 1u];
-          const uint32_t chunk = (last - first + ns - 1u) / ns;
-          const uint32_t lo = first + sub * chunk, hi = lo + chunk < last ? lo + chunk : last;
-          for (uint32_t s = lo; s < hi; ++s) {
-            const uint32_t i = (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + s];
-            if (i >= n) break;
+          uint32_t first, step, cnt;
+          level_rows(t, l, first, step, cnt);
+          const uint32_t chunk = (cnt + ns - 1u) / ns;
+          const uint32_t lo = sub * chunk, hi = lo + chunk < cnt ? lo + chunk : cnt;
+          for (uint32_t sl = lo; sl < hi; ++sl) {
+            const uint32_t i = t == 0u ? first + sl * step : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + first + sl];
+            if (i >= n) break;  // ascending within a level: the rest lies past this grid point's sample
             double a[3];
             gg_row_term<P>(prm, m, t, i, n_pad, a);
             const double w = m.wrow[i], rs = m.res[i];
@@ -392,8 +410,7 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
             }
           }
         }
-        // the level's first lane adds the partial sums of the others in lane order: a fixed association
-        for (uint32_t s2 = 1; s2 < ns; ++s2) {
+        for (uint32_t s2 = 1; s2 < ns; ++s2) {  // the level's first lane adds the partial sums of the others in lane order
           const int src = (int)((lane & ~(ns - 1u)) + s2);
 #pragma unroll
           for (int b = 0; b < 3; ++b) {
@@ -409,7 +426,7 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
         }
         if (sub == 0u && l < nl) {
           const uint32_t colbase = pick3(m.off, t) + l * q;
-          #pragma unroll
+#pragma unroll
           for (int b = 0; b < 3; ++b)
             if ((uint32_t)b < q) {
               m.r[colbase + (uint32_t)b] = rl[b];
@@ -418,58 +435,56 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
                 if (dd <= b) m.M[(size_t)(colbase + (uint32_t)b) * RS + colbase + (uint32_t)dd] = bl[b][dd] + (b == dd ? 1.0 : 0.0);
             }
         }
-        gq_sync();
-        continue;
       }
-      for (uint32_t l = lane; l < nl; l += QW) {
-        double rl[3] = {0.0, 0.0, 0.0}, bl[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-        // rows of the level: an arithmetic progression for the primary grouping, the level's slice of the row list else
-        const uint32_t first = t == 0u ? (prm.cluster_fixed_clusters ? l : l * cv) : (uint32_t)m.lstart[pick3(m.so, t) + l];
-        const uint32_t step = t == 0u ? (prm.cluster_fixed_clusters ? cv : 1u) : 1u;
-        const uint32_t last = t == 0u ? (prm.cluster_fixed_clusters ? n : ((l + 1u) * cv < n ? (l + 1u) * cv : n))
-                                      : (uint32_t)m.lstart[pick3(m.so, t) + l + 1u];
-        const uint32_t colbase = pick3(m.off, t) + l * q;
-        for (uint32_t s = first; s < last; s += step) {
-          const uint32_t i = t == 0u ? s : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + s];
-          if (i >= n) break;  // ascending within a level: the rest lies past this grid point's sample
-          double a[3];
-          gg_row_term<P>(prm, m, t, i, n_pad, a);
-          const double w = m.wrow[i], rs = m.res[i];
-#pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            rl[b] += rs * a[b];
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd)
-              if (dd <= b) bl[b][dd] += w * a[b] * a[dd];
-          }
-          for (uint32_t t2 = t + 1u; t2 < nterms; ++t2) {  // strips against later terms: rows of the later term, my columns
-            double a2[3];
-            const uint32_t l2 = gg_row_term<P>(prm, m, t2, i, n_pad, a2);
-            const uint32_t q2 = prm.lmg_q[t2], rowbase = pick3(m.off, t2) + l2 * q2;
-            // the lower triangle: the entry lives in the row of whichever term sits later in the index layout (this lane owns
-            // the indices colbase.. either way, so no two lanes touch one entry)
-            const bool mine_below = colbase > rowbase;
+    }
+    // ---- (b) the strips between two terms: lane = one (level of the earlier term, level of the later term) pair.  It walks the
+    //      rows of the earlier term's level in ascending order and adds those that sit in its level of the later term -- the order
+    //      in which the level-owning lane used to add them, so every entry keeps its bits.  A grouping nested in the primary
+    //      one only pairs a child with its own parent ----
+    for (uint32_t t = 0; t + 1u < nterms; ++t)
+      for (uint32_t t2 = t + 1u; t2 < nterms; ++t2) {
+        const uint32_t q = prm.lmg_q[t], q2 = prm.lmg_q[t2];
+        const uint32_t nl = t == 0u ? ncl : prm.lmg_levels[t], nl2 = prm.lmg_levels[t2];
+        const bool child = t == 0u && prm.lmg_relation[t2] == 1u;
+        const uint32_t cnt2 = prm.lmg_count[t2];
+        const uint32_t npairs = child ? nl2 : nl * nl2;
+        for (uint32_t pe = lane; pe < npairs; pe += QW) {
+          const uint32_t l = child ? pe / cnt2 : pe / nl2, l2 = child ? pe : pe % nl2;
+          if (l >= nl) continue;  // children of clusters past this grid point's sample
+          double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+          // walk the rows of whichever of the two levels is the smaller one (the term with more levels), ascending either way
+          const bool walk2 = nl2 > nl;
+          const uint32_t tw = walk2 ? t2 : t, lw = walk2 ? l2 : l, to = walk2 ? t : t2, lo2 = walk2 ? l : l2;
+          uint32_t first, step, cnt;
+          level_rows(tw, lw, first, step, cnt);
+          for (uint32_t sl = 0; sl < cnt; ++sl) {
+            const uint32_t i = tw == 0u ? first + sl * step : (uint32_t)m.rows[(size_t)(tw - 1u) * n_pad + first + sl];
+            if (i >= n) break;
+            const uint32_t lother = to == 0u ? gg_level_of_row(prm, 0u, i) : (uint32_t)m.lvl[(size_t)(to - 1u) * n_pad + i];
+            if (lother != lo2) continue;
+            double a[3], a2[3];
+            gg_row_term<P>(prm, m, t, i, n_pad, a);
+            gg_row_term<P>(prm, m, t2, i, n_pad, a2);
+            const double w = m.wrow[i];
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2)
 #pragma unroll
-              for (int b = 0; b < 3; ++b)
-                if ((uint32_t)b2 < q2 && (uint32_t)b < q) {
-                  const uint32_t ra = rowbase + (uint32_t)b2, ca = colbase + (uint32_t)b;
-                  m.M[mine_below ? (size_t)ca * RS + ra : (size_t)ra * RS + ca] += w * a2[b2] * a[b];
-                }
+              for (int b = 0; b < 3; ++b) acc[b2][b] += w * a2[b2] * a[b];
           }
+          // the lower triangle: the entry lives in the row of whichever term sits later in the index layout
+          const uint32_t colbase = pick3(m.off, t) + l * q, rowbase = pick3(m.off, t2) + l2 * q2;
+          const bool mine_below = colbase > rowbase;
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+              if ((uint32_t)b2 < q2 && (uint32_t)b < q) {
+                const uint32_t ra = rowbase + (uint32_t)b2, ca = colbase + (uint32_t)b;
+                m.M[mine_below ? (size_t)ca * RS + ra : (size_t)ra * RS + ca] = acc[b2][b];
+              }
         }
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-          if ((uint32_t)b < q) {
-            m.r[colbase + (uint32_t)b] = rl[b];
-#pragma unroll
-            for (int dd = 0; dd < 3; ++dd)
-              if (dd <= b) m.M[(size_t)(colbase + (uint32_t)b) * RS + colbase + (uint32_t)dd] = bl[b][dd] + (b == dd ? 1.0 : 0.0);
-          }
       }
-      gq_sync();
-    }
+    gq_sync();
     // levels past this grid point's sample (FixedSize sizing) hold no rows: identity rows, zero modes
     for (uint32_t a = lane; a < R; a += QW) {
       if (m.M[(size_t)a * RS + a] == 0.0) {
