@@ -5,9 +5,11 @@
 // over all R = sum_t q_t L_t random effects, following oracle/fit_glmm_general.c operation for operation.
 //
 // One wavefront per replicate, everything in LDS (R <= ~115: the R x R system is the big tenant).  One Fisher
-// step: lane = row evaluates the family kernel (weight, working residual, deviance); then, term by term, lane = level
-// folds the rows of that level into the columns of I + A'WA it OWNS (its own q x q block and the strips against
-// later terms) -- no two lanes ever touch the same entry, and every entry sums its rows in row order; a
+// step: lane = row evaluates the family kernel (weight, working residual, deviance); then I + A'WA is assembled with every
+// lane busy -- 2^k lanes share a level for its q x q diagonal block and right-hand side (contiguous chunks of its rows, the
+// partial sums added in lane order: a fixed association), one lane per (level, level) pair for the strips between two
+// terms (it walks the smaller level's rows in ascending order: every strip entry sums its rows in row order) -- no two
+// lanes ever touch the same entry; a
 // right-looking dense Cholesky with lane = row (entries update in ascending pivot order: the oracle's dot-product
 // order) skips exact zeros, which is most of the primary block-diagonal part; two triangular solves give the step.
 // Wald covariance "rx": X'WX - (A'WX)' (I + A'WA)^-1 (A'WX) from the last factor.
