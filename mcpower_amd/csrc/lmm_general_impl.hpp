@@ -292,33 +292,30 @@ __device__ __forceinline__ double lmg_eval(const SimParams& prm, const LmgLds m,
     }
   }
   lmg_sync();
-  // ---- left-looking Cholesky over [rest | X], y is the last row ----
+  // ---- Cholesky over [rest | X], y is the last row: right-looking, one ENTRY of the trailing triangle per lane.  Every entry
+  //      still loses its pivot products in ascending pivot order and is divided last -- the operation sequence of the left-looking
+  //      form (lane = row, a k-loop of length j per column: W^2 / 2 dependent steps) with W (W + 1) / 128 trips per column ----
   const uint32_t M = R + p;
   for (uint32_t j = 0; j < M; ++j) {
-    double vv[2] = {0.0, 0.0};
-    uint32_t cntr = 0;
-    for (uint32_t i = j + lane; i < W; i += GW) {
-      double v = m.S[lmg_tri(i, j)];
-      for (uint32_t k = 0; k < j; ++k) v -= m.S[lmg_tri(i, k)] * m.S[lmg_tri(j, k)];
-      vv[cntr++] = v;
-      if (i == j) m.misc[1] = v;
-    }
-    lmg_sync();
-    const double d = m.misc[1];
+    const double d = m.S[lmg_tri(j, j)];  // finished: every earlier column has been subtracted
     ok = ok && (d > 0.0) && (d < inf);
     const double ljj = __builtin_sqrt(d);
     pd *= d;
     if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; }
-    cntr = 0;
-    for (uint32_t i = j + lane; i < W; i += GW) {
-      m.S[lmg_tri(i, j)] = i == j ? ljj : vv[cntr] / ljj;
-      ++cntr;
+    lmg_sync();  // every lane holds the pivot
+    for (uint32_t i = j + lane; i < W; i += GW) m.S[lmg_tri(i, j)] = i == j ? ljj : m.S[lmg_tri(i, j)] / ljj;
+    lmg_sync();
+    const uint32_t T = W - j - 1u;  // rows j + 1 .. W - 1
+    for (uint32_t en = lane; en < (uint32_t)lmg_tri(T, 0u); en += GW) {
+      uint32_t a, b;
+      lmg_tri_decode(en, a, b);
+      const uint32_t i = j + 1u + a, c = j + 1u + b;
+      m.S[lmg_tri(i, c)] -= m.S[lmg_tri(i, j)] * m.S[lmg_tri(c, j)];
     }
     lmg_sync();
   }
   logdet += log(pd);
-  double pwrss = m.S[lmg_tri(M, M)];
-  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[lmg_tri(M, k)] * m.S[lmg_tri(M, k)];
+  const double pwrss = m.S[lmg_tri(M, M)];  // y'y minus the squares of the y row, in column order
   const double dfr = n_rows - (double)p;
   double lmin = inf, lmax = 0.0;
   for (uint32_t a = 0; a < p; ++a) {
@@ -424,34 +421,30 @@ __device__ __forceinline__ double lmg_eval_red(const SimParams& prm, const LmgLd
     m.S[en] = sacc;
   }
   lmg_sync();
-  // ---- dense Cholesky over [rest | X]; dropped columns are identities and stay out of the pivot products ----
+  // ---- dense Cholesky over [rest | X] (right-looking, lane = entry, as lmg_eval); a dropped column is an identity: its
+  //      products are exact zeros and its pivot stays out of the determinant ----
   for (uint32_t j = 0; j < M; ++j) {
-    double vv[2] = {0.0, 0.0};
-    uint32_t cntr = 0;
-    for (uint32_t i = j + lane; i < W; i += GW) {
-      double v = m.S[lmg_tri(i, j)];
-      for (uint32_t k = 0; k < j; ++k) v -= m.S[lmg_tri(i, k)] * m.S[lmg_tri(j, k)];
-      vv[cntr++] = v;
-      if (i == j) m.misc[1] = v;
-    }
-    lmg_sync();
-    const double dj = m.misc[1];
+    const double dj = m.S[lmg_tri(j, j)];
     ok = ok && (dj > 0.0) && (dj < inf);
     const double ljj = __builtin_sqrt(dj);
     if (!dropped(j)) {
       pd *= dj;
       if (++npd == 4u) { logdet += log(pd); pd = 1.0; npd = 0; }
     }
-    cntr = 0;
-    for (uint32_t i = j + lane; i < W; i += GW) {
-      m.S[lmg_tri(i, j)] = i == j ? ljj : vv[cntr] / ljj;
-      ++cntr;
+    lmg_sync();
+    for (uint32_t i = j + lane; i < W; i += GW) m.S[lmg_tri(i, j)] = i == j ? ljj : m.S[lmg_tri(i, j)] / ljj;
+    lmg_sync();
+    const uint32_t T = W - j - 1u;
+    for (uint32_t en = lane; en < (uint32_t)lmg_tri(T, 0u); en += GW) {
+      uint32_t a, b;
+      lmg_tri_decode(en, a, b);
+      const uint32_t i = j + 1u + a, c = j + 1u + b;
+      m.S[lmg_tri(i, c)] -= m.S[lmg_tri(i, j)] * m.S[lmg_tri(c, j)];
     }
     lmg_sync();
   }
   logdet += log(pd);
-  double pwrss = m.S[lmg_tri(M, M)];
-  for (uint32_t k = 0; k < M; ++k) pwrss -= m.S[lmg_tri(M, k)] * m.S[lmg_tri(M, k)];
+  const double pwrss = m.S[lmg_tri(M, M)];
   const double dfr = n_rows - (double)red.p_fit;
   double lmin = inf, lmax = 0.0;
   for (uint32_t a = 0; a < p; ++a) {
