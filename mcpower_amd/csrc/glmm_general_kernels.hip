@@ -450,6 +450,37 @@ __device__ __forceinline__ double glmm_eval(const SimParams& prm, const GlmmLds&
         const bool child = t == 0u && prm.lmg_relation[t2] == 1u;
         const uint32_t cnt2 = prm.lmg_count[t2];
         const uint32_t npairs = child ? nl2 : nl * nl2;
+        // ... unless the pairs outnumber the lanes by more than the walk gets shorter (many levels of few rows each, e.g. 24
+        // clusters x 6 items): then the earlier term's level walks its rows once and updates its own strip entries, as before
+        const uint32_t big = nl > nl2 ? nl : nl2;
+        const uint32_t steps_pairs = ((npairs + (uint32_t)QW - 1u) / (uint32_t)QW) * (n / (big ? big : 1u));
+        const uint32_t steps_level = ((nl + (uint32_t)QW - 1u) / (uint32_t)QW) * (n / (nl ? nl : 1u));
+        if (steps_pairs > steps_level) {
+          for (uint32_t l = lane; l < nl; l += QW) {
+            uint32_t first, step, cnt;
+            level_rows(t, l, first, step, cnt);
+            const uint32_t colbase = pick3(m.off, t) + l * q;
+            for (uint32_t sl = 0; sl < cnt; ++sl) {
+              const uint32_t i = t == 0u ? first + sl * step : (uint32_t)m.rows[(size_t)(t - 1u) * n_pad + first + sl];
+              if (i >= n) break;
+              double a[3], a2[3];
+              gg_row_term<P>(prm, m, t, i, n_pad, a);
+              const uint32_t l2 = gg_row_term<P>(prm, m, t2, i, n_pad, a2);
+              const uint32_t rowbase = pick3(m.off, t2) + l2 * q2;
+              const bool mine_below = colbase > rowbase;
+              const double w = m.wrow[i];
+#pragma unroll
+              for (int b2 = 0; b2 < 3; ++b2)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                  if ((uint32_t)b2 < q2 && (uint32_t)b < q) {
+                    const uint32_t ra = rowbase + (uint32_t)b2, ca = colbase + (uint32_t)b;
+                    m.M[mine_below ? (size_t)ca * RS + ra : (size_t)ra * RS + ca] += w * a2[b2] * a[b];
+                  }
+            }
+          }
+          continue;
+        }
         for (uint32_t pe = lane; pe < npairs; pe += QW) {
           const uint32_t l = child ? pe / cnt2 : pe / nl2, l2 = child ? pe : pe % nl2;
           if (l >= nl) continue;  // children of clusters past this grid point's sample

@@ -174,6 +174,10 @@ static double gg_f(gg_model* m, double* par, uint32_t* n_eval) {
   return gg_deviance(m, par);
 }
 
+/* no-tree-vectorize: gcc 11.4 at -O3 -march=native (the cpu_baseline build, AVX-512 hosts) emits an ALIGNED 32-byte load
+ * for the shrink loop below at an address that is only 16-byte aligned -- a #GP on the first shrink step (seen on the
+ * (1 + x1 | g) + (1 | item) bench shape).  The simplex arithmetic is a vanishing share of a fit; scalar code is exact too. */
+__attribute__((optimize("no-tree-vectorize")))
 static double gg_nelder_mead(gg_model* m, double* x0, double step, double ftol, double xtol, uint32_t* n_eval) {
   const uint32_t d = m->nth + m->p;
   double sx[GG_MAX_DIM + 1][GG_MAX_DIM], fv[GG_MAX_DIM + 1];
