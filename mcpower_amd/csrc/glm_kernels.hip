@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void reduce_counter_copies_kernel(const unsign
 hipError_t launch_reduce_counters(const unsigned long long* copies, uint32_t copy_stride, uint32_t n,
                                   unsigned long long* out, hipStream_t st) {
   static_assert(CTR_COPIES % 64 == 0, "one wave sums the copies of a word");
-  hipLaunchKernelGGL(reduce_counter_copies_kernel, dim3((n + 3u) / 4u), dim3(256), 0, st, copies, copy_stride, n, out);
+  // one wave per workgroup: a 256-thread workgroup needs four free wave slots on ONE CU at once and starved behind the next
+  // batch's single-wave workgroups (mean residence 27 ms for microseconds of work, profiles/r03_m_r03m_lmm_slope_kernel_stats.csv)
+  hipLaunchKernelGGL(reduce_counter_copies_kernel, dim3(n), dim3(64), 0, st, copies, copy_stride, n, out);
   return hipGetLastError();
 }
 
